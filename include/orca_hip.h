@@ -1,0 +1,210 @@
+/*
+ * orca_hip.h -- C ABI of liborca_hip.so: the MI355X (gfx950) implementation of Orca's temporal
+ * sample -> TGAT aggregate -> GRU memory / raw message -> embedding-reuse hot path.
+ *
+ * The reference (LuckyLYM/Orca) is pure Python + Numba and has no FFI of its own:
+ * its boundary is a set of Python classes.  The Python package orca_amd/ mirrors those classes
+ * one-for-one and binds these entry points with ctypes; INTEGRATION.md shows the binding a
+ * reference maintainer would add.  Each entry point cites the reference lines it replaces
+ * (paths relative to the LuckyLYM/Orca tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ORCA_E* code otherwise, and never throws;
+ *     orca_last_error() returns a thread-local message for the last failure;
+ *   - all array arguments are DEVICE pointers unless the name ends in _host; buffers are
+ *     caller-owned; nothing here allocates device memory except orca_csr_create_*;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous;
+ *   - node id 0 / edge id 0 are the padding entries of the reference's datasets
+ *     (utils/preprocess_data.py:55-57,78-79); node/memory/time widths are fixed at ORCA_D = 100
+ *     and the attention has 2 heads (train.py:24,56-58 defaults), the edge width d_e is a run-time
+ *     argument (<= ORCA_MAX_DE);
+ *   - handles are immutable after creation; mutable tables are single-writer per stream.
+ */
+#ifndef ORCA_HIP_H
+#define ORCA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORCA_D 100          /* node / memory / time feature width */
+#define ORCA_HEADS 2
+#define ORCA_MAX_DE 192     /* widest supported edge feature row */
+#define ORCA_MAX_K 20       /* most neighbours per query in orca_tgat_forward */
+
+#define ORCA_OK 0
+#define ORCA_EINVAL -1      /* bad argument (ValueError / assert upstream) */
+#define ORCA_EHIP -2        /* HIP runtime failure */
+#define ORCA_ENOMEM -3
+#define ORCA_ERANGE -4      /* node id out of range (IndexError upstream) */
+
+typedef struct orca_csr orca_csr_t;   /* opaque time-sorted CSR living in HBM */
+
+const char* orca_last_error(void);
+int orca_version(void);
+
+/* ---- sampler: utils/util.py:91-151 ------------------------------------------------------ */
+
+/* get_neighbor_finder (utils/util.py:91-105): undirected per-node adjacency, each list stably
+ * sorted by timestamp, stored as int32 nbr / int32 edge idx / float64 ts.  n_rows = max_node_idx+1.
+ * _host: arrays in host memory, built on the host and uploaded to `device`.
+ * _device: arrays already in HBM on the current device, built there (radix sorts). */
+int orca_csr_create_host(int64_t n_edges, const int64_t* src_host, const int64_t* dst_host,
+                         const int64_t* eidx_host, const double* ts_host, int64_t n_rows, int device,
+                         orca_csr_t** out);
+int orca_csr_create_device(int64_t n_edges, const int64_t* src, const int64_t* dst, const int64_t* eidx,
+                           const double* ts, int64_t n_rows, void* stream, orca_csr_t** out);
+/* NeighborFinder(node_to_neighbors, node_to_edge_idxs, node_to_edge_timestamps) (utils/util.py:123-126):
+ * adopts ragged lists that are already flattened (host arrays, each list time-sorted). */
+int orca_csr_from_arrays_host(int64_t n_rows, const int64_t* indptr_host, const int32_t* nbr_host,
+                              const int32_t* eidx_host, const double* ts_host, int device, orca_csr_t** out);
+int orca_csr_destroy(orca_csr_t* csr);
+/* device pointers of the CSR arrays (for tests / export); any out pointer may be NULL */
+int orca_csr_arrays(const orca_csr_t* csr, int64_t* n_rows, int64_t* nnz, const int64_t** indptr,
+                    const int32_t** nbr, const int32_t** eidx, const double** ts);
+
+/* NeighborFinder.get_temporal_neighbor (utils/util.py:134-151) + the Δt of
+ * modules/embedding_module.py:130-131.  Outputs are [Q, K] row-major, right-aligned, zero padded;
+ * neighbours are STRICTLY before t (np.searchsorted side='left').  out_dt may be NULL.  K >= 1
+ * (the K == 0 quirk of :136 is handled by the Python shim).  Node ids outside [0, n_rows) set
+ * *err_flag (device int, may be NULL) and produce an all-padding row. */
+int orca_sample_recent(const orca_csr_t* csr, const int64_t* nodes, const double* ts, int64_t Q, int K,
+                       int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
+                       int* err_flag, void* stream);
+/* NeighborFinder.find_before (utils/util.py:129-131): out_count[q] = #entries of nodes[q] before ts[q]. */
+int orca_find_before(const orca_csr_t* csr, const int64_t* nodes, const double* ts, int64_t Q,
+                     int64_t* out_count, void* stream);
+/* Not in the reference ("parity unpinned"): K draws with replacement among the
+ * entries before t from a counter RNG keyed (seed, query, slot), returned in time order. */
+int orca_sample_uniform(const orca_csr_t* csr, const int64_t* nodes, const double* ts, int64_t Q, int K,
+                        uint64_t seed, int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
+                        int* err_flag, void* stream);
+
+/* ---- time encoder: model/time_encoding.py:23-28 ------------------------------------------ */
+/* out[i, :] = cos(t[i] * w + b), w,b [ORCA_D] */
+int orca_time_encode(const float* t, int64_t n, const float* w, const float* b, float* out, void* stream);
+
+/* ---- TGAT attention layer: model/temporal_attention.py:24-56 ----------------------------- */
+
+/* Number of floats of the packed parameter blob for edge width d_e. */
+int64_t orca_tgat_blob_floats(int d_e);
+/* Re-lays one TemporalAttentionLayer's parameters (nn.MultiheadAttention with kdim != embed_dim,
+ * MergeLayer utils/util.py:12-24, LayerNorm) into MFMA-fragment order.  Inputs are the raw
+ * row-major state_dict tensors; must be re-run after the parameters change. */
+int orca_tgat_pack(int d_e, const float* q_proj_w, const float* k_proj_w, const float* v_proj_w,
+                   const float* in_proj_b, const float* out_proj_w, const float* out_proj_b,
+                   const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                   const float* ln_w, const float* ln_b, float* blob, void* stream);
+
+/* Where the rows of one attention call come from.  Two modes:
+ *  gather: rows are fetched by index from feature tables (the fused path used by
+ *          modules/embedding_module.py:116-285), time features are computed in-kernel;
+ *  dense:  the six dense tensors of TemporalAttentionLayer.forward (the drop-in boundary). */
+typedef struct {
+  /* source-node rows [*,ORCA_D]: row = src_idx ? src_idx[q] : q.  If src_flags && src_flags[row]
+   * the row is read from src_overlay instead (memory with pending messages applied). */
+  const float* src_table;
+  const int32_t* src_idx;
+  const float* src_overlay;
+  const uint8_t* src_flags;
+  /* neighbour rows: row = nbr_idx[q*K+j] (gather) or q*K+j (nbr_idx == NULL, dense) */
+  const float* nbr_table;
+  const int32_t* nbr_idx;
+  const float* nbr_overlay;
+  const uint8_t* nbr_flags;
+  /* padding mask: nbr_ids[q*K+j] == 0 (embedding_module.py:134) or, if nbr_ids == NULL, mask bytes
+   * (torch.bool, true = padded).  In mask mode the all-padded fix-up of temporal_attention.py:46-47
+   * is written back into `mask`, as the reference mutates its argument. */
+  const int32_t* nbr_ids;
+  uint8_t* mask;
+  /* edge rows [*, d_e]: row = edge_idx[q*K+j], or q*K+j when edge_idx == NULL */
+  const float* edge_table;
+  const int32_t* edge_idx;
+  /* time features: computed as cos(dt*w+b) when dt != NULL (src uses dt = 0), else read from
+   * src_time [Q,ORCA_D] and nbr_time [Q*K,ORCA_D] */
+  const float* dt;
+  const float* time_w;
+  const float* time_b;
+  const float* src_time;
+  const float* nbr_time;
+} orca_tgat_inputs;
+
+/* out [Q, ORCA_D]; out_weights [Q, K] (head-averaged attention, may be NULL).  1 <= K <= ORCA_MAX_K. */
+int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
+                      float* out, float* out_weights, void* stream);
+
+/* ---- GRU memory updater: modules/memory_updater.py:25-86 --------------------------------- */
+
+int64_t orca_gru_blob_floats(int msg_dim);
+/* nn.GRUCell(msg_dim -> ORCA_D) parameters (weight_ih [300,msg_dim], weight_hh [300,100], biases) */
+int orca_gru_pack(int msg_dim, const float* weight_ih, const float* weight_hh, const float* bias_ih,
+                  const float* bias_hh, float* blob, void* stream);
+/* For r in [0, n): id = ids ? ids[r] : r;  out[id] = GRUCell(x[id], h[id]).  n is read from *n_dev
+ * when n_dev != NULL (device-resident work-list length; rows >= *n_dev are skipped and `n` is
+ * then the launch upper bound).  out may alias h (in-place persist, update_memory :25-39) or be the
+ * overlay table (get_updated_memory :56-78 without the full-table clone).  If last_update != NULL,
+ * last_update[id] = msg_ts[id] (:37). */
+int orca_gru_update(const float* blob, int msg_dim, const int32_t* ids, int64_t n, const int32_t* n_dev,
+                    const float* x, const float* h, float* out, float* last_update, const float* msg_ts,
+                    void* stream);
+
+/* ---- node-id bookkeeping that the reference does with NumPy on the host ------------------- */
+
+/* Append to worklist every distinct id of the concatenation of ids32 (n32 int32 values, e.g. the
+ * sampled neighbours) and ids64 (n64 int64 values, e.g. the roots) whose flags[id] != 0 (flags may
+ * be NULL = take all).  `stamp` is an int32 [n_nodes] scratch table owned by the caller, `epoch` a
+ * value never used before on it (replaces np.unique + memory.nodes[index] of
+ * modules/memory_updater.py:60-65 and embedding_module.py:121,160).  *count must be zeroed by the
+ * caller (orca_fill_i32).  Order of the work-list is unspecified. */
+int orca_worklist_build(const int32_t* ids32, int64_t n32, const int64_t* ids64, int64_t n64,
+                        const uint8_t* flags, int32_t* stamp, int32_t epoch, int64_t n_nodes,
+                        int32_t* worklist, int32_t* count, void* stream);
+int orca_fill_i32(int32_t* p, int64_t n, int32_t v, void* stream);
+int orca_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream);
+/* flags[ids[i]] = v for i < n (ids int64, or the int32 work-list when ids64 == NULL) */
+int orca_set_flags(uint8_t* flags, const int64_t* ids64, const int32_t* ids32, int64_t n,
+                   const int32_t* n_dev, uint8_t v, void* stream);
+
+/* ---- raw messages: model/tgn_model.py:131-141,172-191 + modules/memory.py:25-28 ----------- */
+
+/* Last-occurrence segment reduce ("scatter-argmax keyed by node id"): for the id list
+ * ids[0..M) marks winner[p] = 1 iff no later position holds the same id
+ * (np.unique(np.flip(ids), return_index=True), tgn_model.py:174-176; also the 'last' rule of
+ * modules/message_aggregator.py:38-54).  `slot` is a caller-owned int64 [n_nodes] scratch table,
+ * `epoch` a value greater than any used before on it. */
+int orca_segment_last(const int64_t* ids, int64_t M, int64_t* slot, int64_t epoch, int64_t n_nodes,
+                      uint8_t* winner, void* stream);
+/* modules/message_aggregator.py:61-81: per distinct id the mean of its rows (arrival order) and the
+ * timestamp of its last row, written at the id's LAST position p (winner[p] = 1). */
+int orca_segment_mean(const int64_t* ids, int64_t M, int64_t D, const float* msgs, const float* ts,
+                      int64_t* slot, int64_t epoch, int64_t n_nodes, uint8_t* winner, float* out_msgs,
+                      void* stream);
+/* For the batch (src,dst,eidx,t)[bs]: ids = [src;dst], partner = [dst;src]; for every last
+ * occurrence p:  messages[id] = [memory[id] | memory[partner] | edge_feats[eidx] |
+ * cos((fp32(t) - last_update[id]) * w + b)], msg_ts[id] = fp32(t), pending[id] = 1. */
+int orca_message_store(const int64_t* src, const int64_t* dst, const int64_t* eidx, const double* t,
+                       int64_t bs, const float* memory, const float* last_update,
+                       const float* edge_feats, int d_e, const float* time_w, const float* time_b,
+                       int64_t* slot, int64_t epoch, int64_t n_nodes,
+                       float* messages, float* msg_ts, uint8_t* pending, void* stream);
+
+/* ---- embedding-reuse cache: modules/history.py:25-46, embedding_module.py:103-113,186-212 - */
+
+/* History.push (history.py:38-40): emb[ids[p]] = x[p]; duplicate ids resolve to the LAST position
+ * (SURVEY H7).  slot/epoch as in orca_segment_last. */
+int orca_history_push(float* emb, const float* x, const int64_t* ids, int64_t n, int64_t* slot,
+                      int64_t epoch, int64_t n_nodes, void* stream);
+/* History.pull (history.py:32-36) / any row gather: out[p] = table[idx[p]], rows of `width` floats.
+ * idx is int64, or int32 when idx64 == NULL. */
+int orca_gather_rows(const float* table, int64_t width, const int64_t* idx64, const int32_t* idx32,
+                     int64_t n, float* out, void* stream);
+/* out_table[ids[p]] = x[p] (ids unique; Memory.set_memory modules/memory.py:33-34) */
+int orca_scatter_rows(float* table, int64_t width, const int64_t* ids, int64_t n, const float* x,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORCA_HIP_H */

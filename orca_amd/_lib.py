@@ -1,0 +1,105 @@
+"""ctypes binding of liborca_hip.so (include/orca_hip.h).  There is no CPU fallback: if the
+library is missing or a call fails, this raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborca_hip.so")
+
+ORCA_D = 100
+ORCA_MAX_DE = 192
+ORCA_MAX_K = 20
+
+vp = ctypes.c_void_p
+i64 = ctypes.c_int64
+i32 = ctypes.c_int
+u64 = ctypes.c_uint64
+u8 = ctypes.c_uint8
+
+
+class TgatInputs(ctypes.Structure):
+  """orca_tgat_inputs (include/orca_hip.h)."""
+  _fields_ = [(n, vp) for n in (
+      "src_table", "src_idx", "src_overlay", "src_flags",
+      "nbr_table", "nbr_idx", "nbr_overlay", "nbr_flags",
+      "nbr_ids", "mask", "edge_table", "edge_idx",
+      "dt", "time_w", "time_b", "src_time", "nbr_time")]
+
+
+# name -> (restype, argtypes); every symbol include/orca_hip.h declares
+SIGNATURES = {
+    "orca_last_error": (ctypes.c_char_p, []),
+    "orca_version": (i32, []),
+    "orca_csr_create_host": (i32, [i64, vp, vp, vp, vp, i64, i32, ctypes.POINTER(vp)]),
+    "orca_csr_create_device": (i32, [i64, vp, vp, vp, vp, i64, vp, ctypes.POINTER(vp)]),
+    "orca_csr_from_arrays_host": (i32, [i64, vp, vp, vp, vp, i32, ctypes.POINTER(vp)]),
+    "orca_csr_destroy": (i32, [vp]),
+    "orca_csr_arrays": (i32, [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                              ctypes.POINTER(vp), ctypes.POINTER(vp)]),
+    "orca_sample_recent": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
+    "orca_find_before": (i32, [vp, vp, vp, i64, vp, vp]),
+    "orca_sample_uniform": (i32, [vp, vp, vp, i64, i32, u64, vp, vp, vp, vp, vp, vp]),
+    "orca_time_encode": (i32, [vp, i64, vp, vp, vp, vp]),
+    "orca_tgat_blob_floats": (i64, [i32]),
+    "orca_tgat_pack": (i32, [i32] + [vp] * 14),
+    "orca_tgat_forward": (i32, [vp, i32, ctypes.POINTER(TgatInputs), i64, i32, vp, vp, vp]),
+    "orca_gru_blob_floats": (i64, [i32]),
+    "orca_gru_pack": (i32, [i32, vp, vp, vp, vp, vp, vp]),
+    "orca_gru_update": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
+    "orca_worklist_build": (i32, [vp, i64, vp, i64, vp, vp, i32, i64, vp, vp, vp]),
+    "orca_fill_i32": (i32, [vp, i64, i32, vp]),
+    "orca_fill_u8": (i32, [vp, i64, u8, vp]),
+    "orca_set_flags": (i32, [vp, vp, vp, i64, vp, u8, vp]),
+    "orca_segment_last": (i32, [vp, i64, vp, i64, i64, vp, vp]),
+    "orca_segment_mean": (i32, [vp, i64, i64, vp, vp, vp, i64, i64, vp, vp, vp]),
+    "orca_message_store": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, vp]),
+    "orca_history_push": (i32, [vp, vp, vp, i64, vp, i64, i64, vp]),
+    "orca_gather_rows": (i32, [vp, i64, vp, vp, i64, vp, vp]),
+    "orca_scatter_rows": (i32, [vp, i64, vp, i64, vp, vp]),
+}
+
+_lib = None
+
+
+class OrcaError(RuntimeError):
+  pass
+
+
+def load():
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise OrcaError(f"{LIB_PATH} is missing: build it with `python -m orca_amd.build` "
+                      "(there is no CPU fallback for the HIP path)")
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+      fn = getattr(L, name)
+      fn.restype = res
+      fn.argtypes = args
+    _lib = L
+  return _lib
+
+
+def check(rc, what=""):
+  if rc != 0:
+    msg = load().orca_last_error().decode("utf-8", "replace")
+    if rc == -4:
+      raise IndexError(f"{what}: {msg}")
+    if rc == -1:
+      raise ValueError(f"{what}: {msg}")
+    raise OrcaError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+  """Device (or host) address of a contiguous torch tensor / numpy array; None -> NULL."""
+  if t is None:
+    return None
+  if hasattr(t, "data_ptr"):
+    assert t.is_contiguous(), "orca_amd: tensor must be contiguous"
+    return t.data_ptr()
+  return t.ctypes.data
+
+
+def stream():
+  import torch
+  return torch.cuda.current_stream().cuda_stream

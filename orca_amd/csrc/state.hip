@@ -1,0 +1,268 @@
+// Device-resident node-state bookkeeping: everything the reference does with NumPy on the host
+// between its GPU ops (np.unique, boolean flag arrays, last-occurrence dedupe, index_put / index_select).
+// All of it is HBM-bound integer / row-copy work: one wave per row, coalesced 4-byte lanes.
+#include "common.h"
+
+namespace {
+constexpr int D = ORCA_D;
+
+__global__ void k_time_encode(const float* __restrict__ t, int64_t n, const float* __restrict__ w,
+                              const float* __restrict__ b, float* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * D) return;
+  int c = (int)(i % D);
+  out[i] = cosf(t[i / D] * w[c] + b[c]);   // model/time_encoding.py:26-27
+}
+
+__global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_fill_u8(uint8_t* p, int64_t n, uint8_t v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void k_worklist(const int32_t* __restrict__ ids32, int64_t n32, const int64_t* __restrict__ ids64,
+                           int64_t n64, const uint8_t* __restrict__ flags, int32_t* stamp, int32_t epoch,
+                           int64_t n_nodes, int32_t* worklist, int32_t* count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n32 + n64) return;
+  int64_t id = i < n32 ? (int64_t)ids32[i] : ids64[i - n32];
+  if (id < 0 || id >= n_nodes) return;
+  if (flags && !flags[id]) return;
+  if (atomicExch(&stamp[id], epoch) == epoch) return;   // somebody else already claimed this id
+  int pos = atomicAdd(count, 1);
+  worklist[pos] = (int32_t)id;
+}
+
+__global__ void k_set_flags(uint8_t* flags, const int64_t* ids64, const int32_t* ids32, int64_t n,
+                            const int32_t* n_dev, uint8_t v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev && i >= *n_dev) return;
+  if (i >= n) return;
+  int64_t id = ids64 ? ids64[i] : (int64_t)ids32[i];
+  flags[id] = v;
+}
+
+// last-occurrence election: slot[id] = max over positions of (epoch + p)
+__global__ void k_elect(const int64_t* __restrict__ ids, int64_t M, int64_t* slot, int64_t epoch, int64_t n_nodes) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  int64_t id = ids[p];
+  if (id < 0 || id >= n_nodes) return;
+  atomicMax(reinterpret_cast<unsigned long long*>(&slot[id]), (unsigned long long)(epoch + p));
+}
+__global__ void k_elect2(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t bs, int64_t* slot,
+                         int64_t epoch, int64_t n_nodes) {   // ids = [a ; b]
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= 2 * bs) return;
+  int64_t id = p < bs ? a[p] : b[p - bs];
+  if (id < 0 || id >= n_nodes) return;
+  atomicMax(reinterpret_cast<unsigned long long*>(&slot[id]), (unsigned long long)(epoch + p));
+}
+__global__ void k_winner(const int64_t* __restrict__ ids, int64_t M, const int64_t* __restrict__ slot, int64_t epoch,
+                         int64_t n_nodes, uint8_t* winner) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  int64_t id = ids[p];
+  winner[p] = (id >= 0 && id < n_nodes && slot[id] == epoch + p) ? 1 : 0;
+}
+
+__global__ void k_segment_mean(const int64_t* __restrict__ ids, int64_t M, int64_t Dm, const float* __restrict__ msgs,
+                               const uint8_t* __restrict__ winner, float* __restrict__ out) {
+  const int64_t p = blockIdx.x;
+  if (!winner[p]) return;
+  const int64_t id = ids[p];
+  int cnt = 0;
+  for (int64_t i = 0; i <= p; ++i) cnt += (ids[i] == id);
+  const float inv = 1.0f / (float)cnt;
+  for (int64_t c = threadIdx.x; c < Dm; c += blockDim.x) {
+    float s = 0.0f;
+    for (int64_t i = 0; i <= p; ++i)
+      if (ids[i] == id) s += msgs[i * Dm + c];   // arrival order, as torch.mean over the stacked rows
+    out[p * Dm + c] = s * inv;
+  }
+}
+
+// model/tgn_model.py:172-191 + modules/memory.py:25-28, one wave per position of [src;dst]
+__global__ __launch_bounds__(256) void k_message_store(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                                       const int64_t* __restrict__ eidx, const double* __restrict__ t,
+                                                       int64_t bs, const float* __restrict__ memory,
+                                                       const float* __restrict__ last_update,
+                                                       const float* __restrict__ edge_feats, int d_e,
+                                                       const float* __restrict__ tw, const float* __restrict__ tb,
+                                                       const int64_t* __restrict__ slot, int64_t epoch,
+                                                       int64_t n_nodes, float* __restrict__ messages,
+                                                       float* __restrict__ msg_ts, uint8_t* __restrict__ pending) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= 2 * bs) return;
+  const int64_t e = p < bs ? p : p - bs;
+  const int64_t id = p < bs ? src[e] : dst[e];
+  const int64_t partner = p < bs ? dst[e] : src[e];
+  if (id < 0 || id >= n_nodes || slot[id] != epoch + p) return;   // not the last occurrence of id
+  const int msg_dim = 3 * D + d_e;
+  float* row = messages + id * msg_dim;
+  const float tf = (float)t[e];                                   // tgn_model.py:181
+  const float delta = tf - last_update[id];                       // :187
+  const float* ms = memory + id * D;
+  const float* md = memory + partner * D;
+  const float* ef = edge_feats + eidx[e] * d_e;
+  for (int c = lane; c < D; c += 64) {
+    row[c] = ms[c];
+    row[D + c] = md[c];
+    row[2 * D + d_e + c] = cosf(delta * tw[c] + tb[c]);           // :188
+  }
+  for (int c = lane; c < d_e; c += 64) row[2 * D + c] = ef[c];
+  if (lane == 0) {
+    msg_ts[id] = tf;
+    pending[id] = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_push_rows(float* __restrict__ emb, const float* __restrict__ x,
+                                                   const int64_t* __restrict__ ids, int64_t n,
+                                                   const int64_t* __restrict__ slot, int64_t epoch, int64_t n_nodes) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const int64_t id = ids[p];
+  if (id < 0 || id >= n_nodes || slot[id] != epoch + p) return;
+  for (int c = lane; c < D; c += 64) emb[id * D + c] = x[p * D + c];
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table, int64_t width,
+                                                     const int64_t* __restrict__ idx64,
+                                                     const int32_t* __restrict__ idx32, int64_t n,
+                                                     float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const int64_t r = idx64 ? idx64[p] : (int64_t)idx32[p];
+  for (int64_t c = lane; c < width; c += 64) out[p * width + c] = table[r * width + c];
+}
+
+__global__ __launch_bounds__(256) void k_scatter_rows(float* __restrict__ table, int64_t width,
+                                                      const int64_t* __restrict__ ids, int64_t n,
+                                                      const float* __restrict__ x) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const int64_t r = ids[p];
+  for (int64_t c = lane; c < width; c += 64) table[r * width + c] = x[p * width + c];
+}
+
+inline unsigned blocks(int64_t n, int per) { return (unsigned)ceil_div64(n, per); }
+}  // namespace
+
+ORCA_API int orca_time_encode(const float* t, int64_t n, const float* w, const float* b, float* out, void* stream) {
+  ORCA_REQUIRE(n >= 0 && (n == 0 || (t && w && b && out)), "orca_time_encode: null pointer");
+  if (n == 0) return ORCA_OK;
+  k_time_encode<<<blocks(n * D, 256), 256, 0, (hipStream_t)stream>>>(t, n, w, b, out);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_fill_i32(int32_t* p, int64_t n, int32_t v, void* stream) {
+  ORCA_REQUIRE(n >= 0 && (n == 0 || p), "orca_fill_i32: null pointer");
+  if (n == 0) return ORCA_OK;
+  k_fill_i32<<<blocks(n, 256), 256, 0, (hipStream_t)stream>>>(p, n, v);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream) {
+  ORCA_REQUIRE(n >= 0 && (n == 0 || p), "orca_fill_u8: null pointer");
+  if (n == 0) return ORCA_OK;
+  k_fill_u8<<<blocks(n, 256), 256, 0, (hipStream_t)stream>>>(p, n, v);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_worklist_build(const int32_t* ids32, int64_t n32, const int64_t* ids64, int64_t n64,
+                                 const uint8_t* flags, int32_t* stamp, int32_t epoch, int64_t n_nodes,
+                                 int32_t* worklist, int32_t* count, void* stream) {
+  ORCA_REQUIRE(n32 >= 0 && n64 >= 0 && stamp && worklist && count && n_nodes > 0, "orca_worklist_build: bad arguments");
+  ORCA_REQUIRE((n32 == 0 || ids32) && (n64 == 0 || ids64), "orca_worklist_build: null id array");
+  if (n32 + n64 == 0) return ORCA_OK;
+  k_worklist<<<blocks(n32 + n64, 256), 256, 0, (hipStream_t)stream>>>(ids32, n32, ids64, n64, flags, stamp, epoch,
+                                                                      n_nodes, worklist, count);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_set_flags(uint8_t* flags, const int64_t* ids64, const int32_t* ids32, int64_t n,
+                            const int32_t* n_dev, uint8_t v, void* stream) {
+  ORCA_REQUIRE(flags && n >= 0 && (n == 0 || ids64 || ids32), "orca_set_flags: bad arguments");
+  if (n == 0) return ORCA_OK;
+  k_set_flags<<<blocks(n, 256), 256, 0, (hipStream_t)stream>>>(flags, ids64, ids32, n, n_dev, v);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_segment_last(const int64_t* ids, int64_t M, int64_t* slot, int64_t epoch, int64_t n_nodes,
+                               uint8_t* winner, void* stream) {
+  ORCA_REQUIRE(M >= 0 && slot && n_nodes > 0 && (M == 0 || (ids && winner)), "orca_segment_last: bad arguments");
+  if (M == 0) return ORCA_OK;
+  k_elect<<<blocks(M, 256), 256, 0, (hipStream_t)stream>>>(ids, M, slot, epoch, n_nodes);
+  k_winner<<<blocks(M, 256), 256, 0, (hipStream_t)stream>>>(ids, M, slot, epoch, n_nodes, winner);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_segment_mean(const int64_t* ids, int64_t M, int64_t Dm, const float* msgs, const float* ts,
+                               int64_t* slot, int64_t epoch, int64_t n_nodes, uint8_t* winner, float* out_msgs,
+                               void* stream) {
+  (void)ts;   // the timestamp of a segment is ts[p] at its winner position p: nothing to compute
+  ORCA_REQUIRE(M >= 0 && Dm > 0 && (M == 0 || (msgs && out_msgs)), "orca_segment_mean: bad arguments");
+  int rc = orca_segment_last(ids, M, slot, epoch, n_nodes, winner, stream);
+  if (rc != ORCA_OK || M == 0) return rc;
+  k_segment_mean<<<(unsigned)M, 128, 0, (hipStream_t)stream>>>(ids, M, Dm, msgs, winner, out_msgs);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_message_store(const int64_t* src, const int64_t* dst, const int64_t* eidx, const double* t,
+                                int64_t bs, const float* memory, const float* last_update, const float* edge_feats,
+                                int d_e, const float* time_w, const float* time_b, int64_t* slot, int64_t epoch,
+                                int64_t n_nodes, float* messages, float* msg_ts, uint8_t* pending, void* stream) {
+  ORCA_REQUIRE(bs >= 0 && d_e >= 1 && n_nodes > 0, "orca_message_store: bad arguments");
+  if (bs == 0) return ORCA_OK;
+  ORCA_REQUIRE(src && dst && eidx && t && memory && last_update && edge_feats && time_w && time_b && slot &&
+               messages && msg_ts && pending, "orca_message_store: null pointer");
+  k_elect2<<<blocks(2 * bs, 256), 256, 0, (hipStream_t)stream>>>(src, dst, bs, slot, epoch, n_nodes);
+  k_message_store<<<blocks(2 * bs, 4), 256, 0, (hipStream_t)stream>>>(src, dst, eidx, t, bs, memory, last_update,
+                                                                      edge_feats, d_e, time_w, time_b, slot, epoch,
+                                                                      n_nodes, messages, msg_ts, pending);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_history_push(float* emb, const float* x, const int64_t* ids, int64_t n, int64_t* slot,
+                               int64_t epoch, int64_t n_nodes, void* stream) {
+  ORCA_REQUIRE(n >= 0 && n_nodes > 0 && (n == 0 || (emb && x && ids && slot)), "orca_history_push: bad arguments");
+  if (n == 0) return ORCA_OK;
+  k_elect<<<blocks(n, 256), 256, 0, (hipStream_t)stream>>>(ids, n, slot, epoch, n_nodes);
+  k_push_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(emb, x, ids, n, slot, epoch, n_nodes);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_gather_rows(const float* table, int64_t width, const int64_t* idx64, const int32_t* idx32,
+                              int64_t n, float* out, void* stream) {
+  ORCA_REQUIRE(n >= 0 && width > 0 && (n == 0 || (table && out && (idx64 || idx32))), "orca_gather_rows: bad arguments");
+  if (n == 0) return ORCA_OK;
+  k_gather_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(table, width, idx64, idx32, n, out);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_scatter_rows(float* table, int64_t width, const int64_t* ids, int64_t n, const float* x,
+                               void* stream) {
+  ORCA_REQUIRE(n >= 0 && width > 0 && (n == 0 || (table && ids && x)), "orca_scatter_rows: bad arguments");
+  if (n == 0) return ORCA_OK;
+  k_scatter_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(table, width, ids, n, x);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
