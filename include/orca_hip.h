@@ -64,6 +64,10 @@ int orca_csr_destroy(orca_csr_t* csr);
 /* device pointers of the CSR arrays (for tests / export); any out pointer may be NULL */
 int orca_csr_arrays(const orca_csr_t* csr, int64_t* n_rows, int64_t* nnz, const int64_t** indptr,
                     const int32_t** nbr, const int32_t** eidx, const double** ts);
+/* copies the CSR arrays back into caller-owned HOST buffers ([n_rows+1], [nnz] x3; any may be NULL):
+ * the node_to_neighbors / node_to_edge_idxs / node_to_edge_timestamps lists of utils/util.py:98-105 */
+int orca_csr_copy_host(const orca_csr_t* csr, int64_t* indptr_host, int32_t* nbr_host, int32_t* eidx_host,
+                       double* ts_host);
 
 /* NeighborFinder.get_temporal_neighbor (utils/util.py:134-151) + the Δt of
  * modules/embedding_module.py:130-131.  Outputs are [Q, K] row-major, right-aligned, zero padded;

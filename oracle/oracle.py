@@ -46,6 +46,7 @@ def lib():
     L.orc_find_before.restype = ctypes.c_int64
     L.orc_find_before.argtypes = [c_i64p, c_f64p, ctypes.c_int64, ctypes.c_double]
     L.orc_sample_recent.restype = ctypes.c_int
+    L.orc_sample_uniform.restype = ctypes.c_int
     L.orc_segment_last.restype = ctypes.c_int64
     L.orc_segment_mean.restype = ctypes.c_int64
     _lib_handle = L
@@ -106,6 +107,24 @@ class OracleNeighborFinder:
     if with_deltas:
       return nbr, eid, et, dt
     return nbr, eid, et
+
+
+def sample_uniform(nf, source_nodes, timestamps, K, seed):
+  """Uniform sampling -- not in the reference ("parity unpinned"); CPU twin of orca_sample_uniform."""
+  nodes = np.ascontiguousarray(source_nodes, dtype=np.int64)
+  qts = np.ascontiguousarray(timestamps, dtype=np.float64)
+  Q = len(nodes)
+  nbr = np.zeros((Q, K), dtype=np.int32)
+  eid = np.zeros((Q, K), dtype=np.int32)
+  et = np.zeros((Q, K), dtype=np.float32)
+  dt = np.zeros((Q, K), dtype=np.float32)
+  rc = lib().orc_sample_uniform(_p(nf.indptr, c_i64p), _p(nf.nbr, c_i32p), _p(nf.eid, c_i32p), _p(nf.ts, c_f64p),
+                                ctypes.c_int64(nf.n_rows), ctypes.c_int64(Q), _p(nodes, c_i64p), _p(qts, c_f64p),
+                                ctypes.c_int(int(K)), ctypes.c_uint64(int(seed)), _p(nbr, c_i32p), _p(eid, c_i32p),
+                                _p(et, c_f32p), _p(dt, c_f32p))
+  if rc != 0:
+    raise IndexError("orc_sample_uniform failed")
+  return nbr, eid, et, dt
 
 
 def sample_recent_numpy(indptr, nbr, eid, ts, nodes, qts, K):

@@ -171,3 +171,45 @@ int64_t orc_segment_mean(int64_t M, int64_t D, const int64_t* ids, const float* 
   free(a);
   return U;
 }
+
+/*
+ * Uniform temporal sampling.  NOT IN THE REFERENCE (utils/util.py:121-151 has only the most-recent
+ * mode) -- "parity unpinned": this restates the definition the product documents in
+ * include/orca_hip.h (orca_sample_uniform) so that the HIP kernel has an independent CPU twin.
+ * For a query q with i > 0 entries before t, slot j draws r_j = mix(seed ^ mix(q*64 + j)) mod i
+ * (splitmix64 finaliser); the K draws are ordered by position (ties by slot) and written to slots
+ * 0..K-1; i == 0 gives an all-zero row.  Δt as in orc_sample_recent.
+ */
+static uint64_t orc_mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+int orc_sample_uniform(const int64_t* indptr, const int32_t* nbr, const int32_t* eid, const double* t, int64_t n_rows,
+                       int64_t Q, const int64_t* nodes, const double* qts, int K, uint64_t seed,
+                       int32_t* out_nbr, int32_t* out_eid, float* out_et, float* out_dt) {
+  if (K < 1 || K > 64) return -3;
+  for (int64_t q = 0; q < Q; ++q) {
+    int64_t v = nodes[q];
+    if (v < 0 || v >= n_rows) return -1;
+    int64_t cnt = orc_find_before(indptr, t, v, qts[q]);
+    int64_t r[64];
+    for (int j = 0; j < K; ++j) {
+      out_nbr[q * K + j] = 0; out_eid[q * K + j] = 0; out_et[q * K + j] = 0.0f;
+      r[j] = cnt > 0 ? (int64_t)(orc_mix64(seed ^ orc_mix64((uint64_t)q * 64u + (uint64_t)j)) % (uint64_t)cnt) : -1;
+    }
+    if (cnt > 0) {
+      for (int j = 0; j < K; ++j) {
+        int rank = 0;
+        for (int k = 0; k < K; ++k) rank += (r[k] < r[j]) || (r[k] == r[j] && k < j);
+        int64_t p = indptr[v] + r[j];
+        out_nbr[q * K + rank] = nbr[p];
+        out_eid[q * K + rank] = eid[p];
+        out_et[q * K + rank] = (float)t[p];
+      }
+    }
+    for (int j = 0; j < K; ++j) out_dt[q * K + j] = (float)(qts[q] - (double)out_et[q * K + j]);
+  }
+  return 0;
+}

@@ -36,6 +36,7 @@ SIGNATURES = {
     "orca_csr_destroy": (i32, [vp]),
     "orca_csr_arrays": (i32, [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp),
                               ctypes.POINTER(vp), ctypes.POINTER(vp)]),
+    "orca_csr_copy_host": (i32, [vp, vp, vp, vp, vp]),
     "orca_sample_recent": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
     "orca_find_before": (i32, [vp, vp, vp, i64, vp, vp]),
     "orca_sample_uniform": (i32, [vp, vp, vp, i64, i32, u64, vp, vp, vp, vp, vp, vp]),

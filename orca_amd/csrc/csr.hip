@@ -273,6 +273,16 @@ ORCA_API int orca_csr_arrays(const orca_csr_t* c, int64_t* n_rows, int64_t* nnz,
   return ORCA_OK;
 }
 
+ORCA_API int orca_csr_copy_host(const orca_csr_t* c, int64_t* indptr, int32_t* nbr, int32_t* eidx, double* ts) {
+  ORCA_REQUIRE(c, "orca_csr_copy_host: null handle");
+  if (indptr) ORCA_HIP_TRY(hipMemcpy(indptr, c->indptr, (size_t)(c->n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (c->nnz == 0) return ORCA_OK;
+  if (nbr) ORCA_HIP_TRY(hipMemcpy(nbr, c->nbr, (size_t)c->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (eidx) ORCA_HIP_TRY(hipMemcpy(eidx, c->eid, (size_t)c->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (ts) ORCA_HIP_TRY(hipMemcpy(ts, c->ts, (size_t)c->nnz * sizeof(double), hipMemcpyDeviceToHost));
+  return ORCA_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Sampler: one 64-lane wavefront per (node, t) query.
 //   1. 64-ary lower_bound on the node's float64 timestamps: every round the 64 lanes probe 64

@@ -435,7 +435,9 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
 
 ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
                                float* out_weights, void* stream) {
-  ORCA_REQUIRE(blob && in && out && Q >= 0, "orca_tgat_forward: null pointer");
+  ORCA_REQUIRE(Q >= 0, "orca_tgat_forward: Q=%lld < 0", (long long)Q);
+  if (Q == 0) return ORCA_OK;   // empty batch (an empty tensor has no address)
+  ORCA_REQUIRE(blob && in && out, "orca_tgat_forward: null pointer");
   ORCA_REQUIRE(d_e >= 1 && d_e <= ORCA_MAX_DE, "orca_tgat_forward: d_e=%d outside [1,%d]", d_e, ORCA_MAX_DE);
   ORCA_REQUIRE(K >= 1 && K <= ORCA_MAX_K, "orca_tgat_forward: K=%d outside [1,%d]", K, ORCA_MAX_K);
   ORCA_REQUIRE(in->src_table && in->nbr_table && in->edge_table, "orca_tgat_forward: null feature table");
@@ -444,7 +446,6 @@ ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_input
                "orca_tgat_forward: need (dt, time_w, time_b) or (src_time, nbr_time)");
   ORCA_REQUIRE(!in->src_flags || in->src_overlay, "orca_tgat_forward: src_flags without src_overlay");
   ORCA_REQUIRE(!in->nbr_flags || in->nbr_overlay, "orca_tgat_forward: nbr_flags without nbr_overlay");
-  if (Q == 0) return ORCA_OK;
   Blob L = blob_layout(d_e);
   size_t lds_bytes = (size_t)(2 * TQ * ASTR + TQ * MSTR + TQ * 2 * (L.KP + 4) + NW * K * D) * sizeof(float);
   static bool attr_set = false;

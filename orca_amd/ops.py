@@ -1,0 +1,286 @@
+"""Torch-tensor front end of the C ABI (include/orca_hip.h).  torch is used for device memory and
+streams only; every function below is one call into liborca_hip.so on the current HIP stream.
+There is no CPU fallback: tensors must live on a HIP device and the library must be built."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ORCA_D, check, ptr, stream
+
+D = ORCA_D
+
+
+def _dev(t, dtype, what):
+  if not (isinstance(t, torch.Tensor) and t.is_cuda):
+    raise _lib.OrcaError(f"{what}: expected a tensor on the HIP device (no CPU fallback)")
+  if t.dtype != dtype:
+    raise TypeError(f"{what}: expected {dtype}, got {t.dtype}")
+  return t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# time-sorted CSR + sampler (utils/util.py:91-151)
+# ---------------------------------------------------------------------------------------------
+class CSR:
+  """Opaque handle of the time-sorted CSR in HBM (orca_csr_t)."""
+
+  def __init__(self, handle, device):
+    self._h = handle
+    self.device = torch.device(device)
+    n_rows, nnz = _lib.i64(), _lib.i64()
+    check(_lib.load().orca_csr_arrays(self._h, ctypes.byref(n_rows), ctypes.byref(nnz), None, None, None, None),
+          "orca_csr_arrays")
+    self.n_rows, self.nnz = n_rows.value, nnz.value
+
+  @staticmethod
+  def _index(device):
+    d = torch.device(device)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+  @classmethod
+  def from_edges_host(cls, src, dst, eidx, ts, n_rows, device):
+    """get_neighbor_finder (utils/util.py:91-105) from host edge arrays."""
+    src = np.ascontiguousarray(src, dtype=np.int64)
+    dst = np.ascontiguousarray(dst, dtype=np.int64)
+    eidx = np.ascontiguousarray(eidx, dtype=np.int64)
+    ts = np.ascontiguousarray(ts, dtype=np.float64)
+    h = _lib.vp()
+    check(_lib.load().orca_csr_create_host(len(src), ptr(src), ptr(dst), ptr(eidx), ptr(ts), int(n_rows),
+                                           cls._index(device), ctypes.byref(h)), "orca_csr_create_host")
+    return cls(h, device)
+
+  @classmethod
+  def from_edges_device(cls, src, dst, eidx, ts, n_rows):
+    """Same, from edge arrays already in HBM (radix-sort build on the device)."""
+    src, dst, eidx = (_dev(x, torch.int64, "CSR edges") for x in (src, dst, eidx))
+    ts = _dev(ts, torch.float64, "CSR timestamps")
+    h = _lib.vp()
+    with torch.cuda.device(src.device):
+      check(_lib.load().orca_csr_create_device(src.numel(), ptr(src), ptr(dst), ptr(eidx), ptr(ts), int(n_rows),
+                                               stream(), ctypes.byref(h)), "orca_csr_create_device")
+    return cls(h, src.device)
+
+  @classmethod
+  def from_arrays_host(cls, indptr, nbr, eidx, ts, device):
+    """NeighborFinder(node_to_neighbors, ...) (utils/util.py:123-126) from flattened ragged lists."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    nbr = np.ascontiguousarray(nbr, dtype=np.int32)
+    eidx = np.ascontiguousarray(eidx, dtype=np.int32)
+    ts = np.ascontiguousarray(ts, dtype=np.float64)
+    h = _lib.vp()
+    check(_lib.load().orca_csr_from_arrays_host(len(indptr) - 1, ptr(indptr), ptr(nbr), ptr(eidx), ptr(ts),
+                                                cls._index(device), ctypes.byref(h)), "orca_csr_from_arrays_host")
+    return cls(h, device)
+
+  def arrays_host(self):
+    """(indptr, nbr, eidx, ts) copied back to NumPy (tests / export / the cache planner)."""
+    indptr = np.empty(self.n_rows + 1, np.int64)
+    nbr = np.empty(self.nnz, np.int32)
+    eidx = np.empty(self.nnz, np.int32)
+    ts = np.empty(self.nnz, np.float64)
+    with torch.cuda.device(self.device):
+      check(_lib.load().orca_csr_copy_host(self._h, ptr(indptr), ptr(nbr), ptr(eidx), ptr(ts)), "orca_csr_copy_host")
+    return indptr, nbr, eidx, ts
+
+  def close(self):
+    if self._h is not None and self._h.value:
+      _lib.load().orca_csr_destroy(self._h)
+    self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+
+def sample_recent(csr, nodes, ts, K, with_dt=True, err_flag=None):
+  """orca_sample_recent: nodes int64 [Q], ts float64 [Q] on the device ->
+  (nbr int32 [Q,K], eidx int32 [Q,K], edge_times float32 [Q,K], dt float32 [Q,K] or None)."""
+  nodes = _dev(nodes, torch.int64, "sample_recent nodes")
+  ts = _dev(ts, torch.float64, "sample_recent ts")
+  Q = nodes.numel()
+  dev = nodes.device
+  nbr = torch.empty((Q, K), dtype=torch.int32, device=dev)
+  eid = torch.empty((Q, K), dtype=torch.int32, device=dev)
+  et = torch.empty((Q, K), dtype=torch.float32, device=dev)
+  dt = torch.empty((Q, K), dtype=torch.float32, device=dev) if with_dt else None
+  check(_lib.load().orca_sample_recent(csr._h, ptr(nodes), ptr(ts), Q, K, ptr(nbr), ptr(eid), ptr(et), ptr(dt),
+                                       ptr(err_flag), stream()), "orca_sample_recent")
+  return nbr, eid, et, dt
+
+
+def sample_uniform(csr, nodes, ts, K, seed, err_flag=None):
+  nodes = _dev(nodes, torch.int64, "sample_uniform nodes")
+  ts = _dev(ts, torch.float64, "sample_uniform ts")
+  Q = nodes.numel()
+  dev = nodes.device
+  nbr = torch.empty((Q, K), dtype=torch.int32, device=dev)
+  eid = torch.empty((Q, K), dtype=torch.int32, device=dev)
+  et = torch.empty((Q, K), dtype=torch.float32, device=dev)
+  dt = torch.empty((Q, K), dtype=torch.float32, device=dev)
+  check(_lib.load().orca_sample_uniform(csr._h, ptr(nodes), ptr(ts), Q, K, int(seed), ptr(nbr), ptr(eid), ptr(et),
+                                        ptr(dt), ptr(err_flag), stream()), "orca_sample_uniform")
+  return nbr, eid, et, dt
+
+
+def find_before(csr, nodes, ts):
+  nodes = _dev(nodes, torch.int64, "find_before nodes")
+  ts = _dev(ts, torch.float64, "find_before ts")
+  out = torch.empty(nodes.numel(), dtype=torch.int64, device=nodes.device)
+  check(_lib.load().orca_find_before(csr._h, ptr(nodes), ptr(ts), nodes.numel(), ptr(out), stream()),
+        "orca_find_before")
+  return out
+
+
+# ---------------------------------------------------------------------------------------------
+def time_encode(t, w, b):
+  """model/time_encoding.py:23-28: t float32 [...] -> [..., 100]."""
+  t = _dev(t, torch.float32, "time_encode t")
+  out = torch.empty(tuple(t.shape) + (D,), dtype=torch.float32, device=t.device)
+  check(_lib.load().orca_time_encode(ptr(t), t.numel(), ptr(w), ptr(b), ptr(out), stream()), "orca_time_encode")
+  return out
+
+
+# ---------------------------------------------------------------------------------------------
+# TGAT attention layer (model/temporal_attention.py)
+# ---------------------------------------------------------------------------------------------
+TGAT_KEYS = ("multi_head_target.q_proj_weight", "multi_head_target.k_proj_weight",
+             "multi_head_target.v_proj_weight", "multi_head_target.in_proj_bias",
+             "multi_head_target.out_proj.weight", "multi_head_target.out_proj.bias",
+             "merger.fc1.weight", "merger.fc1.bias", "merger.fc2.weight", "merger.fc2.bias",
+             "norm.weight", "norm.bias")
+
+
+def tgat_pack(sd, d_e, device, blob=None):
+  """Packs one TemporalAttentionLayer state_dict (keys TGAT_KEYS) into the kernel's blob."""
+  n = _lib.load().orca_tgat_blob_floats(int(d_e))
+  if n < 0:
+    raise ValueError(f"tgat_pack: unsupported edge width {d_e}")
+  if blob is None:
+    blob = torch.empty(n, dtype=torch.float32, device=device)
+  ts = [sd[k].detach().to(device=device, dtype=torch.float32).contiguous() for k in TGAT_KEYS]
+  k_w = ts[1]
+  if k_w.shape != (2 * D, 2 * D + d_e):
+    raise ValueError(f"tgat_pack: k_proj_weight has shape {tuple(k_w.shape)}, expected {(2 * D, 2 * D + d_e)}")
+  check(_lib.load().orca_tgat_pack(int(d_e), *(ptr(t) for t in ts), ptr(blob), stream()), "orca_tgat_pack")
+  return blob
+
+
+def tgat_forward(blob, d_e, Q, K, out=None, want_weights=False, **kw):
+  """orca_tgat_forward.  kw: the fields of orca_tgat_inputs (tensors or None)."""
+  inp = _lib.TgatInputs()
+  keep = []
+  for name, _ in _lib.TgatInputs._fields_:
+    t = kw.pop(name, None)
+    if t is not None:
+      if not t.is_cuda:
+        raise _lib.OrcaError(f"tgat_forward: {name} is not on the HIP device")
+      t = t.contiguous()
+      keep.append(t)
+    setattr(inp, name, ptr(t))
+  if kw:
+    raise TypeError(f"tgat_forward: unknown inputs {sorted(kw)}")
+  dev = blob.device
+  if out is None:
+    out = torch.empty((Q, D), dtype=torch.float32, device=dev)
+  w = torch.empty((Q, K), dtype=torch.float32, device=dev) if want_weights else None
+  check(_lib.load().orca_tgat_forward(ptr(blob), int(d_e), ctypes.byref(inp), int(Q), int(K), ptr(out), ptr(w),
+                                      stream()), "orca_tgat_forward")
+  return out, w
+
+
+# ---------------------------------------------------------------------------------------------
+# GRU memory updater (modules/memory_updater.py)
+# ---------------------------------------------------------------------------------------------
+def gru_pack(weight_ih, weight_hh, bias_ih, bias_hh, device, blob=None):
+  msg_dim = weight_ih.shape[1]
+  n = _lib.load().orca_gru_blob_floats(int(msg_dim))
+  if n < 0:
+    raise ValueError(f"gru_pack: unsupported message width {msg_dim}")
+  if blob is None:
+    blob = torch.empty(n, dtype=torch.float32, device=device)
+  ts = [t.detach().to(device=device, dtype=torch.float32).contiguous() for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
+  check(_lib.load().orca_gru_pack(int(msg_dim), *(ptr(t) for t in ts), ptr(blob), stream()), "orca_gru_pack")
+  return blob
+
+
+def gru_update(blob, msg_dim, ids, n, n_dev, x, h, out, last_update=None, msg_ts=None):
+  check(_lib.load().orca_gru_update(ptr(blob), int(msg_dim), ptr(ids), int(n), ptr(n_dev), ptr(x), ptr(h), ptr(out),
+                                    ptr(last_update), ptr(msg_ts), stream()), "orca_gru_update")
+
+
+# ---------------------------------------------------------------------------------------------
+# node-id bookkeeping, messages, history
+# ---------------------------------------------------------------------------------------------
+def fill_i32(t, v):
+  check(_lib.load().orca_fill_i32(ptr(t), t.numel(), int(v), stream()), "orca_fill_i32")
+
+
+def fill_u8(t, v):
+  check(_lib.load().orca_fill_u8(ptr(t), t.numel(), int(v), stream()), "orca_fill_u8")
+
+
+def worklist_build(ids32, ids64, flags, stamp, epoch, worklist, count):
+  n32 = ids32.numel() if ids32 is not None else 0
+  n64 = ids64.numel() if ids64 is not None else 0
+  check(_lib.load().orca_worklist_build(ptr(ids32), n32, ptr(ids64), n64, ptr(flags), ptr(stamp), int(epoch),
+                                        stamp.numel(), ptr(worklist), ptr(count), stream()), "orca_worklist_build")
+
+
+def set_flags(flags, ids64=None, ids32=None, n=None, n_dev=None, v=1):
+  if n is None:
+    n = (ids64 if ids64 is not None else ids32).numel()
+  check(_lib.load().orca_set_flags(ptr(flags), ptr(ids64), ptr(ids32), int(n), ptr(n_dev), int(v), stream()),
+        "orca_set_flags")
+
+
+def segment_last(ids, slot, epoch):
+  ids = _dev(ids, torch.int64, "segment_last ids")
+  winner = torch.empty(ids.numel(), dtype=torch.uint8, device=ids.device)
+  check(_lib.load().orca_segment_last(ptr(ids), ids.numel(), ptr(slot), int(epoch), slot.numel(), ptr(winner),
+                                      stream()), "orca_segment_last")
+  return winner
+
+
+def segment_mean(ids, msgs, ts, slot, epoch):
+  ids = _dev(ids, torch.int64, "segment_mean ids")
+  msgs = _dev(msgs, torch.float32, "segment_mean msgs")
+  winner = torch.empty(ids.numel(), dtype=torch.uint8, device=ids.device)
+  out = torch.zeros_like(msgs)
+  check(_lib.load().orca_segment_mean(ptr(ids), ids.numel(), msgs.shape[1], ptr(msgs), ptr(ts), ptr(slot), int(epoch),
+                                      slot.numel(), ptr(winner), ptr(out), stream()), "orca_segment_mean")
+  return winner, out
+
+
+def message_store(src, dst, eidx, t, memory, last_update, edge_feats, time_w, time_b, slot, epoch, messages, msg_ts,
+                  pending):
+  check(_lib.load().orca_message_store(ptr(src), ptr(dst), ptr(eidx), ptr(t), src.numel(), ptr(memory),
+                                       ptr(last_update), ptr(edge_feats), edge_feats.shape[1], ptr(time_w),
+                                       ptr(time_b), ptr(slot), int(epoch), slot.numel(), ptr(messages), ptr(msg_ts),
+                                       ptr(pending), stream()), "orca_message_store")
+
+
+def history_push(emb, x, ids, slot, epoch):
+  check(_lib.load().orca_history_push(ptr(emb), ptr(x), ptr(ids), ids.numel(), ptr(slot), int(epoch), slot.numel(),
+                                      stream()), "orca_history_push")
+
+
+def gather_rows(table, idx, out=None):
+  n = idx.numel()
+  width = table.shape[1]
+  if out is None:
+    out = torch.empty((n, width), dtype=table.dtype, device=table.device)
+  i64 = idx if idx.dtype == torch.int64 else None
+  i32 = idx if idx.dtype == torch.int32 else None
+  if i64 is None and i32 is None:
+    raise TypeError("gather_rows: idx must be int64 or int32")
+  check(_lib.load().orca_gather_rows(ptr(table), width, ptr(i64), ptr(i32), n, ptr(out), stream()), "orca_gather_rows")
+  return out
+
+
+def scatter_rows(table, ids, x):
+  check(_lib.load().orca_scatter_rows(ptr(table), table.shape[1], ptr(ids), ids.numel(), ptr(x), stream()),
+        "orca_scatter_rows")
