@@ -1,0 +1,317 @@
+"""Device-resident TGN step: the hot path of LuckyLYM/Orca with every table, id list and flag kept
+in HBM between kernels (no host NumPy set algebra, no per-layer PCIe copies, no full-table clone).
+
+Follows, stage by stage, model/tgn_model.py:95-147 (compute_temporal_embeddings) with
+  Path A  modules/embedding_module.py:116-147   exact TGN recursion       (reuse=False)
+  Path B  modules/embedding_module.py:154-182   Orca-P push-and-pull      (reuse=True, budget=0)
+  Path C  modules/embedding_module.py:215-285   Orca-R budgeted reuse     (reuse=True, budget>0)
+and the memory / message steps of modules/memory_updater.py:25-78, modules/memory.py:25-28,
+model/tgn_model.py:172-191.  Forward only (the reference's no_grad persist/eval path and the
+forward half of a train step); dropout is off (module.eval()).
+
+Multi-GPU (not in the reference): state tables are replicated, each rank embeds a
+contiguous slice of the batch's (node, t) queries; the rows that later stages read across ranks
+(history rows between layers, updated memory rows) are exchanged with all_gather.  Duplicate
+resolution (last occurrence wins) is applied after the gather in global query order, so N-rank
+results equal 1-rank results.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import ORCA_D, OrcaError
+
+D = ORCA_D
+
+
+class OrcaEngine:
+  def __init__(self, state_dict, edge_feats, n_nodes, n_layers, n_neighbors, reuse=False, budget=0,
+               device="cuda:0", group=None):
+    """state_dict: the TGN state_dict of the reference (key names of SURVEY §8b); edge_feats
+    [n_edges+1, d_e] (row 0 = padding); n_nodes = number of table rows (args.n_nodes, train.py:129)."""
+    self.device = torch.device(device)
+    if self.device.type != "cuda":
+      raise OrcaError("OrcaEngine needs a HIP device (there is no CPU fallback)")
+    self.N, self.L, self.K = int(n_nodes), int(n_layers), int(n_neighbors)
+    self.reuse, self.budget = bool(reuse), int(budget)
+    self.group = group
+    if group is not None:
+      import torch.distributed as dist
+      self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+      self.rank, self.world = 0, 1
+    dev = self.device
+    ef = edge_feats if isinstance(edge_feats, torch.Tensor) else torch.as_tensor(np.asarray(edge_feats))
+    self.edge_feats = ef.to(device=dev, dtype=torch.float32).contiguous()
+    self.d_e = self.edge_feats.shape[1]
+    self.msg_dim = 3 * D + self.d_e                                   # tgn_model.py:49-50
+    self.load_state_dict(state_dict)
+    f32 = dict(dtype=torch.float32, device=dev)
+    # modules/memory.py:17-23 (+ the pending flag bitmap, a host bool array upstream)
+    self.memory = torch.zeros(self.N, D, **f32)
+    self.last_update = torch.zeros(self.N, **f32)
+    self.messages = torch.zeros(self.N, self.msg_dim, **f32)
+    self.msg_ts = torch.zeros(self.N, **f32)
+    self.pending = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+    # replaces the per-batch full-table clone of memory_updater.py:72,76
+    self.overlay = torch.zeros(self.N, D, **f32)
+    # modules/history.py:11-20
+    nh = self.L - 1 if self.reuse else 0
+    self.hist = [torch.zeros(self.N, D, **f32) for _ in range(nh)]
+    self.cache_flag = [torch.zeros(self.N, dtype=torch.uint8, device=dev) for _ in range(nh)]
+    # scratch
+    self.slot = torch.zeros(self.N, dtype=torch.int64, device=dev)
+    self.slot_epoch = 1
+    self.stamp = torch.zeros(self.N, dtype=torch.int32, device=dev)
+    self.stamp_epoch = 0
+    self.worklist = torch.zeros(self.N, dtype=torch.int32, device=dev)
+    self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+    self.all_ids = None
+    self.csr = None
+    self.test_mode = False
+    self.batch_counter = 0
+
+  # -------------------------------------------------------------------------------------------
+  def load_state_dict(self, sd):
+    dev = self.device
+    sd = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in sd.items()}
+    self.time_w = sd["time_encoder.w.weight"].reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+    b = sd.get("time_encoder.w.bias")
+    self.time_b = (b.reshape(-1).to(device=dev, dtype=torch.float32).contiguous() if b is not None
+                   else torch.zeros(D, device=dev))
+    self.att_blobs = []
+    for i in range(self.L):
+      p = f"embedding_module.attention_models.{i}."
+      self.att_blobs.append(ops.tgat_pack({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, self.d_e, dev))
+    p = "memory_updater.memory_updater."
+    self.gru_blob = ops.gru_pack(sd[p + "weight_ih"], sd[p + "weight_hh"], sd[p + "bias_ih"], sd[p + "bias_hh"], dev)
+    self.aff = {k[len("affinity_score."):]: v.to(device=dev, dtype=torch.float32)
+                for k, v in sd.items() if k.startswith("affinity_score.")}
+
+  def set_neighbor_finder(self, csr):
+    """tgn_model.py:193-195; csr is an ops.CSR (or a shim NeighborFinder carrying .csr)."""
+    self.csr = getattr(csr, "csr", csr)
+
+  # modules/memory.py:17-23, modules/history.py:14-20
+  def reset_state(self):
+    for t in (self.memory, self.last_update, self.messages, self.msg_ts, self.pending, self.overlay):
+      t.zero_()
+    for t in self.hist + self.cache_flag:
+      t.zero_()
+    self.test_mode = False
+
+  # modules/memory.py:39-43, embedding_module.py:83-91
+  def backup(self):
+    return ([t.clone() for t in (self.memory, self.last_update, self.messages, self.msg_ts, self.pending)],
+            [h.clone() for h in self.hist], [c.clone() for c in self.cache_flag])
+
+  def restore(self, b):
+    for t, s in zip((self.memory, self.last_update, self.messages, self.msg_ts, self.pending), b[0]):
+      t.copy_(s)
+    for t, s in zip(self.hist, b[1]):
+      t.copy_(s)
+    for t, s in zip(self.cache_flag, b[2]):
+      t.copy_(s)
+
+  # -------------------------------------------------------------------------------------------
+  def _slot_epoch(self, n):
+    e = self.slot_epoch
+    self.slot_epoch += int(n) + 1
+    return e
+
+  def _stamp_epoch(self):
+    self.stamp_epoch += 1
+    if self.stamp_epoch >= 2 ** 31 - 1:
+      self.stamp.zero_()
+      self.stamp_epoch = 1
+    return self.stamp_epoch
+
+  def _build_worklist(self, ids32, ids64, bound):
+    """distinct ids of (ids32 ∪ ids64) that hold a pending message -> self.worklist[:count]."""
+    ops.fill_i32(self.count, 0)
+    ops.worklist_build(ids32, ids64, self.pending, self.stamp, self._stamp_epoch(), self.worklist, self.count)
+    return min(int(bound), self.N)
+
+  def _overlay_updated_memory(self, ids32, ids64):
+    """memory_updater.get_updated_memory (memory_updater.py:56-78) restricted to the rows this batch
+    reads: GRU(messages, memory) of every pending id is written to the overlay table."""
+    n32 = ids32.numel() if ids32 is not None else 0
+    n64 = ids64.numel() if ids64 is not None else 0
+    bound = self._build_worklist(ids32, ids64, n32 + n64)
+    ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory,
+                   self.overlay)
+
+  def _persist_memory(self, ids64):
+    """memory_updater.update_memory (:25-39) + memory.clear_messages (memory.py:49-50)."""
+    bound = self._build_worklist(None, ids64, ids64.numel())
+    ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory,
+                   self.memory, self.last_update, self.msg_ts)
+    ops.set_flags(self.pending, ids64=ids64, v=0)
+
+  def _flush_all_pending(self):
+    """memory_updater.update_memory_in_test (:42-53)."""
+    if self.all_ids is None:
+      self.all_ids = torch.arange(self.N, dtype=torch.int64, device=self.device)
+    bound = self._build_worklist(None, self.all_ids, self.N)
+    ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory,
+                   self.memory, self.last_update, self.msg_ts)
+    ops.fill_u8(self.pending, 0)
+
+  def _sample(self, nodes, ts):
+    nbr, eid, _, dt = ops.sample_recent(self.csr, nodes, ts, self.K)
+    return nbr, eid, dt
+
+  def _attend(self, layer, Q, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr_idx, from_memory):
+    """embedding_module.py:318-329 (aggregate) fused with the gathers of :123,133,172-174 and the
+    time encodings of :126,132."""
+    kw = dict(src_table=src_table, src_idx=src_idx, nbr_table=nbr_table, nbr_idx=nbr_idx, nbr_ids=nbr,
+              edge_table=self.edge_feats, edge_idx=eid, dt=dt, time_w=self.time_w, time_b=self.time_b)
+    if from_memory and train:
+      kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
+    out, _ = ops.tgat_forward(self.att_blobs[layer - 1], self.d_e, Q, self.K, **kw)
+    return out
+
+  # -------------------------------------------------------------------------------------------
+  def _slice(self, Q):
+    """contiguous query slice of this rank"""
+    per = (Q + self.world - 1) // self.world
+    lo = min(self.rank * per, Q)
+    return lo, min(lo + per, Q), per
+
+  def _all_gather_rows(self, x, Q, per):
+    """x: this rank's [n_local, D] rows of a [Q, D] result -> the full [Q, D] on every rank."""
+    if self.world == 1:
+      return x
+    import torch.distributed as dist
+    buf = torch.zeros(per, x.shape[1], dtype=x.dtype, device=x.device)
+    buf[:x.shape[0]] = x
+    full = torch.empty(self.world * per, x.shape[1], dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(full, buf, group=self.group)
+    return full[:Q]
+
+  # Path A: embedding_module.py:116-147
+  def _embed_exact(self, nodes, ts, train):
+    Q = nodes.numel()
+    lo, hi, per = self._slice(Q)
+    f_nodes, f_ts = [nodes[lo:hi]], [ts[lo:hi]]
+    samples = []
+    for _ in range(self.L):                           # top-down frontier expansion (:127-139)
+      nbr, eid, dt = self._sample(f_nodes[-1], f_ts[-1])
+      samples.append((nbr, eid, dt))
+      f_nodes.append(torch.cat([f_nodes[-1], nbr.flatten().to(torch.int64)]))
+      f_ts.append(torch.cat([f_ts[-1], f_ts[-1].repeat_interleave(self.K)]))
+    if train:                                         # base case (:119-124)
+      self._overlay_updated_memory(None, f_nodes[-1])
+    emb = None
+    for layer in range(1, self.L + 1):                # bottom-up aggregation (:142-146)
+      lvl = self.L - layer
+      nbr, eid, dt = samples[lvl]
+      n = f_nodes[lvl].numel()
+      if layer == 1:
+        emb = self._attend(1, n, nbr, eid, dt, train, self.memory, f_nodes[lvl].to(torch.int32), self.memory, nbr,
+                           True)
+      else:
+        emb = self._attend(layer, n, nbr, eid, dt, train, emb, None, emb[n:], None, False)
+    return self._all_gather_rows(emb, Q, per)
+
+  # Path B: embedding_module.py:154-182
+  def _embed_reuse(self, nodes, ts, train):
+    Q = nodes.numel()
+    lo, hi, per = self._slice(Q)
+    my_nodes = nodes[lo:hi]
+    n = my_nodes.numel()
+    nbr, eid, dt = self._sample(my_nodes, ts[lo:hi])
+    if train:                                         # :159-161
+      self._overlay_updated_memory(nbr, my_nodes)
+    emb = self._attend(1, n, nbr, eid, dt, train, self.memory, my_nodes.to(torch.int32), self.memory, nbr, True)
+    for layer in range(2, self.L + 1):                # :176-181
+      full = self._all_gather_rows(emb, Q, per)       # history rows pushed by every rank
+      h = self.hist[layer - 2]
+      ops.history_push(h, full, nodes, self.slot, self._slot_epoch(Q))     # :103-113, history.py:38-40
+      emb = self._attend(layer, n, nbr, eid, dt, train, emb, None, h, nbr, False)
+    return self._all_gather_rows(emb, Q, per)
+
+  # embedding_module.py:200-212
+  def _find_uncached(self, nodes, nbr):
+    u = torch.unique(nbr.flatten().to(torch.int64))
+    u = u[~torch.isin(u, nodes)]
+    u = u[self.cache_flag[0][u] == 0]
+    return u[1:]
+
+  # Path C: embedding_module.py:215-285 (single rank: its control flow depends on global sets)
+  def _embed_budget(self, nodes, ts, n_layers, cache_plan, train):
+    n = nodes.numel()
+    nbr, eid, dt = self._sample(nodes, ts)
+    if n_layers == 1:                                 # :224-246
+      if train:
+        self._overlay_updated_memory(nbr, nodes)
+      return self._attend(1, n, nbr, eid, dt, train, self.memory, nodes.to(torch.int32), self.memory, nbr, True)
+    unc = self._find_uncached(nodes, nbr)             # :251
+    if unc.numel():                                   # :253-260
+      c_nodes = torch.cat([nodes, unc])
+      c_ts = torch.cat([ts, ts.max().expand(unc.numel())])
+    else:
+      c_nodes, c_ts = nodes, ts
+    comb = self._embed_budget(c_nodes, c_ts, n_layers - 1, cache_plan, train)        # :273
+    h = self.hist[n_layers - 2]
+    ops.history_push(h, comb, c_nodes, self.slot, self._slot_epoch(c_nodes.numel()))  # :186-197
+    flag = self.cache_flag[n_layers - 2]
+    if cache_plan is not None:                        # history.py:25-28
+      ops.fill_u8(flag, 0)
+      if cache_plan.numel():
+        ops.set_flags(flag, ids64=cache_plan, v=1)
+    else:                                             # history.py:30
+      ops.set_flags(flag, ids64=c_nodes, v=1)
+    return self._attend(n_layers, n, nbr, eid, dt, train, comb, None, h, nbr, False)
+
+  # -------------------------------------------------------------------------------------------
+  def compute_temporal_embeddings(self, src, dst, neg, ts, eidx, train=True, cache_plan=None):
+    """model/tgn_model.py:95-147.  src/dst/neg/eidx int64 [bs], ts float64 [bs], device tensors
+    (NumPy arrays are uploaded).  Returns the [3*bs, 100] embeddings of [src; dst; neg]."""
+    dev = self.device
+    src, dst, neg, eidx = (self._dev(x, torch.int64) for x in (src, dst, neg, eidx))
+    ts = self._dev(ts, torch.float64)
+    if self.csr is None:
+      raise OrcaError("OrcaEngine: set_neighbor_finder() first")
+    self.batch_counter += 1
+    nodes = torch.cat([src, dst, neg])
+    t3 = torch.cat([ts, ts, ts])
+    positives = nodes[:2 * src.numel()]
+    if train:                                          # :105-112
+      self.test_mode = False
+    elif not self.test_mode:
+      self._flush_all_pending()
+      self.test_mode = True
+    if self.reuse and self.budget != 0:                # :114-120
+      if self.world != 1:
+        raise OrcaError("budgeted reuse (Path C) runs on one rank")
+      plan = self._dev(cache_plan, torch.int64) if cache_plan is not None else None
+      emb = self._embed_budget(nodes, t3, self.L, plan, train)
+    elif self.reuse:
+      emb = self._embed_reuse(nodes, t3, train)
+    else:
+      emb = self._embed_exact(nodes, t3, train)
+    if train:                                          # :127-129
+      self._persist_memory(positives)
+    ops.message_store(src, dst, eidx, ts, self.memory, self.last_update, self.edge_feats, self.time_w, self.time_b,
+                      self.slot, self._slot_epoch(2 * src.numel()), self.messages, self.msg_ts, self.pending)  # :131-141
+    if not train:                                      # :143-145
+      self._persist_memory(positives)
+    return emb
+
+  def compute_edge_probabilities(self, src, dst, neg, ts, eidx, train=True, cache_plan=None):
+    """model/tgn_model.py:150-157; the link decoder (MergeLayer utils/util.py:12-24) is a plain
+    library GEMM outside the hot path."""
+    emb = self.compute_temporal_embeddings(src, dst, neg, ts, eidx, train, cache_plan)
+    self.last_embeddings = emb
+    n = emb.shape[0] // 3
+    se, de, ne = emb[:n], emb[n:2 * n], emb[2 * n:]
+    x = torch.cat([torch.cat([se, se]), torch.cat([de, ne])], dim=1)
+    h = torch.relu(x @ self.aff["fc1.weight"].t() + self.aff["fc1.bias"])
+    s = h @ self.aff["fc2.weight"].t() + self.aff["fc2.bias"]
+    return s[:n].sigmoid(), s[n:].sigmoid()
+
+  def _dev(self, x, dtype):
+    if not isinstance(x, torch.Tensor):
+      x = torch.from_numpy(np.ascontiguousarray(x))
+    return x.to(device=self.device, dtype=dtype).contiguous()

@@ -1,0 +1,120 @@
+"""End-to-end parity of the device-resident step (orca_amd/engine.py, all kernels through the C ABI)
+against the golden vectors captured from the reference's TGN (tests/golden/tgn.npz) -- Paths A, B
+and C, train and eval ordering, d_e = 172 and the zero-feature d_e = 1 case -- and, at the
+BASELINE config-4 batch shape (4096 queries, K=10, 2 layers, 172-d), against the CPU oracle plus
+size-independent properties.  Needs a real MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close_fp32
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_num_threads(1)
+DEV = "cuda:0"
+
+
+def _engine_and_graph(g, tag, graph):
+  from orca_amd import ops
+  from orca_amd.engine import OrcaEngine
+  meta = g[f"{tag}_meta"]
+  L, reuse, budget, bs, K, n_train, n_eval, n_nodes, n_edges = [int(x) for x in meta]
+  src, dst, ts, eidx = (g[f"{graph}_{k}"] for k in ("src", "dst", "ts", "eidx"))
+  sd = {k[len(graph + "_sd."):]: g[k] for k in g.files if k.startswith(graph + "_sd.")}
+  eng = OrcaEngine(sd, g[f"{graph}_edge_feats"], n_nodes + 1, L, K, bool(reuse), budget, device=DEV)
+  n_tr = n_train * bs
+  train_csr = ops.CSR.from_edges_host(src[:n_tr], dst[:n_tr], eidx[:n_tr], ts[:n_tr], n_nodes + 1, DEV)
+  full_csr = ops.CSR.from_edges_host(src, dst, eidx, ts, n_nodes + 1, DEV)
+  return eng, train_csr, full_csr, (L, reuse, budget, bs, K, n_train, n_eval, n_nodes, n_edges), (src, dst, ts, eidx)
+
+
+@pytest.mark.parametrize("tag,graph", [("A1", "g172"), ("A2", "g172"), ("B2", "g172"), ("C2", "g172"),
+                                       ("B2z", "g1"), ("A1z", "g1")])
+def test_tgn_paths_vs_reference_golden(golden, tag, graph):
+  g = golden("tgn.npz")
+  eng, train_csr, full_csr, meta, edges = _engine_and_graph(g, tag, graph)
+  L, reuse, budget, bs, K, n_train, n_eval, n_nodes, n_edges = meta
+  src, dst, ts, eidx = edges
+  negs = g[f"{tag}_negs"]
+  b = 0
+  for phase, nb in (("train", n_train), ("eval", n_eval)):
+    eng.set_neighbor_finder(train_csr if phase == "train" else full_csr)
+    for _ in range(nb):
+      s, e = b * bs, min(n_edges, (b + 1) * bs)
+      plan = g[f"{tag}_plan{b}"] if (budget and phase == "train") else None
+      pos, neg = eng.compute_edge_probabilities(src[s:e], dst[s:e], negs[s:e], ts[s:e], eidx[s:e], phase == "train", plan)
+      what = f"{tag} batch {b} ({phase})"
+      emb = eng.last_embeddings.cpu().numpy()
+      assert_close_fp32(emb, g[f"{tag}_b{b}_emb"], 1e-5, what + " emb")
+      assert_close_fp32(pos.cpu().numpy(), g[f"{tag}_b{b}_pos"], 1e-5, what + " pos")
+      assert_close_fp32(neg.cpu().numpy(), g[f"{tag}_b{b}_neg"], 1e-5, what + " neg")
+      assert_close_fp32(eng.memory.cpu().numpy(), g[f"{tag}_b{b}_memory"], 1e-5, what + " memory")
+      assert np.array_equal(eng.last_update.cpu().numpy(), g[f"{tag}_b{b}_last_update"])
+      assert np.array_equal(eng.pending.cpu().numpy().astype(bool), g[f"{tag}_b{b}_pending"])
+      if reuse:
+        hist = np.stack([h.cpu().numpy() for h in eng.hist])
+        assert_close_fp32(hist, g[f"{tag}_b{b}_hist"], 1e-5, what + " hist")
+        if budget:
+          flags = np.stack([c.cpu().numpy() for c in eng.cache_flag])
+          assert np.array_equal(flags, g[f"{tag}_b{b}_cache_flag"])
+      b += 1
+  assert_close_fp32(eng.messages.cpu().numpy(), g[f"{tag}_final_messages"], 1e-5, tag + " messages")
+  assert np.array_equal(eng.msg_ts.cpu().numpy(), g[f"{tag}_final_timestamps"])
+
+
+def _synthetic(seed, n_nodes, n_edges, d_e):
+  rs = np.random.RandomState(seed)
+  w = 1.0 / np.arange(1, n_nodes + 1) ** 1.2
+  w /= w.sum()
+  perm = rs.permutation(n_nodes) + 1
+  src = perm[rs.choice(n_nodes, n_edges, p=w)].astype(np.int64)
+  dst = perm[rs.choice(n_nodes, n_edges, p=w)].astype(np.int64)
+  ts = np.sort(rs.uniform(0, 2.6e6, n_edges))
+  pos = rs.choice(np.arange(1, n_edges), n_edges // 100, replace=False)
+  ts[pos] = ts[pos - 1]
+  ts = np.sort(ts)
+  eidx = np.arange(1, n_edges + 1, dtype=np.int64)
+  ef = rs.randn(n_edges + 1, d_e).astype(np.float32)
+  ef[0] = 0
+  return src, dst, ts, eidx, ef
+
+
+@pytest.mark.parametrize("reuse", [True, False])
+def test_config4_batch_shape_vs_oracle(golden, reuse):
+  """4096-query batches (bs = 1365 interactions + 1 padding query is the bench shape; here bs=1365),
+  K = 10, 2 layers, 172-d edge features on a 20k-node / 300k-edge power-law graph: the HIP step
+  against the oracle over several consecutive batches (state carried), plus properties."""
+  from orca_amd import ops
+  from orca_amd.engine import OrcaEngine
+  g = golden("tgn.npz")
+  sd = {k[len("g172_sd."):]: g[k] for k in g.files if k.startswith("g172_sd.")}
+  N, E, bs, K = 20000, 300000, 1365, 10
+  src, dst, ts, eidx, ef = _synthetic(5, N, E, 172)
+  n_hist = 290000
+  eng = OrcaEngine(sd, ef, N + 1, 2, K, reuse, 0, device=DEV)
+  eng.set_neighbor_finder(ops.CSR.from_edges_device(*(torch.from_numpy(x).to(DEV) for x in (src, dst, eidx, ts)), N + 1))
+  ref = O.OracleTGN(sd, ef, N + 1, 2, K, reuse, 0)
+  ref.neighbor_finder = O.OracleNeighborFinder(src, dst, eidx, ts, max_node_idx=N)
+  rs = np.random.RandomState(6)
+  n_batches = 4 if reuse else 2
+  for b in range(n_batches):
+    s, e = n_hist + b * bs, n_hist + (b + 1) * bs
+    neg = rs.randint(1, N + 1, bs).astype(np.int64)
+    emb = eng.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True).cpu().numpy()
+    exp = ref.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True).numpy()
+    assert emb.shape == (3 * bs, 100)
+    assert_close_fp32(emb, exp, 1e-5, f"batch {b} emb")
+    assert_close_fp32(eng.memory.cpu().numpy(), ref.memory.numpy(), 1e-5, f"batch {b} memory")
+    assert np.array_equal(eng.last_update.cpu().numpy(), ref.last_update.numpy())
+    assert np.array_equal(eng.pending.cpu().numpy().astype(bool), ref.pending)
+    # properties: LayerNorm output rows have ~zero mean / unit variance under the affine params
+    assert np.isfinite(emb).all()
+    # duplicate root (node, t) queries get identical embeddings
+    nodes = np.concatenate([src[s:e], dst[s:e], neg])
+    t3 = np.concatenate([ts[s:e]] * 3)
+    key = np.stack([nodes.astype(np.float64), t3], axis=1)
+    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    assert np.array_equal(emb, emb[first][inv])
+  assert_close_fp32(eng.messages.cpu().numpy(), ref.messages.numpy(), 1e-5, "messages")
