@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- temporal edges/sec through (sample + 2-layer embed + memory), K=10, on MI355X.
+
+One "step" = one batch of the hot path in the reference's train ordering, forward only, no_grad,
+dropout off (model/tgn_model.py:95-147 with --reuse, i.e. Path B modules/embedding_module.py:154-182):
+sample 3*bs (node, t) root queries -> GRU overlay of pending memory rows -> layer-1 TGAT attention ->
+history push/pull -> layer-2 attention -> persist memory update -> raw-message build + store.
+
+Workload (BASELINE.json configs[3], the one the metric's north_star is quoted on; it fits one GPU):
+synthetic power-law temporal graph, 1M nodes / 100M edges, 172-d edge features, K=10, 2 layers,
+4096-query batches (bs = 1365 interactions -> 4095 root queries).  Everything is generated on the
+device and resident in HBM before the timed region.  N>1: state replicated, the global batch is
+N x 1365 interactions and each rank embeds its 4095-query slice (weak scaling); rows other ranks
+read later (history rows between layers, final embeddings) are exchanged with RCCL all-gather.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=200)
+  ap.add_argument("--warmup", type=int, default=50)
+  ap.add_argument("--nodes", type=int, default=1_000_000)
+  ap.add_argument("--edges", type=int, default=100_000_000)
+  ap.add_argument("--d-e", type=int, default=172)
+  ap.add_argument("--bs", type=int, default=1365, help="interactions per rank per batch (3*bs root queries)")
+  ap.add_argument("--k", type=int, default=10)
+  ap.add_argument("--layers", type=int, default=2)
+  ap.add_argument("--no-reuse", action="store_true", help="Path A (exact TGN recursion) instead of Path B")
+  ap.add_argument("--cpu-batches", type=int, default=200, help="batches of the CPU baseline sample (0 = skip)")
+  ap.add_argument("--no-kernel-events", action="store_true")
+  return ap.parse_args()
+
+
+class DeviceBackedRows:
+  """Host-side view of the 68.8 GB edge-feature table for the CPU baseline: rows are copied from HBM
+  on demand (input staging only -- no arithmetic happens on the device)."""
+
+  def __init__(self, table):
+    self.table = table
+    self.shape = table.shape
+
+  def __getitem__(self, idx):
+    idx = torch.as_tensor(idx)
+    return self.table[idx.to(self.table.device)].cpu()
+
+
+def cpu_baseline(args, csr, edge_feats, sd, batches, threads):
+  """The oracle (oracle/oracle.py, the CPU restatement of the reference's PyTorch+Numba path; "port")
+  timed on the host cores on the first batches of the timed sequence."""
+  from oracle import oracle as O
+  torch.set_num_threads(threads)
+  nf = O.OracleNeighborFinder.from_arrays(*csr.arrays_host())
+  ref = O.OracleTGN(sd, torch.zeros(1, args.d_e), args.nodes + 1, args.layers, args.k, not args.no_reuse, 0)
+  ref.edge_feats = DeviceBackedRows(edge_feats)
+  ref.neighbor_finder = nf
+  warm = 2
+  t0 = None
+  n_edges = 0
+  for i, b in enumerate(batches[:warm + args.cpu_batches]):
+    if i == warm:
+      t0 = time.perf_counter()
+    s, d, n, t, e = (x.cpu().numpy() for x in b)
+    ref.compute_temporal_embeddings(s, d, n, t, e, True)
+    if i >= warm:
+      n_edges += len(s)
+  dt = time.perf_counter() - t0
+  return {"value": n_edges / dt, "unit": "temporal edges/s", "cores": threads, "kind": "port",
+          "sample": f"{args.cpu_batches} consecutive {args.bs}-interaction batches of the same workload after {warm} "
+                    f"warm-up batches, oracle.OracleTGN ({'Path A' if args.no_reuse else 'Path B'}, forward, torch CPU "
+                    f"fp32 + serial C sampler), {dt:.1f} s of CPU work"}
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local = int(os.environ.get("LOCAL_RANK", "0"))
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+  torch.cuda.set_device(local)
+  dev = torch.device("cuda", local)
+  group = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=dev)
+    group = dist.group.WORLD
+
+  from orca_amd import ops, synth
+  from orca_amd.engine import OrcaEngine
+
+  t_setup = time.perf_counter()
+  src, dst, eidx, ts = synth.powerlaw_graph(args.nodes, args.edges, dev)
+  csr = ops.CSR.from_edges_device(src, dst, eidx, ts, args.nodes + 1)
+  ef = synth.edge_features(args.edges, args.d_e, dev)
+  sd = synth.tgn_state_dict(args.d_e, args.layers)
+  eng = OrcaEngine(sd, ef, args.nodes + 1, args.layers, args.k, reuse=not args.no_reuse, budget=0, device=dev,
+                   group=group)
+  eng.set_neighbor_finder(csr)
+  # consecutive time-ordered batches from the 70 % mark (train.py:131-137 chronological split)
+  gbs = args.bs * world
+  n_batches = args.warmup + args.steps
+  start = int(0.7 * args.edges)
+  if start + n_batches * gbs > args.edges:
+    start = max(0, args.edges - n_batches * gbs)
+  g = torch.Generator(device=dev)
+  g.manual_seed(7)
+  neg_all = torch.randint(1, args.nodes + 1, (n_batches * gbs,), generator=g, device=dev)
+  batches = []
+  for b in range(n_batches):
+    s, e = start + b * gbs, start + (b + 1) * gbs
+    batches.append((src[s:e], dst[s:e], neg_all[b * gbs:(b + 1) * gbs], ts[s:e], eidx[s:e]))
+  torch.cuda.synchronize()
+  t_setup = time.perf_counter() - t_setup
+
+  def barrier():
+    torch.cuda.synchronize()
+    if world > 1:
+      import torch.distributed as dist
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  with torch.no_grad():
+    for b in batches[:args.warmup]:
+      eng.compute_temporal_embeddings(*b, train=True)
+    if not args.no_kernel_events:
+      eng.prof = {}
+    barrier()
+    t0 = time.perf_counter()
+    for b in batches[args.warmup:]:
+      eng.compute_temporal_embeddings(*b, train=True)
+    barrier()
+    dt = time.perf_counter() - t0
+  if world > 1:
+    import torch.distributed as dist
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+  prof = eng.prof_summary()
+  eng.prof = None
+
+  if rank == 0:
+    Q = 3 * args.bs
+    out = {
+        "metric": "temporal edges/sec (sample+2-layer embed+memory), K=10",
+        "value": args.steps * gbs / dt,
+        "unit": "temporal edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic power-law temporal graph {args.nodes} nodes/{args.edges} edges, "
+                               f"{args.d_e}-d edge feats, K={args.k}, {args.layers} layers, "
+                               f"{'Path A exact recursion' if args.no_reuse else 'Path B --reuse'}, "
+                               f"{Q}-query batches ({args.bs} interactions) per GPU, forward train-order step",
+                   "root_queries_per_s": args.steps * gbs * 3 / dt,
+                   "setup_s": round(t_setup, 1)},
+    }
+    if "tgat_forward" in prof:
+      n, ms = prof["tgat_forward"]
+      per_launch_q = Q * (1 + args.k) if args.no_reuse and args.layers > 1 else Q
+      # Path A launches differ in size (layer 1: Q*(1+K) queries, layer 2: Q); use the mean per launch
+      q_mean = (Q * (1 + args.k) + Q) / 2 if args.no_reuse and args.layers == 2 else per_launch_q
+      flops = synth.tgat_flops_per_query(args.d_e, args.k) * q_mean
+      ach = flops / (ms * 1e-3) / 1e12
+      out["roofline"] = {"kernel": "k_tgat_forward", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launches": n, "avg_launch_ms": ms, "queries_per_launch": q_mean,
+                         "flops_per_query": synth.tgat_flops_per_query(args.d_e, args.k),
+                         "bytes_per_query": synth.tgat_bytes_per_query(args.d_e, args.k),
+                         "hbm_gbs_algorithmic": synth.tgat_bytes_per_query(args.d_e, args.k) * q_mean / (ms * 1e-3) / 1e9}
+      out["kernels_ms"] = {k: {"launches": v[0], "avg_ms": v[1]} for k, v in prof.items()}
+    if world == 1 and args.cpu_batches > 0:
+      threads = min(16, os.cpu_count() or 1)
+      out["cpu_baseline"] = cpu_baseline(args, csr, ef, sd, batches[args.warmup:], threads)
+    print(json.dumps(out), flush=True)
+  if world > 1:
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -82,6 +82,18 @@ class OracleNeighborFinder:
     if rc != 0:
       raise IndexError("node id out of range in get_neighbor_finder")
 
+  @classmethod
+  def from_arrays(cls, indptr, nbr, eid, ts):
+    """NeighborFinder(node_to_neighbors, node_to_edge_idxs, node_to_edge_timestamps) (utils/util.py:123-126)
+    on already-flattened, time-sorted lists."""
+    self = cls.__new__(cls)
+    self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    self.nbr = np.ascontiguousarray(nbr, dtype=np.int32)
+    self.eid = np.ascontiguousarray(eid, dtype=np.int32)
+    self.ts = np.ascontiguousarray(ts, dtype=np.float64)
+    self.n_rows = len(self.indptr) - 1
+    return self
+
   def find_before(self, src_idx, cut_time):
     """utils/util.py:129-131."""
     i = lib().orc_find_before(_p(self.indptr, c_i64p), _p(self.ts, c_f64p), int(src_idx), float(cut_time))

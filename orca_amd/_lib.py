@@ -72,6 +72,10 @@ def load():
     if not os.path.exists(LIB_PATH):
       raise OrcaError(f"{LIB_PATH} is missing: build it with `python -m orca_amd.build` "
                       "(there is no CPU fallback for the HIP path)")
+    # torch must be loaded first: its wheel carries its own libamdhip64 and the device pointers we are
+    # handed come from that runtime; loading ours first would bring a second HIP runtime into the
+    # process (observed: "no ROCm-capable device is detected" from the late-loaded one).
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
       fn = getattr(L, name)

@@ -70,6 +70,22 @@ class OrcaEngine:
     self.csr = None
     self.test_mode = False
     self.batch_counter = 0
+    self.prof = None     # set to {} to bracket the kernels with HIP events (bench.py roofline)
+
+  def _timed(self, name, fn, *a, **k):
+    """Runs fn; when profiling is on, brackets it with HIP events on the launch stream."""
+    if self.prof is None:
+      return fn(*a, **k)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn(*a, **k)
+    e1.record()
+    self.prof.setdefault(name, []).append((e0, e1))
+    return r
+
+  def prof_summary(self):
+    """{kernel: (launches, mean ms)}; call after torch.cuda.synchronize()."""
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in (self.prof or {}).items()}
 
   # -------------------------------------------------------------------------------------------
   def load_state_dict(self, sd):
@@ -138,8 +154,8 @@ class OrcaEngine:
     n32 = ids32.numel() if ids32 is not None else 0
     n64 = ids64.numel() if ids64 is not None else 0
     bound = self._build_worklist(ids32, ids64, n32 + n64)
-    ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory,
-                   self.overlay)
+    self._timed("gru_update", ops.gru_update, self.gru_blob, self.msg_dim, self.worklist, bound, self.count,
+                self.messages, self.memory, self.overlay)
 
   def _persist_memory(self, ids64):
     """memory_updater.update_memory (:25-39) + memory.clear_messages (memory.py:49-50)."""
@@ -158,7 +174,7 @@ class OrcaEngine:
     ops.fill_u8(self.pending, 0)
 
   def _sample(self, nodes, ts):
-    nbr, eid, _, dt = ops.sample_recent(self.csr, nodes, ts, self.K)
+    nbr, eid, _, dt = self._timed("sample_recent", ops.sample_recent, self.csr, nodes, ts, self.K)
     return nbr, eid, dt
 
   def _attend(self, layer, Q, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr_idx, from_memory):
@@ -168,7 +184,7 @@ class OrcaEngine:
               edge_table=self.edge_feats, edge_idx=eid, dt=dt, time_w=self.time_w, time_b=self.time_b)
     if from_memory and train:
       kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
-    out, _ = ops.tgat_forward(self.att_blobs[layer - 1], self.d_e, Q, self.K, **kw)
+    out, _ = self._timed("tgat_forward", ops.tgat_forward, self.att_blobs[layer - 1], self.d_e, Q, self.K, **kw)
     return out
 
   # -------------------------------------------------------------------------------------------
