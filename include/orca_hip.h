@@ -208,6 +208,19 @@ int orca_gather_rows(const float* table, int64_t width, const int64_t* idx64, co
 int orca_scatter_rows(float* table, int64_t width, const int64_t* ids, int64_t n, const float* x,
                       void* stream);
 
+/* ---- offline cache planner: utils/cache.py:19-89 (read_batches) + :92-166 (MRD_numba) ------- */
+
+/* HOST function (all pointers are host memory).  For the E training interactions (src, dst) cut into
+ * batches of bs, and the sampled neighbours of every src / dst query (nbr_src, nbr_dst: int32 [E, K],
+ * from orca_sample_recent at the interaction's own timestamp), writes per batch b the ids to keep
+ * cached: plan_out[b*budget .. b*budget + plan_len[b]).  stats[0..1] = n_reuse, n_recompute
+ * (cache.py:115,119); *avg_reuse_distance as cache.py:165.  Equal reuse distances are ordered by node
+ * id (the reference's unstable argsort leaves that order undefined: SURVEY H11). */
+int orca_mrd_plan_host(int64_t n_interactions, int64_t bs, int K, const int64_t* src_host, const int64_t* dst_host,
+                       const int32_t* nbr_src_host, const int32_t* nbr_dst_host, int64_t n_nodes, int64_t budget,
+                       int64_t* plan_out_host, int64_t* plan_len_host, int64_t* stats_host,
+                       double* avg_reuse_distance_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,7 @@ SIGNATURES = {
     "orca_history_push": (i32, [vp, vp, vp, i64, vp, i64, i64, vp]),
     "orca_gather_rows": (i32, [vp, i64, vp, vp, i64, vp, vp]),
     "orca_scatter_rows": (i32, [vp, i64, vp, i64, vp, vp]),
+    "orca_mrd_plan_host": (i32, [i64, i64, i32, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]),
 }
 
 _lib = None

@@ -1,0 +1,72 @@
+"""model/temporal_attention.py:6-56 + MergeLayer utils/util.py:12-24 -- TemporalAttentionLayer."""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class MergeLayer(nn.Module):
+  """utils/util.py:12-24 (parameter container; the fused kernel evaluates it)."""
+
+  def __init__(self, dim1, dim2, dim3, dim4):
+    super().__init__()
+    self.fc1 = nn.Linear(dim1 + dim2, dim3)
+    self.fc2 = nn.Linear(dim3, dim4)
+    self.act = nn.ReLU()
+    nn.init.xavier_normal_(self.fc1.weight)
+    nn.init.xavier_normal_(self.fc2.weight)
+
+  def forward(self, x1, x2):
+    return self.fc2(self.act(self.fc1(torch.cat([x1, x2], dim=1))))
+
+
+class TemporalAttentionLayer(nn.Module):
+  """Same constructor, parameters (state_dict keys) and forward contract as the reference; forward
+  runs the fused HIP kernel.  Dropout is not applied (inference / module.eval() semantics)."""
+
+  def __init__(self, n_node_features, n_neighbors_features, n_edge_features, time_dim, output_dimension, n_head=2,
+               dropout=0.1):
+    super().__init__()
+    if (n_node_features, n_neighbors_features, time_dim, output_dimension, n_head) != (ops.D, ops.D, ops.D, ops.D, 2):
+      raise ValueError("TemporalAttentionLayer: the HIP path is built for 100-d node/time features and 2 heads")
+    self.n_head = n_head
+    self.feat_dim = n_node_features
+    self.time_dim = time_dim
+    self.n_edge_features = n_edge_features
+    self.query_dim = n_node_features + time_dim
+    self.key_dim = n_neighbors_features + time_dim + n_edge_features
+    self.merger = MergeLayer(self.query_dim, n_node_features, n_node_features, output_dimension)
+    self.multi_head_target = nn.MultiheadAttention(embed_dim=self.query_dim, kdim=self.key_dim, vdim=self.key_dim,
+                                                   num_heads=n_head, dropout=dropout)
+    self.norm = nn.LayerNorm(output_dimension)
+    self._blob = None
+    self._blob_key = None
+
+  def packed(self):
+    """The kernel's parameter blob, re-packed whenever a parameter changed (in place or rebound)."""
+    ps = list(self.parameters())
+    key = tuple((p.data_ptr(), p._version) for p in ps)
+    if self._blob is None or key != self._blob_key:
+      dev = ps[0].device
+      sd = {k: v for k, v in self.state_dict().items()}
+      self._blob = ops.tgat_pack(sd, self.n_edge_features, dev, None)
+      self._blob_key = key
+    return self._blob
+
+  @torch.no_grad()
+  def forward(self, src_node_features, src_time_features, neighbors_features, neighbors_time_features, edge_features,
+              neighbors_padding_mask):
+    """[B,100], [B,1,100], [B,K,100], [B,K,100], [B,K,d_e], bool [B,K] (mutated in place as
+    temporal_attention.py:46-47 does) -> (out [B,100], weights [B,K])."""
+    B, K = neighbors_padding_mask.shape
+    mask = neighbors_padding_mask
+    if mask.dtype != torch.bool or not mask.is_contiguous():
+      raise TypeError("neighbors_padding_mask must be a contiguous torch.bool tensor")
+    f = lambda x, w: x.float().contiguous().view(-1, w)
+    out, wts = ops.tgat_forward(self.packed(), self.n_edge_features, B, K, want_weights=True,
+                                src_table=f(src_node_features, self.feat_dim),
+                                nbr_table=f(neighbors_features, self.feat_dim),
+                                edge_table=f(edge_features, self.n_edge_features), mask=mask.view(torch.uint8),
+                                src_time=f(src_time_features, self.time_dim),
+                                nbr_time=f(neighbors_time_features, self.time_dim))
+    return out, wts

@@ -27,13 +27,24 @@ __global__ void k_worklist(const int32_t* __restrict__ ids32, int64_t n32, const
                            int64_t n64, const uint8_t* __restrict__ flags, int32_t* stamp, int32_t epoch,
                            int64_t n_nodes, int32_t* worklist, int32_t* count) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n32 + n64) return;
-  int64_t id = i < n32 ? (int64_t)ids32[i] : ids64[i - n32];
-  if (id < 0 || id >= n_nodes) return;
-  if (flags && !flags[id]) return;
-  if (atomicExch(&stamp[id], epoch) == epoch) return;   // somebody else already claimed this id
-  int pos = atomicAdd(count, 1);
-  worklist[pos] = (int32_t)id;
+  bool take = false;
+  int64_t id = -1;
+  if (i < n32 + n64) {
+    id = i < n32 ? (int64_t)ids32[i] : ids64[i - n32];
+    take = id >= 0 && id < n_nodes && (!flags || flags[id]);
+    // cheap pre-check keeps hub ids (thousands of duplicates) from hammering one address
+    if (take && __builtin_nontemporal_load(&stamp[id]) == epoch) take = false;
+    if (take) take = atomicExch(&stamp[id], epoch) != epoch;   // first claimant of this id wins
+  }
+  // one atomicAdd per wavefront instead of one per id
+  const unsigned long long m = __ballot(take);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(count, __popcll(m));
+  base = __shfl(base, leader, 64);
+  if (take) worklist[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)id;
 }
 
 __global__ void k_set_flags(uint8_t* flags, const int64_t* ids64, const int32_t* ids32, int64_t n,

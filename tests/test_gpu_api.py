@@ -1,0 +1,241 @@
+"""The host-side mirror of the reference's entry points (orca_amd/api: same names, arguments and error
+behaviour as LuckyLYM/Orca) against the golden vectors captured from the reference.  These tests are
+written the way a test of the reference itself would read.  Needs a real MI355X."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close_fp32
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_num_threads(1)
+DEV = torch.device("cuda:0")
+
+
+class Data:
+  def __init__(self, sources, destinations, timestamps, edge_idxs):
+    self.sources, self.destinations, self.timestamps, self.edge_idxs = sources, destinations, timestamps, edge_idxs
+    self.n_interactions = len(sources)
+
+
+@pytest.fixture(scope="module")
+def api():
+  import orca_amd.api as A
+  return A
+
+
+@pytest.mark.parametrize("tag", ["sorted", "shuf"])
+def test_neighbor_finder(api, golden, tag):
+  g = golden("sampler.npz")
+  src, dst, ts, eidx = g["src"], g["dst"], g["ts"], g["eidx"]
+  if tag == "shuf":
+    s = g["shuf"]
+    src, dst, ts, eidx = src[s], dst[s], ts[s], eidx[s]
+  nf = api.get_neighbor_finder(Data(src, dst, ts, eidx), max_node_idx=63, device=DEV)
+  assert np.array_equal(np.concatenate(nf.node_to_neighbors), g[f"{tag}_nbr"])
+  assert np.array_equal(np.concatenate(nf.node_to_edge_timestamps), g[f"{tag}_ts"])
+  qn, qt = g[f"{tag}_q_nodes"], g[f"{tag}_q_ts"]
+  for K in (0, 1, 5, 10, 20):
+    nbr, ei, et = nf.get_temporal_neighbor(qn, qt, K)
+    assert nbr.dtype == np.int32 and ei.dtype == np.int32 and et.dtype == np.float32
+    assert np.array_equal(nbr, g[f"{tag}_K{K}_nbr"])
+    assert np.array_equal(ei, g[f"{tag}_K{K}_eidx"])
+    assert np.array_equal(et.view(np.uint32), g[f"{tag}_K{K}_et"].view(np.uint32))
+    deltas = torch.from_numpy(qt[:, np.newaxis] - et).float().numpy()      # embedding_module.py:130-131 on the host
+    assert np.array_equal(deltas.view(np.uint32), g[f"{tag}_K{K}_dt"].view(np.uint32))
+  for n, t, ln in zip(g[f"{tag}_fb_nodes"], g[f"{tag}_fb_ts"], g[f"{tag}_fb_len"]):
+    a, b, c = nf.find_before(int(n), float(t))
+    assert len(a) == len(b) == len(c) == ln
+  with pytest.raises(IndexError):
+    nf.get_temporal_neighbor(np.array([64]), np.array([1.0]), 5)
+  # the jitclass constructor form: three ragged lists
+  nf2 = api.NeighborFinder(nf.node_to_neighbors, nf.node_to_edge_idxs, nf.node_to_edge_timestamps, device=DEV)
+  a = nf2.get_temporal_neighbor(qn, qt, 10)
+  assert np.array_equal(a[0], g[f"{tag}_K10_nbr"]) and np.array_equal(a[1], g[f"{tag}_K10_eidx"])
+
+
+def test_time_encode(api, golden):
+  g = golden("time_encode.npz")
+  te = api.TimeEncode(100).to(DEV)
+  assert np.array_equal(te.w.weight.detach().cpu().numpy().reshape(-1), g["w"])
+  assert list(te.state_dict().keys()) == ["w.weight", "w.bias"]
+  out = te(torch.from_numpy(g["t"]).to(DEV))
+  assert out.shape == (6, 10, 100)
+  assert_close_fp32(out.cpu().numpy(), g["out"], 1e-5, "TimeEncode")
+
+
+@pytest.mark.parametrize("tag", ["de172_K10_", "de1_K10_", "de4_K20_", "de172_K1_"])
+def test_temporal_attention_layer(api, golden, tag):
+  g = golden("attention.npz")
+  d_e = g[tag + "edge"].shape[2]
+  layer = api.TemporalAttentionLayer(100, 100, d_e, 100, 100, n_head=2, dropout=0.1)
+  layer.load_state_dict({k[len(tag + "sd."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "sd.")},
+                        strict=True)
+  layer = layer.to(DEV).eval()
+  mask = torch.from_numpy(g[tag + "mask_in"].copy()).to(DEV)
+  t = lambda k: torch.from_numpy(g[tag + k]).to(DEV)
+  out, w = layer(t("src"), t("src_t"), t("nbr"), t("nbr_t"), t("edge"), mask)
+  assert_close_fp32(out.cpu().numpy(), g[tag + "out"], 1e-5, tag + "out")
+  assert np.array_equal(mask.cpu().numpy(), g[tag + "mask_out"])           # mutated in place, as upstream
+  if tag + "weights" in g.files:
+    assert_close_fp32(w.cpu().numpy(), g[tag + "weights"], 1e-5, tag + "weights")
+  # parameters changed in place -> the packed blob follows
+  with torch.no_grad():
+    layer.norm.bias.add_(1.0)
+  out2, _ = layer(t("src"), t("src_t"), t("nbr"), t("nbr_t"), t("edge"), torch.from_numpy(g[tag + "mask_in"].copy()).to(DEV))
+  assert_close_fp32(out2.cpu().numpy(), g[tag + "out"] + 1.0, 1e-5, tag + "out after in-place update")
+
+
+def test_history(api, golden):
+  g = golden("history.npz")
+  h = api.History(50, 100, DEV, history_budget=10)
+  h.push(torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["ids"]).to(DEV))
+  assert np.array_equal(h.emb.cpu().numpy(), g["emb"])
+  assert np.array_equal(h.pull(torch.from_numpy(g["pull_ids"]).to(DEV)).cpu().numpy(), g["pulled"])
+  h.update_flag(None, g["ids"][:5])
+  assert np.array_equal(h.cache_flag, g["flag_acc"])
+  h.update_flag(g["plan"], g["ids"])
+  assert np.array_equal(h.cache_flag, g["flag_plan"])
+  h2 = api.History(50, 100, DEV)
+  out = h2.push_and_pull(torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["ids"]).to(DEV),
+                         torch.from_numpy(g["pull_ids"]).to(DEV))
+  assert np.array_equal(out.cpu().numpy(), g["pulled"])
+  h2.reset_parameters()
+  assert float(h2.emb.abs().sum()) == 0.0
+
+
+def test_message_aggregators(api, golden):
+  g = golden("aggregators.npz")
+  from collections import defaultdict
+  d = defaultdict(list)
+  for i, n in enumerate(g["ids"]):
+    d[int(n)].append((torch.from_numpy(g["msgs"][i]), torch.tensor(g["ts"][i])))
+  for kind in ("last", "mean"):
+    agg = api.get_message_aggregator(kind, DEV)
+    u, m, t = agg.aggregate(g["query_ids"], d)
+    assert list(u) == list(g[kind + "_ids"])
+    assert_close_fp32(m.cpu().numpy(), g[kind + "_msgs"], 1e-6, kind + " msgs")
+    assert np.array_equal(t.cpu().numpy(), g[kind + "_ts"])
+  with pytest.raises(ValueError):
+    api.get_message_aggregator("sum", DEV)
+  assert api.get_message_aggregator("last", DEV).aggregate(np.array([20]), d) == ([], [], [])
+
+
+def test_memory_and_updater(api):
+  """Memory / get_memory_updater in the reference's own call pattern (memory_updater.py:25-78)."""
+  rs = np.random.RandomState(0)
+  N, msg = 300, 472
+  mem = api.Memory(N, 100, msg, msg, device=DEV)
+  upd = api.get_memory_updater("gru", msg, 100, DEV).to(DEV)
+  assert api.get_memory_updater("lstm", msg, 100, DEV) is None
+  P = {k: v.detach().cpu() for k, v in upd.memory_updater.state_dict().items()}
+  mem.memory = torch.from_numpy(rs.randn(N, 100).astype(np.float32)).to(DEV)
+  ids = np.unique(rs.randint(1, N, 80))
+  msgs = torch.from_numpy(rs.randn(len(ids), msg).astype(np.float32))
+  ts = torch.from_numpy(rs.uniform(0, 1e5, len(ids)).astype(np.float32))
+  mem.store_raw_messages(ids, msgs.to(DEV), ts.to(DEV))
+  assert np.array_equal(np.nonzero(mem.nodes)[0], ids)
+  m0 = mem.memory.cpu().clone()
+  index = np.unique(np.concatenate([ids[:30], rs.randint(1, N, 40)]))
+  view, last = upd.get_updated_memory(mem, index)
+  hit = index[np.isin(index, ids)]
+  exp = m0.clone()
+  exp[hit] = O.gru_cell(P, msgs[np.searchsorted(ids, hit)], m0[hit])
+  assert_close_fp32(view[torch.from_numpy(np.arange(N))].cpu().numpy(), exp.numpy(), 1e-5, "get_updated_memory")
+  assert np.array_equal(mem.memory.cpu().numpy(), m0.numpy())               # persistent table untouched
+  exp_last = np.zeros(N, np.float32)
+  exp_last[hit] = ts.numpy()[np.searchsorted(ids, hit)]
+  assert np.array_equal(last.cpu().numpy(), exp_last)
+  positives = ids[10:50]
+  upd.update_memory(mem, positives)
+  mem.clear_messages(positives)
+  exp = m0.clone()
+  exp[positives] = O.gru_cell(P, msgs[10:50], m0[positives])
+  assert_close_fp32(mem.memory.cpu().numpy(), exp.numpy(), 1e-5, "update_memory")
+  assert np.array_equal(np.nonzero(mem.nodes)[0], np.setdiff1d(ids, positives))
+  bk = mem.backup_memory()
+  upd.update_memory_in_test(mem)
+  assert not mem.nodes.any()
+  rest = np.setdiff1d(ids, positives)
+  exp[rest] = O.gru_cell(P, msgs[np.searchsorted(ids, rest)], m0[rest])
+  assert_close_fp32(mem.memory.cpu().numpy(), exp.numpy(), 1e-5, "update_memory_in_test")
+  mem.restore_memory(bk)
+  assert np.array_equal(np.nonzero(mem.nodes)[0], rest)
+
+
+@pytest.mark.parametrize("tag,graph", [("A1", "g172"), ("A2", "g172"), ("B2", "g172"), ("C2", "g172"),
+                                       ("B2z", "g1"), ("A1z", "g1")])
+def test_tgn_flow_like_the_reference(api, golden, tag, graph):
+  """The flow of tests/golden/make_golden.py:run_tgn, with orca_amd.api in place of the reference."""
+  g = golden("tgn.npz")
+  L, reuse, budget, bs, K, n_train, n_eval, n_nodes, n_edges = [int(x) for x in g[f"{tag}_meta"]]
+  src, dst, ts, eidx = (g[f"{graph}_{k}"] for k in ("src", "dst", "ts", "eidx"))
+  n_tr = n_train * bs
+  args = argparse.Namespace(n_nodes=n_nodes + 1, n_edges=n_edges + 1, reuse=bool(reuse), budget=budget, gradient=False,
+                            bs=bs, n_degree=K)
+  train_nf = api.get_neighbor_finder(Data(src[:n_tr], dst[:n_tr], ts[:n_tr], eidx[:n_tr]), max_node_idx=n_nodes, device=DEV)
+  full_nf = api.get_neighbor_finder(Data(src, dst, ts, eidx), max_node_idx=n_nodes, device=DEV)
+  tgn = api.TGN(neighbor_finder=train_nf, node_features=None, edge_features=g[f"{graph}_edge_feats"], device=DEV,
+                n_layers=L, n_heads=2, dropout=0.4, use_memory=True, node_dimension=100, time_dimension=100,
+                memory_dimension=100, embedding_module_type="graph_attention", message_function="identity",
+                aggregator_type="last", memory_updater_type="gru", n_neighbors=K, args=args)
+  own = tgn.state_dict()
+  sd = {k[len(graph + "_sd."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(graph + "_sd.")}
+  missing = tgn.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+  assert not missing.missing_keys, missing
+  tgn.eval()
+  negs = g[f"{tag}_negs"]
+  b = 0
+  for phase, nb in (("train", n_train), ("eval", n_eval)):
+    if phase == "eval":
+      tgn.set_neighbor_finder(full_nf)
+    for _ in range(nb):
+      s, e = b * bs, min(n_edges, (b + 1) * bs)
+      plan = g[f"{tag}_plan{b}"] if (budget and phase == "train") else None
+      pos, neg = tgn.compute_edge_probabilities(src[s:e], dst[s:e], negs[s:e], ts[s:e], eidx[s:e], K, bool(reuse),
+                                                phase == "train", plan)
+      what = f"{tag} batch {b} ({phase})"
+      assert_close_fp32(pos.cpu().numpy(), g[f"{tag}_b{b}_pos"], 1e-5, what + " pos")
+      assert_close_fp32(neg.cpu().numpy(), g[f"{tag}_b{b}_neg"], 1e-5, what + " neg")
+      assert_close_fp32(tgn.memory.memory.cpu().numpy(), g[f"{tag}_b{b}_memory"], 1e-5, what + " memory")
+      assert np.array_equal(tgn.memory.last_update.cpu().numpy(), g[f"{tag}_b{b}_last_update"])
+      assert np.array_equal(tgn.memory.nodes, g[f"{tag}_b{b}_pending"])
+      if reuse:
+        hs = tgn.embedding_module.histories
+        assert_close_fp32(np.stack([h.emb.cpu().numpy() for h in hs]), g[f"{tag}_b{b}_hist"], 1e-5, what + " hist")
+        if budget:
+          assert np.array_equal(np.stack([h.cache_flag for h in hs]).astype(np.uint8), g[f"{tag}_b{b}_cache_flag"])
+      b += 1
+  assert_close_fp32(tgn.memory.messages.cpu().numpy(), g[f"{tag}_final_messages"], 1e-5, tag + " messages")
+  assert np.array_equal(tgn.memory.timestamps.cpu().numpy(), g[f"{tag}_final_timestamps"])
+  with pytest.raises(ValueError):
+    api.get_embedding_module("graph_sum", None, None, None, None, None, 1, 100, 172, 100, 100, DEV)
+
+
+@pytest.mark.parametrize("tag", ["tight", "loose", "mid"])
+def test_get_cache_plan(api, golden, tag, capsys):
+  g = golden("mrd.npz")
+  n_nodes, n_edges, bs, K, budget, num_batch = [int(x) for x in g[f"{tag}_meta"]]
+  src, dst, ts, eidx = (g[f"{tag}_{k}"] for k in ("src", "dst", "ts", "eidx"))
+  data = Data(src, dst, ts, eidx)
+  nf = api.get_neighbor_finder(data, max_node_idx=n_nodes, device=DEV)
+  args = argparse.Namespace(n_nodes=n_nodes + 1, bs=bs, n_degree=K, budget=budget)
+  plans = api.get_cache_plan(args, data, nf, args.n_nodes, "MRD")
+  assert "n_reuse" in capsys.readouterr().out
+  assert len(plans) == num_batch
+  assert np.array_equal(np.array([len(p) for p in plans]), g[f"{tag}_plan_len"])
+  # exact plans under the defined (distance, node id) order == the oracle in stable mode
+  onf = O.OracleNeighborFinder(src, dst, eidx, ts, max_node_idx=n_nodes)
+  nb, tl, nl, occ = O.read_batches(src, dst, ts, onf, bs, K, n_nodes + 1)
+  ref, _, _, _ = O.mrd_plan(n_nodes + 1, nb, budget, tl, nl, occ, stable=True)
+  for a, b in zip(plans, ref):
+    assert np.array_equal(a, b)
+  if tag == "loose":   # no tie group straddles the budget cut: same sets as the reference's own plan
+    off = np.concatenate([[0], np.cumsum(g[f"{tag}_plan_len"])])
+    for i, p in enumerate(plans):
+      assert np.array_equal(np.sort(p), np.sort(g[f"{tag}_plan_flat"][off[i]:off[i + 1]]))
+  with pytest.raises(SystemExit):
+    api.get_cache_plan(args, data, nf, args.n_nodes, "LRU")
