@@ -18,6 +18,7 @@ results equal 1-rank results.
 import numpy as np
 import torch
 
+from . import dist as dist_utils
 from . import ops
 from ._lib import ORCA_D, OrcaError
 
@@ -190,20 +191,13 @@ class OrcaEngine:
   # -------------------------------------------------------------------------------------------
   def _slice(self, Q):
     """contiguous query slice of this rank"""
-    per = (Q + self.world - 1) // self.world
-    lo = min(self.rank * per, Q)
-    return lo, min(lo + per, Q), per
+    return dist_utils.query_slice(Q, self.rank, self.world)
 
   def _all_gather_rows(self, x, Q, per):
     """x: this rank's [n_local, D] rows of a [Q, D] result -> the full [Q, D] on every rank."""
     if self.world == 1:
       return x
-    import torch.distributed as dist
-    buf = torch.zeros(per, x.shape[1], dtype=x.dtype, device=x.device)
-    buf[:x.shape[0]] = x
-    full = torch.empty(self.world * per, x.shape[1], dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(full, buf, group=self.group)
-    return full[:Q]
+    return self._timed("all_gather", dist_utils.all_gather_rows, x, Q, per, self.group)
 
   # Path A: embedding_module.py:116-147
   def _embed_exact(self, nodes, ts, train):
