@@ -139,6 +139,10 @@ typedef struct {
 int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
                       float* out, float* out_weights, void* stream);
 
+/* Profiling aid (no counterpart in the reference): when buf != NULL (device int64 [ceil(Q/16) * 16]) later
+ * orca_tgat_forward launches write the 100 MHz real-time counter at each internal phase boundary. */
+int orca_debug_tgat_phase_clock(void* buf);
+
 /* ---- GRU memory updater: modules/memory_updater.py:25-86 --------------------------------- */
 
 int64_t orca_gru_blob_floats(int msg_dim);
@@ -156,14 +160,14 @@ int orca_gru_update(const float* blob, int msg_dim, const int32_t* ids, int64_t 
 
 /* ---- node-id bookkeeping that the reference does with NumPy on the host ------------------- */
 
-/* Append to worklist every distinct id of the concatenation of ids32 (n32 int32 values, e.g. the
+/* Writes to worklist every distinct id of the concatenation of ids32 (n32 int32 values, e.g. the
  * sampled neighbours) and ids64 (n64 int64 values, e.g. the roots) whose flags[id] != 0 (flags may
- * be NULL = take all).  `stamp` is an int32 [n_nodes] scratch table owned by the caller, `epoch` a
- * value never used before on it (replaces np.unique + memory.nodes[index] of
- * modules/memory_updater.py:60-65 and embedding_module.py:121,160).  *count must be zeroed by the
- * caller (orca_fill_i32).  Order of the work-list is unspecified. */
+ * be NULL = take all), and their number to *count (device int, zeroed here).  `slot` is the caller's
+ * int64 [n_nodes] scratch table and `epoch` a value greater than any used before on it plus the
+ * length of that use (as in orca_segment_last).  Replaces np.unique + memory.nodes[index] of
+ * modules/memory_updater.py:60-65 and embedding_module.py:121,160.  Order of the list is unspecified. */
 int orca_worklist_build(const int32_t* ids32, int64_t n32, const int64_t* ids64, int64_t n64,
-                        const uint8_t* flags, int32_t* stamp, int32_t epoch, int64_t n_nodes,
+                        const uint8_t* flags, int64_t* slot, int64_t epoch, int64_t n_nodes,
                         int32_t* worklist, int32_t* count, void* stream);
 int orca_fill_i32(int32_t* p, int64_t n, int32_t v, void* stream);
 int orca_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream);

@@ -44,10 +44,11 @@ SIGNATURES = {
     "orca_tgat_blob_floats": (i64, [i32]),
     "orca_tgat_pack": (i32, [i32] + [vp] * 14),
     "orca_tgat_forward": (i32, [vp, i32, ctypes.POINTER(TgatInputs), i64, i32, vp, vp, vp]),
+    "orca_debug_tgat_phase_clock": (i32, [vp]),
     "orca_gru_blob_floats": (i64, [i32]),
     "orca_gru_pack": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "orca_gru_update": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
-    "orca_worklist_build": (i32, [vp, i64, vp, i64, vp, vp, i32, i64, vp, vp, vp]),
+    "orca_worklist_build": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, vp]),
     "orca_fill_i32": (i32, [vp, i64, i32, vp]),
     "orca_fill_u8": (i32, [vp, i64, u8, vp]),
     "orca_set_flags": (i32, [vp, vp, vp, i64, vp, u8, vp]),

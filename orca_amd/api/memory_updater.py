@@ -55,8 +55,8 @@ class GRUMemoryUpdater(nn.Module):
     n = memory.memory.shape[0]
     dev = memory.memory.device
     s = self._scratch
-    if s is None or s["stamp"].numel() != n or s["stamp"].device != dev:
-      s = self._scratch = dict(stamp=torch.zeros(n, dtype=torch.int32, device=dev), epoch=0,
+    if s is None or s["slot"].numel() != n or s["slot"].device != dev:
+      s = self._scratch = dict(slot=torch.zeros(n, dtype=torch.int64, device=dev), epoch=1,
                                worklist=torch.zeros(n, dtype=torch.int32, device=dev),
                                count=torch.zeros(1, dtype=torch.int32, device=dev),
                                overlay=torch.zeros(n, ops.D, device=dev))
@@ -64,9 +64,8 @@ class GRUMemoryUpdater(nn.Module):
 
   def _worklist(self, memory, ids64):
     s = self._work(memory)
-    s["epoch"] += 1
-    ops.fill_i32(s["count"], 0)
-    ops.worklist_build(None, ids64, memory.pending, s["stamp"], s["epoch"], s["worklist"], s["count"])
+    ops.worklist_build(None, ids64, memory.pending, s["slot"], s["epoch"], s["worklist"], s["count"])
+    s["epoch"] += ids64.numel() + 1
     return s
 
   @staticmethod

@@ -45,31 +45,43 @@ __host__ __device__ static inline int64_t pw_floats(int N, int Kd) { return (int
 // One wave accumulates up to NT 16x16 output tiles of C = A(16 x 16*KB) * PW.
 // a_row: LDS pointer to this lane's A row (row l&15) already offset by 4*(l>>4) floats.
 // pw: packed matrix base; tile[t] the n-tile ids; nt <= NT of them are live (wave-uniform).
-template <int NT>
+// The B operands stream from L2 (every tile is used by exactly one wave of the workgroup, so there is
+// nothing to share through LDS); they are fetched G k-blocks ahead, double buffered in registers, so a
+// chain of KB dependent steps pays the L2 latency once per group instead of once per k-block.
+template <int NT, int G = (NT == 1 ? 6 : (NT == 2 ? 3 : 2))>
 __device__ __forceinline__ void wave_gemm16(const float* a_row, const f32x4* __restrict__ pw, int KB,
                                             const int (&tile)[NT], int nt, f32x4 (&acc)[NT], int lane) {
   const f32x4* bp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) bp[t] = pw + (int64_t)(t < nt ? tile[t] : tile[0]) * KB * 64 + lane;
-  f32x4 bcur[NT], bnext[NT];
+  f32x4 cur[G][NT], nxt[G][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-    if (t < nt) bcur[t] = bp[t][0];
-  for (int kb = 0; kb < KB; ++kb) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(a_row + kb * 16);
-    if (kb + 1 < KB) {
+  for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (t < nt) bnext[t] = bp[t][(kb + 1) * 64];
-    }
+    for (int t = 0; t < NT; ++t)
+      if (g < KB && t < nt) cur[g][t] = bp[t][g * 64];
+  for (int kb0 = 0; kb0 < KB; kb0 += G) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int g = 0; g < G; ++g)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bcur[t][s], acc[t], 0, 0, 0);
+        if (kb0 + G + g < KB && t < nt) nxt[g][t] = bp[t][(kb0 + G + g) * 64];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (kb0 + g < KB) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(a_row + (kb0 + g) * 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], cur[g][t][s], acc[t], 0, 0, 0);
+        }
+      }
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bcur[t] = bnext[t];
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) cur[g][t] = nxt[g][t];
   }
 }
 
@@ -83,6 +95,27 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// cos(x) for the time encoder (model/time_encoding.py:27).  Arguments reach 2.6e6 (Δt in seconds times
+// ω_0 = 1), where the libm cosf takes its slow Payne-Hanek path; here the range reduction
+// x = n·π/2 + r is done in fp64 (full rate on CDNA4; two-constant π/2, error < 1e-9 for |x| < 1e9) and the
+// kernel polynomials in fp32 (|r| <= π/4).  Absolute error < 2e-7, i.e. ~2 ulp of the O(1) result.
+__device__ __forceinline__ float orca_cosf(float x) {
+  const double xd = (double)x;
+  const double n = __builtin_rint(xd * 0.63661977236758134308);
+  double r = __builtin_fma(-n, 1.57079632679489655800e+00, xd);
+  r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
+  const int q = (int)((long long)n & 3LL);
+  const float rf = (float)r;
+  const float r2 = rf * rf;
+  const float s = __builtin_fmaf(rf * r2, __builtin_fmaf(r2, __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), rf);
+  const float c = __builtin_fmaf(r2 * r2, __builtin_fmaf(r2, __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                                 __builtin_fmaf(r2, -0.5f, 1.0f));
+  const float v = (q & 1) ? s : c;
+  return (q == 1 || q == 2) ? -v : v;
+}
+// t·ω + φ exactly as nn.Linear(1, D) rounds it: one rounded product, then the bias add (no fma contraction)
+__device__ __forceinline__ float orca_time_arg(float t, float w, float b) { return __fadd_rn(__fmul_rn(t, w), b); }
 
 // generic strided pack kernel launcher (pack.hip)
 int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd, const float* src,

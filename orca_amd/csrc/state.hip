@@ -11,7 +11,7 @@ __global__ void k_time_encode(const float* __restrict__ t, int64_t n, const floa
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * D) return;
   int c = (int)(i % D);
-  out[i] = cosf(t[i / D] * w[c] + b[c]);   // model/time_encoding.py:26-27
+  out[i] = orca_cosf(orca_time_arg(t[i / D], w[c], b[c]));   // model/time_encoding.py:26-27
 }
 
 __global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
@@ -23,20 +23,33 @@ __global__ void k_fill_u8(uint8_t* p, int64_t n, uint8_t v) {
   if (i < n) p[i] = v;
 }
 
-__global__ void k_worklist(const int32_t* __restrict__ ids32, int64_t n32, const int64_t* __restrict__ ids64,
-                           int64_t n64, const uint8_t* __restrict__ flags, int32_t* stamp, int32_t epoch,
-                           int64_t n_nodes, int32_t* worklist, int32_t* count) {
+// Distinct-id work-list in two passes without same-address atomics (hub ids repeat thousands of times
+// in a power-law batch, and atomics on one address serialise at L2):
+//   claim : every position p stores slot[id] = epoch + p with a plain store -- some one value survives;
+//   append: the position whose value survived is the id's unique representative; representatives are
+//           appended with one atomicAdd per wavefront.
+__device__ __forceinline__ int64_t worklist_id(const int32_t* ids32, int64_t n32, const int64_t* ids64, int64_t i) {
+  return i < n32 ? (int64_t)ids32[i] : ids64[i - n32];
+}
+__global__ void k_worklist_claim(const int32_t* __restrict__ ids32, int64_t n32, const int64_t* __restrict__ ids64,
+                                 int64_t n64, const uint8_t* __restrict__ flags, int64_t* slot, int64_t epoch,
+                                 int64_t n_nodes) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n32 + n64) return;
+  int64_t id = worklist_id(ids32, n32, ids64, i);
+  if (id < 0 || id >= n_nodes || (flags && !flags[id])) return;
+  slot[id] = epoch + i;
+}
+__global__ void k_worklist_append(const int32_t* __restrict__ ids32, int64_t n32, const int64_t* __restrict__ ids64,
+                                  int64_t n64, const uint8_t* __restrict__ flags, const int64_t* __restrict__ slot,
+                                  int64_t epoch, int64_t n_nodes, int32_t* worklist, int32_t* count) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool take = false;
   int64_t id = -1;
   if (i < n32 + n64) {
-    id = i < n32 ? (int64_t)ids32[i] : ids64[i - n32];
-    take = id >= 0 && id < n_nodes && (!flags || flags[id]);
-    // cheap pre-check keeps hub ids (thousands of duplicates) from hammering one address
-    if (take && __builtin_nontemporal_load(&stamp[id]) == epoch) take = false;
-    if (take) take = atomicExch(&stamp[id], epoch) != epoch;   // first claimant of this id wins
+    id = worklist_id(ids32, n32, ids64, i);
+    take = id >= 0 && id < n_nodes && (!flags || flags[id]) && slot[id] == epoch + i;
   }
-  // one atomicAdd per wavefront instead of one per id
   const unsigned long long m = __ballot(take);
   if (m == 0ull) return;
   const int lane = threadIdx.x & 63;
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(256) void k_message_store(const int64_t* __restrict
   for (int c = lane; c < D; c += 64) {
     row[c] = ms[c];
     row[D + c] = md[c];
-    row[2 * D + d_e + c] = cosf(delta * tw[c] + tb[c]);           // :188
+    row[2 * D + d_e + c] = orca_cosf(orca_time_arg(delta, tw[c], tb[c]));   // :188
   }
   for (int c = lane; c < d_e; c += 64) row[2 * D + c] = ef[c];
   if (lane == 0) {
@@ -192,13 +205,16 @@ ORCA_API int orca_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream) {
 }
 
 ORCA_API int orca_worklist_build(const int32_t* ids32, int64_t n32, const int64_t* ids64, int64_t n64,
-                                 const uint8_t* flags, int32_t* stamp, int32_t epoch, int64_t n_nodes,
+                                 const uint8_t* flags, int64_t* slot, int64_t epoch, int64_t n_nodes,
                                  int32_t* worklist, int32_t* count, void* stream) {
-  ORCA_REQUIRE(n32 >= 0 && n64 >= 0 && stamp && worklist && count && n_nodes > 0, "orca_worklist_build: bad arguments");
+  ORCA_REQUIRE(n32 >= 0 && n64 >= 0 && slot && worklist && count && n_nodes > 0, "orca_worklist_build: bad arguments");
   ORCA_REQUIRE((n32 == 0 || ids32) && (n64 == 0 || ids64), "orca_worklist_build: null id array");
+  ORCA_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream));
   if (n32 + n64 == 0) return ORCA_OK;
-  k_worklist<<<blocks(n32 + n64, 256), 256, 0, (hipStream_t)stream>>>(ids32, n32, ids64, n64, flags, stamp, epoch,
-                                                                      n_nodes, worklist, count);
+  k_worklist_claim<<<blocks(n32 + n64, 256), 256, 0, (hipStream_t)stream>>>(ids32, n32, ids64, n64, flags, slot, epoch,
+                                                                            n_nodes);
+  k_worklist_append<<<blocks(n32 + n64, 256), 256, 0, (hipStream_t)stream>>>(ids32, n32, ids64, n64, flags, slot, epoch,
+                                                                             n_nodes, worklist, count);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

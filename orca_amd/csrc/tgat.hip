@@ -19,14 +19,14 @@ namespace {
 constexpr int D = ORCA_D;          // 100
 constexpr int QD = 2 * D;          // query / embed dim 200
 constexpr int TQ = 16;             // queries per workgroup (one MFMA M tile)
-constexpr int NW = 8;              // waves per workgroup
+constexpr int NW = 16;             // waves per workgroup: one per query in the per-query stage
 constexpr int ASTR = 212;          // LDS row stride of the 200-wide activation buffers (== 4 mod 16)
 constexpr int MSTR = 308;          // LDS row stride of the 300-wide merger input
 constexpr int MAXE = (ORCA_MAX_DE + 63) / 64;   // edge-feature registers per lane
 
 struct Blob {   // float offsets inside the packed parameter blob
   int kdim, KP, NTk, KBk;
-  int64_t pw_q, b_q, pw_kt, pw_v, b_v, pw_o, b_o, pw_1, b_1, pw_2, b_2, ln_w, ln_b, total;
+  int64_t pw_q, b_q, pw_kt, pw_v, b_v, b_vp, pw_o, b_o, pw_1, b_1, pw_2, b_2, ln_w, ln_b, total;
 };
 
 __host__ __device__ inline Blob blob_layout(int d_e) {
@@ -41,6 +41,7 @@ __host__ __device__ inline Blob blob_layout(int d_e) {
   L.pw_kt = o; o += 2 * pw_floats(L.kdim + 1, D);
   L.pw_v = o;  o += 2 * (int64_t)pw_tiles(D) * L.KBk * 256;
   L.b_v = o;   o += 208;
+  L.b_vp = o;  o += 2 * 112;        // value bias per head, each padded to 112 (n-tile granularity)
   L.pw_o = o;  o += pw_floats(QD, QD);
   L.b_o = o;   o += 208;
   L.pw_1 = o;  o += pw_floats(D, 3 * D);
@@ -125,6 +126,8 @@ ORCA_API int orca_tgat_pack(int d_e, const float* q_w, const float* k_w, const f
     rc |= orca_pack_matrix(pv, KB100, L.KBk, 0, D, kdim, v_w + (int64_t)h * D * kdim, kdim, 1, s);
   }
   rc |= copy_pad(blob + L.b_v, in_b + 2 * QD, QD, 208, s);
+  rc |= copy_pad(blob + L.b_vp, in_b + 2 * QD, D, 112, s);
+  rc |= copy_pad(blob + L.b_vp + 112, in_b + 2 * QD + D, D, 112, s);
   rc |= orca_pack_matrix(blob + L.pw_o, pw_tiles(QD), pw_tiles(QD), 0, QD, QD, o_w, QD, 1, s);
   rc |= copy_pad(blob + L.b_o, o_b, QD, 208, s);
   rc |= orca_pack_matrix(blob + L.pw_1, pw_tiles(D), pw_tiles(3 * D), 0, D, 3 * D, fc1_w, 3 * D, 1, s);
@@ -151,33 +154,209 @@ __device__ __forceinline__ void for_acc(const f32x4& acc, int tile, int lane, F 
   for (int r = 0; r < 4; ++r) f(m0 + r, n, acc[r]);
 }
 
-// C[16 x N] = A * PW (+bias) for the n-tiles owned by this wave, NT tiles at a time.
-template <typename F>
-__device__ __forceinline__ void gemm_phase(const float* A, int a_str, const f32x4* pw, int KB, int NTtot, int wave,
-                                           int lane, F epilogue) {
-  const float* a_row = A + (lane & 15) * a_str + 4 * (lane >> 4);
-  for (int t0 = wave; t0 < NTtot; t0 += NW * 4) {
-    int tile[4];
-    int nt = 0;
+// One wave's share of a projection: up to NT 16x16 output tiles of C = A(16 x 16*KB) * PW, the B operands
+// streamed from L2 G k-blocks ahead (double buffered in registers).  prefetch() only needs the weights, so
+// it is issued BEFORE the barrier that publishes the A operand: the first group's L2 round trip hides
+// behind the barrier wait instead of starting every phase.
+template <int NT, int G>
+struct WaveGemm {
+  const f32x4* bp[NT];
+  f32x4 cur[G][NT];
+  float bias[NT];      // bias of this lane's output column n = tile*16 + (lane & 15), fetched with the weights
+  int tile[NT];
+  int KB, nt;
+
+  __device__ __forceinline__ void prefetch(const f32x4* __restrict__ pw, int KB_, int first_tile, int tile_stride,
+                                           int n_tiles, int lane, const float* __restrict__ bias_vec = nullptr) {
+    KB = KB_;
+    nt = 0;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      tile[t] = t0 + t * NW;
-      if (tile[t] < NTtot) nt = t + 1;
+    for (int t = 0; t < NT; ++t) {
+      tile[t] = first_tile + t * tile_stride;
+      if (first_tile >= 0 && tile[t] < n_tiles) nt = t + 1;
     }
-    f32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wave_gemm16<4>(a_row, pw, KB, tile, nt, acc, lane);
+    for (int t = 0; t < NT; ++t) bp[t] = pw + (int64_t)(t < nt ? tile[t] : 0) * KB * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (t < nt) for_acc(acc[t], tile[t], lane, epilogue);
+    for (int t = 0; t < NT; ++t) bias[t] = (bias_vec && t < nt) ? bias_vec[tile[t] * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (g < KB && t < nt) cur[g][t] = bp[t][g * 64];
+  }
+
+  // a_row: LDS pointer to this lane's A row (row l&15) already offset by 4*(l>>4) floats.
+  template <typename F>
+  __device__ __forceinline__ void run(const float* a_row, int lane, F epilogue) {
+    if (nt == 0) return;
+    f32x4 acc[NT], nxt[G][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb0 = 0; kb0 < KB; kb0 += G) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (kb0 + G + g < KB && t < nt) nxt[g][t] = bp[t][(kb0 + G + g) * 64];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (kb0 + g < KB) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(a_row + (kb0 + g) * 16);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], cur[g][t][s], acc[t], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cur[g][t] = nxt[g][t];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t < nt) {
+        const float b = bias[t];
+        for_acc(acc[t], tile[t], lane, [&](int m, int n, float v) { epilogue(m, n, v + b); });
+      }
+  }
+};
+
+constexpr int KC = 10;   // neighbour rows a wave keeps in registers at a time
+
+// The K key rows [nbr(100) | edge(d_e) | time(100)] of one query, spread over the 64 lanes: lane l holds
+// columns l and l+64 of the nbr and time parts and columns l, l+64, l+128 of the edge part.
+struct KeyRows {
+  float na[KC], nb[KC], e[KC][MAXE];
+};
+struct KeyTimes {
+  float ta[KC], tb[KC];
+};
+
+struct QuerySlots {   // lane j (< K) describes neighbour slot j of this wave's query
+  int nrow, erow, ovl;
+  float dt;
+  bool masked;
+};
+
+// Issues the global loads of slots j0 .. j0+KC-1 (all in flight at once; nothing here waits on them).
+__device__ __forceinline__ void load_key_rows(KeyRows& R, KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S,
+                                              int64_t q, int j0, int K, int d_e, int lane) {
+  const int c1 = lane + 64;
+#pragma unroll
+  for (int j = 0; j < KC; ++j) {
+    if (j0 + j < K) {   // wave-uniform
+      const int nr = __builtin_amdgcn_readlane(S.nrow, j0 + j);
+      const int er = __builtin_amdgcn_readlane(S.erow, j0 + j);
+      const int ov = __builtin_amdgcn_readlane(S.ovl, j0 + j);
+      const float* np = (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D;
+      const float* ep = in.edge_table + (int64_t)er * d_e;
+      R.na[j] = np[lane];
+      R.nb[j] = c1 < D ? np[c1] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXE; ++i) {
+        const int c = lane + 64 * i;
+        R.e[j][i] = c < d_e ? ep[c] : 0.f;
+      }
+      if (!in.dt) {     // dense boundary: time features are given
+        const float* tp = in.nbr_time + (q * K + j0 + j) * D;
+        T.ta[j] = tp[lane];
+        T.tb[j] = c1 < D ? tp[c1] : 0.f;
+      }
+    } else {
+      R.na[j] = R.nb[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXE; ++i) R.e[j][i] = 0.f;
+      if (!in.dt) T.ta[j] = T.tb[j] = 0.f;
+    }
   }
 }
 
+// cos(dt*w + b) for the chunk's slots (model/time_encoding.py:26-27), kept in registers
+__device__ __forceinline__ void encode_key_times(KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S, int j0,
+                                                 int K, int lane) {
+  if (!in.dt) return;
+  const int c1 = lane + 64;
+  const float wa = in.time_w[lane], ba = in.time_b[lane];
+  const float wb = c1 < D ? in.time_w[c1] : 0.f, bb = c1 < D ? in.time_b[c1] : 0.f;
+#pragma unroll
+  for (int j = 0; j < KC; ++j) {
+    if (j0 + j < K) {
+      const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.dt), j0 + j));
+      T.ta[j] = orca_cosf(orca_time_arg(d, wa, ba));
+      T.tb[j] = c1 < D ? orca_cosf(orca_time_arg(d, wb, bb)) : 0.f;
+    } else {
+      T.ta[j] = T.tb[j] = 0.f;
+    }
+  }
+}
+
+// ---- 2 x KC wave-wide sums in 22 shuffles instead of 2*KC*6 -------------------------------------------
+// Recursive halving: at xor-distance d each lane keeps one half of its value list and adds the partner's
+// copy of that half, so the list shrinks 20 -> 10 -> 5 -> 3 -> 2 -> 1 while every value keeps summing over
+// twice as many lanes.  The full sum of (head h, slot j) ends in the two lanes holder(h, j) | {0, 1}.
+__host__ __device__ constexpr int holder_lane(int h, int j) {
+  int b4 = j >= 5, a = j - 5 * b4;
+  int b3 = a >= 3, b = a - 3 * b3;
+  int b2 = b == 2, c = b2 ? 0 : b;
+  return 32 * h + 16 * b4 + 8 * b3 + 4 * b2 + 2 * c;
+}
+// slot held by this lane (ignoring the head bit), or -1 for a padding lane
+__device__ __forceinline__ int held_slot(int lane) {
+  const int b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1, b1 = (lane >> 1) & 1;
+  if ((b2 && b1) || (b3 && b2)) return -1;
+  return 5 * b4 + 3 * b3 + (b2 ? 2 : b1);
+}
+__device__ __forceinline__ float reduce_2xKC(const float (&p0)[KC], const float (&p1)[KC], int lane) {
+  static_assert(KC == 10, "the halving schedule below is written for 10 slots");
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+  float w[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) w[j] = (b5 ? p1[j] : p0[j]) + __shfl_xor(b5 ? p0[j] : p1[j], 32, 64);
+  float x[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) x[j] = (b4 ? w[5 + j] : w[j]) + __shfl_xor(b4 ? w[j] : w[5 + j], 16, 64);
+  float y[3];
+  y[0] = (b3 ? x[3] : x[0]) + __shfl_xor(b3 ? x[0] : x[3], 8, 64);
+  y[1] = (b3 ? x[4] : x[1]) + __shfl_xor(b3 ? x[1] : x[4], 8, 64);
+  y[2] = (b3 ? 0.f : x[2]) + __shfl_xor(b3 ? x[2] : 0.f, 8, 64);
+  float z[2];
+  z[0] = (b2 ? y[2] : y[0]) + __shfl_xor(b2 ? y[0] : y[2], 4, 64);
+  z[1] = (b2 ? 0.f : y[1]) + __shfl_xor(b2 ? y[1] : 0.f, 4, 64);
+  float u = (b1 ? z[1] : z[0]) + __shfl_xor(b1 ? z[0] : z[1], 2, 64);
+  return u + __shfl_xor(u, 1, 64);
+}
+__device__ __forceinline__ float half_max(float v) {   // over the 32-lane half this lane is in
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// KT = compile-time neighbour count (10, the reference's default n_degree: every per-slot predicate and
+// the second-chunk code fold away) or 0 = run-time K <= ORCA_MAX_K.
+template <int KT>
 __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restrict__ blob, int d_e,
-                                                          orca_tgat_inputs in, int64_t Q, int K,
-                                                          float* __restrict__ out, float* __restrict__ out_w) {
+                                                          orca_tgat_inputs in, int64_t Q, int K_rt,
+                                                          float* __restrict__ out, float* __restrict__ out_w,
+                                                          long long* __restrict__ phase_clock) {
   extern __shared__ __align__(16) float lds[];
+  // optional profiling aid (orca_debug_tgat_phase_clock): wave 0 of each workgroup stamps the 100 MHz
+  // real-time counter at every phase boundary
+  int phase_no = 0;
+  auto stamp = [&]() {
+    if (phase_clock && threadIdx.x == 0) phase_clock[(int64_t)blockIdx.x * 16 + phase_no] = wall_clock64();
+    ++phase_no;
+  };
+  stamp();
+  const int K = KT ? KT : K_rt;
   const Blob L = blob_layout(d_e);
   const int kdim = L.kdim;
   const int KPS = L.KP + 4;                       // row stride of the q~ / x-bar buffer
@@ -185,253 +364,290 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   float* bufP = bufQ + TQ * ASTR;                 // [TQ][ASTR]  0.1*q, later relu(fc1)
   float* bufM = bufP + TQ * ASTR;                 // [TQ][MSTR]  [attn_out(200) | src(100)]
   float* bufT = bufM + TQ * MSTR;                 // [TQ][2][KPS] q~ then x-bar
-  float* bufE = bufT + TQ * 2 * KPS;              // [NW][K][D]  time encodings of the wave's current query
   __shared__ int s_invalid[TQ];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = tid >> 6;                      // wave m owns query q0 + m in the per-query stages
   const int64_t q0 = (int64_t)blockIdx.x * TQ;
   const f32x4* blob4 = reinterpret_cast<const f32x4*>(blob);
+  const int c1 = lane + 64;
+  const int a_off = (lane & 15), a_k = 4 * (lane >> 4);
+  const int NT200 = pw_tiles(QD), NT100 = pw_tiles(D);
 
-  // ---- P0: stage the query vectors [src | src_time] and the merger's copy of src --------------
-  for (int idx = tid; idx < TQ * ASTR; idx += NW * 64) {
-    int m = idx / ASTR, c = idx - m * ASTR;
-    int64_t q = q0 + m;
-    float v = 0.0f;
-    if (q < Q && c < QD) {
-      if (c < D) {
-        int64_t row = in.src_idx ? (int64_t)in.src_idx[q] : q;
-        const float* tab = (in.src_flags && in.src_flags[row]) ? in.src_overlay : in.src_table;
-        v = tab[row * D + c];
-        bufM[m * MSTR + QD + c] = v;
-      } else {
-        int cc = c - D;
-        v = in.dt ? cosf(0.0f * in.time_w[cc] + in.time_b[cc]) : in.src_time[q * D + cc];
-      }
-    } else if (c < D) {
-      bufM[m * MSTR + QD + c] = 0.0f;
+  // LayerNorm affine parameters (P8) and the q-projection weights depend on nothing: fetch them right away
+  const float ln_ga = blob[L.ln_w + lane], ln_ba = blob[L.ln_b + lane];
+  const float ln_gb = blob[c1 < D ? L.ln_w + c1 : L.ln_w], ln_bb = blob[c1 < D ? L.ln_b + c1 : L.ln_b];
+  WaveGemm<1, 6> g1;
+  g1.prefetch(blob4 + L.pw_q / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_q);
+
+  // ---- T0: this wave's query: neighbour slots, source row, L2 touches, time encodings ------------
+  const int64_t q = q0 + wave;
+  const bool live_q = q < Q;
+  QuerySlots S{0, 0, 0, 0.f, true};
+  if (live_q && lane < K) {
+    const int64_t p = q * K + lane;
+    S.nrow = in.nbr_idx ? in.nbr_idx[p] : (int)p;
+    S.erow = in.edge_idx ? in.edge_idx[p] : (int)p;
+    S.masked = in.nbr_ids ? (in.nbr_ids[p] == 0) : (in.mask[p] != 0);
+    if (in.dt) S.dt = in.dt[p];
+    if (in.nbr_flags) S.ovl = in.nbr_flags[S.nrow] ? 1 : 0;
+  }
+  // source row [src(100) | src_time(100)] of query m = wave and the merger's copy of src
+  float sa = 0.f, sb = 0.f, sta = 0.f, stb = 0.f;
+  if (live_q) {
+    const int64_t row = in.src_idx ? (int64_t)in.src_idx[q] : q;
+    const float* tab = (in.src_flags && in.src_flags[row]) ? in.src_overlay : in.src_table;
+    sa = tab[row * D + lane];
+    sb = c1 < D ? tab[row * D + c1] : 0.f;
+    if (in.dt) {    // embedding_module.py:126: the source's own time encoding is cos(0*w + b)
+      sta = orca_cosf(orca_time_arg(0.0f, in.time_w[lane], in.time_b[lane]));
+      stb = c1 < D ? orca_cosf(orca_time_arg(0.0f, in.time_w[c1], in.time_b[c1])) : 0.f;
+    } else {
+      sta = in.src_time[q * D + lane];
+      stb = c1 < D ? in.src_time[q * D + c1] : 0.f;
     }
-    bufQ[idx] = v;
-    bufP[idx] = 0.0f;
   }
-  for (int idx = tid; idx < TQ * (MSTR - 3 * D); idx += NW * 64) {   // zero the merger row padding
-    int m = idx / (MSTR - 3 * D), c = idx - m * (MSTR - 3 * D);
-    bufM[m * MSTR + 3 * D + c] = 0.0f;
+  // touch every 128-B line of the K neighbour and edge rows now (one dword per line, two VGPRs held):
+  // the lines travel HBM -> L2 while the projection phases run, and the row loads of P3 then hit L2
+  float touch0 = 0.f, touch1 = 0.f;
+  if (live_q) {
+    const int nl = (D * 4 + 127) / 128, el = (d_e * 4 + 127) / 128;   // lines per nbr / edge row
+    const int per = nl + el, total = K * per;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int idx = lane + 64 * r;
+      if (idx < total) {
+        const int j = idx / per, ln = idx - j * per;
+        const int nr = __shfl(S.nrow, j, 64), er = __shfl(S.erow, j, 64), ov = __shfl(S.ovl, j, 64);
+        const float* p = ln < nl ? (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D + ln * 32
+                                 : in.edge_table + (int64_t)er * d_e + (ln - nl) * 32;
+        const float v = *p;
+        if (r == 0) touch0 = v; else touch1 = v;
+      }
+    }
   }
-  __syncthreads();
-
-  // ---- P1: q = Wq [src|time] + bq, scaled by sqrt(1/head_dim) ----------------------------------
+  // the time encodings of slots 0..KC-1 need only dt: all VALU, computed while the loads above are in flight
+  KeyTimes T;
+  if (live_q) encode_key_times(T, in, S, 0, K, lane);
   {
-    const float* bq = blob + L.b_q;
-    gemm_phase(bufQ, ASTR, blob4 + L.pw_q / 4, pw_tiles(QD), pw_tiles(QD), wave, lane,
-               [&](int m, int n, float v) {
-                 if (n < ASTR) bufP[m * ASTR + n] = (n < QD) ? (v + bq[n]) * 0.1f : 0.0f;
-               });
+    const int m = wave;
+    bufQ[m * ASTR + lane] = sa;
+    bufQ[m * ASTR + D + lane] = sta;
+    bufM[m * MSTR + QD + lane] = sa;
+    if (c1 < D) {
+      bufQ[m * ASTR + c1] = sb;
+      bufQ[m * ASTR + D + c1] = stb;
+      bufM[m * MSTR + QD + c1] = sb;
+    }
+    if (lane < ASTR - QD) bufQ[m * ASTR + QD + lane] = 0.f;
+    if (lane < MSTR - 3 * D) bufM[m * MSTR + 3 * D + lane] = 0.f;
+    for (int c = lane; c < ASTR; c += 64) bufP[m * ASTR + c] = 0.f;
   }
   __syncthreads();
+  stamp();
 
-  // ---- P2: q~_h = Wk_h^T (0.1 q_h)  (column kdim carries (0.1 q_h).bk_h) -----------------------
-  for (int h = 0; h < 2; ++h) {
-    const f32x4* pw = blob4 + (L.pw_kt + (int64_t)h * pw_floats(kdim + 1, D)) / 4;
-    float* dstT = bufT + h * KPS;
-    gemm_phase(bufP + h * D, ASTR, pw, pw_tiles(D), L.NTk, wave, lane,
-               [&](int m, int n, float v) { dstT[m * 2 * KPS + n] = v; });
+  // ---- P1: q = Wq [src|time] + bq, scaled by sqrt(1/head_dim) -> bufP ---------------------------
+  {
+    g1.run(bufQ + a_off * ASTR + a_k, lane, [&](int m, int n, float v) {
+      if (n < ASTR) bufP[m * ASTR + n] = (n < QD) ? v * 0.1f : 0.0f;
+    });
+  }
+  // ---- P2: q~_h = Wk_h^T (0.1 q_h)  (column kdim carries (0.1 q_h).bk_h): wave (h = w&1, slot = w>>1)
+  //      owns tiles slot, slot+8, slot+16 of head h -> bufT
+  const int h2 = wave & 1;
+  WaveGemm<3, 2> g2;
+  g2.prefetch(blob4 + (L.pw_kt + (int64_t)h2 * pw_floats(kdim + 1, D)) / 4, NT100, wave >> 1, NW / 2, L.NTk, lane);
+  __syncthreads();
+  stamp();
+  {
+    float* dstT = bufT + h2 * KPS;
+    g2.run(bufP + h2 * D + a_off * ASTR + a_k, lane, [&](int m, int n, float v) { dstT[m * 2 * KPS + n] = v; });
   }
   __syncthreads();
+  stamp();
 
-  // ---- P3: per query (one wave each): scores, masked softmax, weighted key sum ------------------
-  for (int m = wave; m < TQ; m += NW) {
-    const int64_t q = q0 + m;
-    if (q >= Q) {
-      if (lane == 0) s_invalid[m] = 1;
-      for (int c = lane; c < 2 * KPS; c += 64) bufT[m * 2 * KPS + c] = 0.0f;
-      continue;
-    }
-    float* te = bufE + wave * K * D;
-    // lane j (< K) owns neighbour slot j
-    int64_t nrow = 0, erow = 0;
-    float dtj = 0.0f;
-    bool masked = true;
-    if (lane < K) {
-      int64_t p = q * K + lane;
-      nrow = in.nbr_idx ? (int64_t)in.nbr_idx[p] : p;
-      erow = in.edge_idx ? (int64_t)in.edge_idx[p] : p;
-      masked = in.nbr_ids ? (in.nbr_ids[p] == 0) : (in.mask[p] != 0);
-      if (in.dt) dtj = in.dt[p];
-    }
-    const bool invalid = (__ballot(lane < K && !masked) == 0ull);   // temporal_attention.py:46
-    if (invalid && lane == 0) {
-      masked = false;                                               // :47
-      if (!in.nbr_ids) in.mask[q * K] = 0;
-    }
-    if (lane == 0) s_invalid[m] = invalid ? 1 : 0;
-    const float* ntab = in.nbr_table;
-    if (lane < K && in.nbr_flags && in.nbr_flags[nrow]) ntab = in.nbr_overlay;
-    const float* nptr = ntab + nrow * D;
-    const float* eptr = in.edge_table + erow * d_e;
-    // time encodings of the K slots -> LDS (computed once, used by both passes)
-    for (int base = 0; base < K * D; base += 64) {   // uniform trip count: every lane takes part in the shuffle
-      int idx = base + lane;
-      int j = idx / D;
-      if (j > K - 1) j = K - 1;
-      int c = idx - j * D;
-      float d = __shfl(dtj, j, 64);
-      if (idx < K * D) te[idx] = in.dt ? cosf(d * in.time_w[c] + in.time_b[c]) : in.nbr_time[(q * K + j) * D + c];
-    }
-    __builtin_amdgcn_wave_barrier();
-    const float* qt0 = bufT + m * 2 * KPS;
-    const float* qt1 = qt0 + KPS;
-    // this lane's columns of q~ (both heads): nbr part c, c+64; edge part; time part c, c+64
-    const int c1 = lane + 64;
-    float qn0a = qt0[lane], qn1a = qt1[lane];
-    float qn0b = c1 < D ? qt0[c1] : 0.f, qn1b = c1 < D ? qt1[c1] : 0.f;
-    float qe0[MAXE], qe1[MAXE];
-#pragma unroll
-    for (int i = 0; i < MAXE; ++i) {
-      int c = lane + 64 * i;
-      qe0[i] = c < d_e ? qt0[D + c] : 0.f;
-      qe1[i] = c < d_e ? qt1[D + c] : 0.f;
-    }
-    const int tb = D + d_e;
-    float qt0a = qt0[tb + lane], qt1a = qt1[tb + lane];
-    float qt0b = c1 < D ? qt0[tb + c1] : 0.f, qt1b = c1 < D ? qt1[tb + c1] : 0.f;
-    const float off0 = qt0[kdim], off1 = qt1[kdim];
-    // pass 1: scores
-    float s0 = 0.f, s1 = 0.f;
-    for (int j = 0; j < K; ++j) {
-      const float* np = (const float*)__shfl((unsigned long long)nptr, j, 64);
-      const float* ep = (const float*)__shfl((unsigned long long)eptr, j, 64);
-      float xa = np[lane];
-      float xb = c1 < D ? np[c1] : 0.f;
-      float p0 = xa * qn0a + xb * qn0b;
-      float p1 = xa * qn1a + xb * qn1b;
-#pragma unroll
-      for (int i = 0; i < MAXE; ++i) {
-        int c = lane + 64 * i;
-        float xe = c < d_e ? ep[c] : 0.f;
-        p0 += xe * qe0[i];
-        p1 += xe * qe1[i];
-      }
-      float ta = te[j * D + lane];
-      float tbv = c1 < D ? te[j * D + c1] : 0.f;
-      p0 += ta * qt0a + tbv * qt0b;
-      p1 += ta * qt1a + tbv * qt1b;
-      p0 = wave_sum(p0);
-      p1 = wave_sum(p1);
-      if (lane == j) { s0 = p0 + off0; s1 = p1 + off1; }
-    }
-    // masked softmax over the K slots (lanes 0..K-1)
-    const bool live = lane < K && !masked;
-    float m0 = wave_max(live ? s0 : -INFINITY), m1 = wave_max(live ? s1 : -INFINITY);
-    float e0 = live ? expf(s0 - m0) : 0.f, e1 = live ? expf(s1 - m1) : 0.f;
-    float a0 = e0 / wave_sum(e0), a1 = e1 / wave_sum(e1);
-    if (out_w && lane < K) out_w[q * K + lane] = invalid ? 0.f : (a0 + a1) * 0.5f;   // :51-53
-    // pass 2: x-bar_h = sum_j a_hj x_j   (rows re-read; they are L1/L2 resident)
-    float an0 = 0.f, an1 = 0.f, bn0 = 0.f, bn1 = 0.f, at0 = 0.f, at1 = 0.f, bt0 = 0.f, bt1 = 0.f;
-    float ae0[MAXE], ae1[MAXE];
-#pragma unroll
-    for (int i = 0; i < MAXE; ++i) { ae0[i] = 0.f; ae1[i] = 0.f; }
-    for (int j = 0; j < K; ++j) {
-      const float w0 = __shfl(a0, j, 64), w1 = __shfl(a1, j, 64);
-      const float* np = (const float*)__shfl((unsigned long long)nptr, j, 64);
-      const float* ep = (const float*)__shfl((unsigned long long)eptr, j, 64);
-      float xa = np[lane];
-      float xb = c1 < D ? np[c1] : 0.f;
-      an0 += w0 * xa; an1 += w1 * xa; bn0 += w0 * xb; bn1 += w1 * xb;
-#pragma unroll
-      for (int i = 0; i < MAXE; ++i) {
-        int c = lane + 64 * i;
-        float xe = c < d_e ? ep[c] : 0.f;
-        ae0[i] += w0 * xe;
-        ae1[i] += w1 * xe;
-      }
-      float ta = te[j * D + lane];
-      float tbv = c1 < D ? te[j * D + c1] : 0.f;
-      at0 += w0 * ta; at1 += w1 * ta; bt0 += w0 * tbv; bt1 += w1 * tbv;
-    }
+  // ---- P3: this wave's query: scores, masked softmax, weighted key sum ---------------------------
+  asm volatile("" ::"v"(touch0), "v"(touch1));   // the touches are complete (and kept) up to here
+  {
+    const int m = wave;
     float* xb0 = bufT + m * 2 * KPS;
     float* xb1 = xb0 + KPS;
-    xb0[lane] = an0; xb1[lane] = an1;
-    if (c1 < D) { xb0[c1] = bn0; xb1[c1] = bn1; }
+    if (!live_q) {
+      if (lane == 0) s_invalid[m] = 1;
+      for (int c = lane; c < 2 * KPS; c += 64) xb0[c] = 0.0f;
+    } else {
+      KeyRows R;
+      load_key_rows(R, T, in, S, q, 0, K, d_e, lane);
+      unsigned long long livebits = __ballot(lane < K && !S.masked);
+      const bool invalid = livebits == 0ull;                           // temporal_attention.py:46
+      if (invalid) {
+        livebits = 1ull;                                                 // :47 un-masks slot 0
+        if (!in.nbr_ids && lane == 0) in.mask[q * K] = 0;
+      }
+      if (lane == 0) s_invalid[m] = invalid ? 1 : 0;
+      // this lane's columns of q~ (both heads): nbr part c, c+64; edge part; time part c, c+64
+      const int tb = D + d_e;
+      const float qn0a = xb0[lane], qn1a = xb1[lane];
+      const float qn0b = c1 < D ? xb0[c1] : 0.f, qn1b = c1 < D ? xb1[c1] : 0.f;
+      float qe0[MAXE], qe1[MAXE];
 #pragma unroll
-    for (int i = 0; i < MAXE; ++i) {
-      int c = lane + 64 * i;
-      if (c < d_e) { xb0[D + c] = ae0[i]; xb1[D + c] = ae1[i]; }
+      for (int i = 0; i < MAXE; ++i) {
+        const int c = lane + 64 * i;
+        qe0[i] = c < d_e ? xb0[D + c] : 0.f;
+        qe1[i] = c < d_e ? xb1[D + c] : 0.f;
+      }
+      const float qt0a = xb0[tb + lane], qt1a = xb1[tb + lane];
+      const float qt0b = c1 < D ? xb0[tb + c1] : 0.f, qt1b = c1 < D ? xb1[tb + c1] : 0.f;
+      const float off = (lane & 32) ? xb1[kdim] : xb0[kdim];
+      // per-lane partial dot products of the chunk's rows with q~, reduced 20 at a time; afterwards the
+      // lanes holder_lane(h, j) | {0,1} hold score(h, j0 + j)
+      auto scores = [&]() {
+        float p0[KC], p1[KC];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+          p0[j] = R.na[j] * qn0a + R.nb[j] * qn0b + T.ta[j] * qt0a + T.tb[j] * qt0b;
+          p1[j] = R.na[j] * qn1a + R.nb[j] * qn1b + T.ta[j] * qt1a + T.tb[j] * qt1b;
+#pragma unroll
+          for (int i = 0; i < MAXE; ++i) {
+            p0[j] += R.e[j][i] * qe0[i];
+            p1[j] += R.e[j][i] * qe1[i];
+          }
+        }
+        return reduce_2xKC(p0, p1, lane) + off;
+      };
+      const int hs = held_slot(lane);
+      float sc[2];
+      sc[0] = scores();
+      if (K > KC) {
+        load_key_rows(R, T, in, S, q, KC, K, d_e, lane);
+        encode_key_times(T, in, S, KC, K, lane);
+        sc[1] = scores();
+      } else {
+        sc[1] = 0.f;
+      }
+      // masked softmax per head = per 32-lane half; every real slot sits in two lanes of its half
+      const bool lv0 = hs >= 0 && ((livebits >> hs) & 1ull);
+      const bool lv1 = K > KC && hs >= 0 && ((livebits >> (hs + KC)) & 1ull);
+      const float mx = half_max(fmaxf(lv0 ? sc[0] : -INFINITY, lv1 ? sc[1] : -INFINITY));
+      const float e0 = lv0 ? expf(sc[0] - mx) : 0.f, e1 = lv1 ? expf(sc[1] - mx) : 0.f;
+      const float inv = 1.0f / (half_sum(e0 + e1) * 0.5f);
+      const float a_c0 = e0 * inv, a_c1 = e1 * inv;      // attention weight of (head = lane>>5, slot hs [+KC])
+      if (out_w) {                                                       // :51-53 (head average); wave-uniform
+        const int jj = lane < K ? (lane < KC ? lane : lane - KC) : 0;
+        int hl = 0;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) hl = (jj == j) ? holder_lane(0, j) : hl;
+        // every lane takes part in the shuffles (a pulled-from lane must be active)
+        float w0 = __shfl(a_c0, hl, 64), w1 = __shfl(a_c0, hl + 32, 64);
+        if (K > KC) {
+          const float v0 = __shfl(a_c1, hl, 64), v1 = __shfl(a_c1, hl + 32, 64);
+          if (lane >= KC) { w0 = v0; w1 = v1; }
+        }
+        if (lane < K) out_w[q * K + lane] = invalid ? 0.f : (w0 + w1) * 0.5f;
+      }
+      // x-bar_h = sum_j a_hj x_j
+      float an0 = 0.f, an1 = 0.f, bn0 = 0.f, bn1 = 0.f, at0 = 0.f, at1 = 0.f, bt0 = 0.f, bt1 = 0.f;
+      float ae0[MAXE], ae1[MAXE];
+#pragma unroll
+      for (int i = 0; i < MAXE; ++i) { ae0[i] = 0.f; ae1[i] = 0.f; }
+      auto accumulate = [&](float a_c) {
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+          const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_c), holder_lane(0, j)));
+          const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_c), holder_lane(1, j)));
+          an0 += w0 * R.na[j]; an1 += w1 * R.na[j]; bn0 += w0 * R.nb[j]; bn1 += w1 * R.nb[j];
+          at0 += w0 * T.ta[j]; at1 += w1 * T.ta[j]; bt0 += w0 * T.tb[j]; bt1 += w1 * T.tb[j];
+#pragma unroll
+          for (int i = 0; i < MAXE; ++i) { ae0[i] += w0 * R.e[j][i]; ae1[i] += w1 * R.e[j][i]; }
+        }
+      };
+      if (K > KC) {          // the registers hold slots KC..K-1: use them, then fetch slots 0..KC-1 again (L2 hits)
+        accumulate(a_c1);
+        load_key_rows(R, T, in, S, q, 0, K, d_e, lane);
+        encode_key_times(T, in, S, 0, K, lane);
+      }
+      accumulate(a_c0);
+      xb0[lane] = an0; xb1[lane] = an1;
+      if (c1 < D) { xb0[c1] = bn0; xb1[c1] = bn1; }
+#pragma unroll
+      for (int i = 0; i < MAXE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d_e) { xb0[D + c] = ae0[i]; xb1[D + c] = ae1[i]; }
+      }
+      xb0[tb + lane] = at0; xb1[tb + lane] = at1;
+      if (c1 < D) { xb0[tb + c1] = bt0; xb1[tb + c1] = bt1; }
+      if (lane == 0) { xb0[kdim] = 0.f; xb1[kdim] = 0.f; }
     }
-    xb0[tb + lane] = at0; xb1[tb + lane] = at1;
-    if (c1 < D) { xb0[tb + c1] = bt0; xb1[tb + c1] = bt1; }
-    if (lane == 0) { xb0[kdim] = 0.f; xb1[kdim] = 0.f; }
   }
+  // ---- P4: o_h = Wv_h x-bar_h + bv_h  ->  bufQ[:, h*100 + d]: wave -> (head, tile) of 2 x 7 ----------
+  const int h4 = wave / NT100, t4 = wave - h4 * NT100;
+  WaveGemm<1, 6> g4;
+  g4.prefetch(blob4 + (L.pw_v + (int64_t)(h4 & 1) * NT100 * L.KBk * 256) / 4, L.KBk, wave < 2 * NT100 ? t4 : -1, 1, NT100, lane,
+              blob + L.b_vp + (h4 & 1) * 112);
   __syncthreads();
-
-  // ---- P4: o_h = Wv_h x-bar_h + bv_h  ->  bufQ[:, h*100 + d] -------------------------------------
+  stamp();
   {
-    const float* bv = blob + L.b_v;
-    const int NT100 = pw_tiles(D);
-    const float* a_base = bufT + (lane & 15) * 2 * KPS + 4 * (lane >> 4);
-    for (int item = wave; item < 2 * NT100; item += NW) {
-      int h = item / NT100, t = item - h * NT100;
-      const f32x4* pw = blob4 + (L.pw_v + (int64_t)h * NT100 * L.KBk * 256) / 4;
-      int tile[1] = {t};
-      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-      wave_gemm16<1>(a_base + h * KPS, pw, L.KBk, tile, 1, acc, lane);
-      for_acc(acc[0], t, lane, [&](int m, int n, float v) {
-        if (n < D) bufQ[m * ASTR + h * D + n] = v + bv[h * D + n];
-      });
-    }
+    g4.run(bufT + a_off * 2 * KPS + a_k + h4 * KPS, lane, [&](int m, int n, float v) {
+      if (n < D) bufQ[m * ASTR + h4 * D + n] = v;
+    });
   }
-  __syncthreads();
-
   // ---- P5: attn = Wo o + bo, zeroed for all-padded neighbourhoods (:52) -> bufM[:, 0:200] -------
-  {
-    const float* bo = blob + L.b_o;
-    gemm_phase(bufQ, ASTR, blob4 + L.pw_o / 4, pw_tiles(QD), pw_tiles(QD), wave, lane,
-               [&](int m, int n, float v) {
-                 if (n < QD) bufM[m * MSTR + n] = s_invalid[m] ? 0.0f : (v + bo[n]);
-               });
-  }
+  WaveGemm<1, 6> g5;
+  g5.prefetch(blob4 + L.pw_o / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_o);
   __syncthreads();
-
+  stamp();
+  {
+    g5.run(bufQ + a_off * ASTR + a_k, lane, [&](int m, int n, float v) {
+      if (n < QD) bufM[m * MSTR + n] = s_invalid[m] ? 0.0f : v;
+    });
+  }
   // ---- P6: h1 = relu(fc1 [attn | src] + b1) -> bufP[:, 0:112] -----------------------------------
-  {
-    const float* b1 = blob + L.b_1;
-    gemm_phase(bufM, MSTR, blob4 + L.pw_1 / 4, pw_tiles(3 * D), pw_tiles(D), wave, lane,
-               [&](int m, int n, float v) { bufP[m * ASTR + n] = (n < D) ? fmaxf(v + b1[n], 0.0f) : 0.0f; });
-  }
+  WaveGemm<1, 6> g6;
+  g6.prefetch(blob4 + L.pw_1 / 4, pw_tiles(3 * D), wave < NT100 ? wave : -1, NW, NT100, lane, blob + L.b_1);
   __syncthreads();
-
+  stamp();
+  {
+    g6.run(bufM + a_off * MSTR + a_k, lane,
+           [&](int m, int n, float v) { bufP[m * ASTR + n] = (n < D) ? fmaxf(v, 0.0f) : 0.0f; });
+  }
   // ---- P7: y = fc2 h1 + b2 -> bufQ[:, 0:100] -----------------------------------------------------
+  WaveGemm<1, 7> g7;
+  g7.prefetch(blob4 + L.pw_2 / 4, NT100, wave < NT100 ? wave : -1, NW, NT100, lane, blob + L.b_2);
+  __syncthreads();
+  stamp();
   {
-    const float* b2 = blob + L.b_2;
-    gemm_phase(bufP, ASTR, blob4 + L.pw_2 / 4, pw_tiles(D), pw_tiles(D), wave, lane,
-               [&](int m, int n, float v) {
-                 if (n < D) bufQ[m * ASTR + n] = v + b2[n];
-               });
+    g7.run(bufP + a_off * ASTR + a_k, lane, [&](int m, int n, float v) {
+      if (n < D) bufQ[m * ASTR + n] = v;
+    });
   }
   __syncthreads();
+  stamp();
 
-  // ---- P8: LayerNorm(100), eps 1e-5, biased variance (:55) ---------------------------------------
-  {
-    const float* g = blob + L.ln_w;
-    const float* b = blob + L.ln_b;
-    for (int m = wave; m < TQ; m += NW) {
-      const int64_t q = q0 + m;
-      if (q >= Q) continue;
-      const int c1 = lane + 64;
-      float ya = bufQ[m * ASTR + lane];
-      float yb = c1 < D ? bufQ[m * ASTR + c1] : 0.f;
-      float mean = wave_sum(ya + yb) * (1.0f / D);
-      float da = ya - mean, db = c1 < D ? yb - mean : 0.f;
-      float var = wave_sum(da * da + db * db) * (1.0f / D);
-      float rstd = 1.0f / sqrtf(var + 1e-5f);
-      out[q * D + lane] = da * rstd * g[lane] + b[lane];
-      if (c1 < D) out[q * D + c1] = db * rstd * g[c1] + b[c1];
-    }
+  // ---- P8: LayerNorm(100), eps 1e-5, biased variance (:55): wave m normalises query m ------------
+  if (live_q) {
+    const int m = wave;
+    float ya = bufQ[m * ASTR + lane];
+    float yb = c1 < D ? bufQ[m * ASTR + c1] : 0.f;
+    float mean = wave_sum(ya + yb) * (1.0f / D);
+    float da = ya - mean, db = c1 < D ? yb - mean : 0.f;
+    float var = wave_sum(da * da + db * db) * (1.0f / D);
+    float rstd = 1.0f / sqrtf(var + 1e-5f);
+    out[q * D + lane] = da * rstd * ln_ga + ln_ba;
+    if (c1 < D) out[q * D + c1] = db * rstd * ln_gb + ln_bb;
   }
+  stamp();
 }
 
 }  // namespace
+
+static long long* g_phase_clock = nullptr;
+// Profiling aid, not part of the product surface: buf = device int64 [n_workgroups * 16] (or NULL to stop);
+// later orca_tgat_forward launches stamp their phase boundaries into it.
+ORCA_API int orca_debug_tgat_phase_clock(void* buf) {
+  g_phase_clock = (long long*)buf;
+  return ORCA_OK;
+}
 
 ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
                                float* out_weights, void* stream) {
@@ -446,16 +662,22 @@ ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_input
                "orca_tgat_forward: need (dt, time_w, time_b) or (src_time, nbr_time)");
   ORCA_REQUIRE(!in->src_flags || in->src_overlay, "orca_tgat_forward: src_flags without src_overlay");
   ORCA_REQUIRE(!in->nbr_flags || in->nbr_overlay, "orca_tgat_forward: nbr_flags without nbr_overlay");
+  ORCA_REQUIRE(in->nbr_idx || Q * K < (1LL << 31), "orca_tgat_forward: dense mode limited to Q*K < 2^31");
   Blob L = blob_layout(d_e);
-  size_t lds_bytes = (size_t)(2 * TQ * ASTR + TQ * MSTR + TQ * 2 * (L.KP + 4) + NW * K * D) * sizeof(float);
+  size_t lds_bytes = (size_t)(2 * TQ * ASTR + TQ * MSTR + TQ * 2 * (L.KP + 4)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     attr_set = true;
   }
   ORCA_REQUIRE(lds_bytes <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds_bytes);
-  k_tgat_forward<<<(unsigned)ceil_div64(Q, TQ), NW * 64, lds_bytes, (hipStream_t)stream>>>(blob, d_e, *in, Q, K, out,
-                                                                                           out_weights);
+  if (K == 10)
+    k_tgat_forward<10><<<(unsigned)ceil_div64(Q, TQ), NW * 64, lds_bytes, (hipStream_t)stream>>>(blob, d_e, *in, Q, K, out,
+                                                                                                 out_weights, g_phase_clock);
+  else
+    k_tgat_forward<0><<<(unsigned)ceil_div64(Q, TQ), NW * 64, lds_bytes, (hipStream_t)stream>>>(blob, d_e, *in, Q, K, out,
+                                                                                                out_weights, g_phase_clock);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

@@ -63,8 +63,6 @@ class OrcaEngine:
     # scratch
     self.slot = torch.zeros(self.N, dtype=torch.int64, device=dev)
     self.slot_epoch = 1
-    self.stamp = torch.zeros(self.N, dtype=torch.int32, device=dev)
-    self.stamp_epoch = 0
     self.worklist = torch.zeros(self.N, dtype=torch.int32, device=dev)
     self.count = torch.zeros(1, dtype=torch.int32, device=dev)
     self.all_ids = None
@@ -136,17 +134,9 @@ class OrcaEngine:
     self.slot_epoch += int(n) + 1
     return e
 
-  def _stamp_epoch(self):
-    self.stamp_epoch += 1
-    if self.stamp_epoch >= 2 ** 31 - 1:
-      self.stamp.zero_()
-      self.stamp_epoch = 1
-    return self.stamp_epoch
-
   def _build_worklist(self, ids32, ids64, bound):
     """distinct ids of (ids32 ∪ ids64) that hold a pending message -> self.worklist[:count]."""
-    ops.fill_i32(self.count, 0)
-    ops.worklist_build(ids32, ids64, self.pending, self.stamp, self._stamp_epoch(), self.worklist, self.count)
+    ops.worklist_build(ids32, ids64, self.pending, self.slot, self._slot_epoch(bound), self.worklist, self.count)
     return min(int(bound), self.N)
 
   def _overlay_updated_memory(self, ids32, ids64):

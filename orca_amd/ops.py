@@ -223,11 +223,12 @@ def fill_u8(t, v):
   check(_lib.load().orca_fill_u8(ptr(t), t.numel(), int(v), stream()), "orca_fill_u8")
 
 
-def worklist_build(ids32, ids64, flags, stamp, epoch, worklist, count):
+def worklist_build(ids32, ids64, flags, slot, epoch, worklist, count):
+  """distinct ids of ids32 ∪ ids64 with flags[id] != 0 -> worklist[:count]; uses n32+n64 epochs of `slot`"""
   n32 = ids32.numel() if ids32 is not None else 0
   n64 = ids64.numel() if ids64 is not None else 0
-  check(_lib.load().orca_worklist_build(ptr(ids32), n32, ptr(ids64), n64, ptr(flags), ptr(stamp), int(epoch),
-                                        stamp.numel(), ptr(worklist), ptr(count), stream()), "orca_worklist_build")
+  check(_lib.load().orca_worklist_build(ptr(ids32), n32, ptr(ids64), n64, ptr(flags), ptr(slot), int(epoch),
+                                        slot.numel(), ptr(worklist), ptr(count), stream()), "orca_worklist_build")
 
 
 def set_flags(flags, ids64=None, ids32=None, n=None, n_dev=None, v=1):

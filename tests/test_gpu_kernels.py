@@ -308,11 +308,10 @@ def test_worklist_and_flags(ops):
   ids32 = rs.randint(0, N, 5000).astype(np.int32)
   ids64 = rs.randint(0, N, 700).astype(np.int64)
   flags = (rs.rand(N) < 0.4).astype(np.uint8)
-  stamp = torch.zeros(N, dtype=torch.int32, device=DEV)
+  stamp = torch.zeros(N, dtype=torch.int64, device=DEV)
   wl = torch.zeros(N, dtype=torch.int32, device=DEV)
   cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
-  for epoch in (1, 2):
-    ops.fill_i32(cnt, 0)
+  for epoch in (1, 10001):
     ops.worklist_build(_t(ids32), _t(ids64), _t(flags), stamp, epoch, wl, cnt)
     n = int(cnt.item())
     u = np.unique(np.concatenate([ids32.astype(np.int64), ids64]))

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the individual kernels at the bench.py shapes (HIP events, median of N launches).
+Usage (on the GPU box): python tools/kbench.py [--nodes 1000000] [--edges 10000000]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from orca_amd import ops, synth  # noqa: E402
+
+
+def timeit(fn, n=30, warm=5):
+  for _ in range(warm):
+    fn()
+  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+  for a, b in ev:
+    a.record()
+    fn()
+    b.record()
+  torch.cuda.synchronize()
+  ts = sorted(a.elapsed_time(b) for a, b in ev)
+  return ts[len(ts) // 2] * 1e3   # us
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--nodes", type=int, default=1_000_000)
+  ap.add_argument("--edges", type=int, default=10_000_000)
+  ap.add_argument("--q", type=int, default=4095)
+  ap.add_argument("--k", type=int, default=10)
+  ap.add_argument("--d-e", type=int, default=172)
+  a = ap.parse_args()
+  dev = "cuda:0"
+  N, E, Q, K, d_e = a.nodes, a.edges, a.q, a.k, a.d_e
+  src, dst, eidx, ts = synth.powerlaw_graph(N, E, dev)
+  csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
+  ef = synth.edge_features(E, d_e, dev)
+  sd = synth.tgn_state_dict(d_e, 2)
+  p = "embedding_module.attention_models.0."
+  blob = ops.tgat_pack({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, d_e, dev)
+  g = "memory_updater.memory_updater."
+  gblob = ops.gru_pack(sd[g + "weight_ih"], sd[g + "weight_hh"], sd[g + "bias_ih"], sd[g + "bias_hh"], dev)
+  tw = sd["time_encoder.w.weight"].reshape(-1).to(dev).contiguous()
+  tb = torch.zeros(100, device=dev)
+  s0 = int(0.7 * E)
+  nodes = torch.cat([src[s0:s0 + Q // 3], dst[s0:s0 + Q // 3], torch.randint(1, N + 1, (Q - 2 * (Q // 3),), device=dev)])
+  t3 = ts[s0:s0 + Q // 3].repeat(3)[:Q].contiguous()
+  if t3.numel() < Q:
+    t3 = torch.cat([t3, t3[:Q - t3.numel()]])
+  memory = torch.randn(N + 1, 100, device=dev)
+  overlay = torch.randn(N + 1, 100, device=dev)
+  pending = (torch.rand(N + 1, device=dev) < 0.5).to(torch.uint8)
+  msg_dim = 300 + d_e
+  messages = torch.randn(N + 1, msg_dim, device=dev)
+  res = {}
+  res["sample_recent"] = timeit(lambda: ops.sample_recent(csr, nodes, t3, K))
+  nbr, eid, et, dt = ops.sample_recent(csr, nodes, t3, K)
+  n32 = nodes.to(torch.int32)
+  out = torch.empty(Q, 100, device=dev)
+  res["tgat_layer1_gather_overlay"] = timeit(lambda: ops.tgat_forward(
+      blob, d_e, Q, K, out=out, src_table=memory, src_idx=n32, src_overlay=overlay, src_flags=pending, nbr_table=memory,
+      nbr_idx=nbr, nbr_overlay=overlay, nbr_flags=pending, nbr_ids=nbr, edge_table=ef, edge_idx=eid, dt=dt, time_w=tw,
+      time_b=tb))
+  emb = torch.randn(Q, 100, device=dev)
+  res["tgat_layer2_history"] = timeit(lambda: ops.tgat_forward(
+      blob, d_e, Q, K, out=out, src_table=emb, nbr_table=memory, nbr_idx=nbr, nbr_ids=nbr, edge_table=ef, edge_idx=eid,
+      dt=dt, time_w=tw, time_b=tb))
+  # phase breakdown of the attention kernel (100 MHz counter -> us), median over workgroups
+  from orca_amd import _lib
+  nwg = (Q + 15) // 16
+  clk = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
+  _lib.load().orca_debug_tgat_phase_clock(clk.data_ptr())
+  ops.tgat_forward(blob, d_e, Q, K, out=out, src_table=memory, src_idx=n32, src_overlay=overlay, src_flags=pending,
+                   nbr_table=memory, nbr_idx=nbr, nbr_overlay=overlay, nbr_flags=pending, nbr_ids=nbr, edge_table=ef,
+                   edge_idx=eid, dt=dt, time_w=tw, time_b=tb)
+  torch.cuda.synchronize()
+  _lib.load().orca_debug_tgat_phase_clock(None)
+  c = clk.view(nwg, 16).cpu().double()
+  d = (c[:, 1:11] - c[:, 0:10]) / 100.0
+  names = ["T0+P0 stage", "P1 q-proj", "P2 fold", "P3 per-query", "P4 Wv", "P5 out-proj", "P6 fc1", "P7 fc2", "P8 LN"]
+  print("tgat phases (median us over workgroups):", {n: round(float(d[:, i].median()), 2) for i, n in enumerate(names)})
+  print("tgat workgroup span us: median", float(((c[:, 9] - c[:, 0]) / 100).median()), "chip span",
+        float((c[:, 9].max() - c[:, 0].min()) / 100), " start skew", float((c[:, 0].max() - c[:, 0].min()) / 100))
+  stamp = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+  wl = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+  cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+  ep = [1]
+
+  def worklist():
+    ops.worklist_build(nbr, nodes, pending, stamp, ep[0], wl, cnt)
+    ep[0] += nbr.numel() + nodes.numel() + 1
+  res["fill+worklist"] = timeit(worklist)
+  n_rows = int(cnt.item())
+  res["worklist_rows"] = n_rows
+  bound = min(Q * (K + 1), N + 1)
+  res[f"gru_overlay_{n_rows}rows_bound{bound}"] = timeit(lambda: ops.gru_update(gblob, msg_dim, wl, bound, cnt, messages,
+                                                                                 memory, overlay))
+  for n in (2730, 8192, 32768):
+    ids = torch.randperm(N, device=dev)[:n].to(torch.int32)
+    res[f"gru_{n}rows"] = timeit(lambda: ops.gru_update(gblob, msg_dim, ids, n, None, messages, memory, overlay))
+  slot = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+  se = [1]
+
+  def push():
+    ops.history_push(overlay, emb, nodes, slot, se[0])
+    se[0] += Q + 1
+  res["history_push"] = timeit(push)
+  bs = Q // 3
+  last_update = torch.zeros(N + 1, device=dev)
+  msg_ts = torch.zeros(N + 1, device=dev)
+
+  def store():
+    ops.message_store(src[s0:s0 + bs], dst[s0:s0 + bs], eidx[s0:s0 + bs], ts[s0:s0 + bs], memory, last_update, ef, tw, tb,
+                      slot, se[0], messages, msg_ts, pending)
+    se[0] += 2 * bs + 1
+  res["message_store"] = timeit(store)
+  fl = synth.tgat_flops_per_query(d_e, K) * Q
+  for k, v in res.items():
+    extra = ""
+    if k.startswith("tgat"):
+      extra = f"  {fl / v / 1e6:.1f} TFLOP/s ({fl / v / 1e6 / 157.3 * 100:.1f}% of fp32 MFMA peak)"
+    if k.startswith("gru_") and "rows" in k and not k.startswith("gru_overlay"):
+      n = int(k.split("_")[1][:-4])
+      extra = f"  {n * 2 * (msg_dim + 100) * 300 / v / 1e6:.1f} TFLOP/s"
+    print(f"{k:45s} {v:10.1f} us{extra}" if isinstance(v, float) else f"{k:45s} {v}")
+
+
+if __name__ == "__main__":
+  main()
