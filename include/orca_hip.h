@@ -212,6 +212,69 @@ int orca_gather_rows(const float* table, int64_t width, const int64_t* idx64, co
 int orca_scatter_rows(float* table, int64_t width, const int64_t* ids, int64_t n, const float* x,
                       void* stream);
 
+/* ---- native step driver: model/tgn_model.py:95-147 with modules/embedding_module.py:154-182 ----- */
+
+/* One TGN batch step in the embedding-reuse (--reuse, budget 0) formulation, issued from C++ on one
+ * stream.  Every table and work buffer is caller-owned device memory, described once: */
+#define ORCA_ENGINE_MAX_LAYERS 4
+typedef struct orca_engine orca_engine_t;
+typedef struct {
+  int64_t n_nodes;                 /* rows of the state tables (args.n_nodes, train.py:129) */
+  int32_t n_layers, K, d_e, reserved;
+  const orca_csr_t* csr;           /* may be NULL here and set later (orca_engine_set_csr) */
+  const float* edge_feats;         /* [n_edges+1, d_e] */
+  const float* time_w;             /* [ORCA_D] time_encoder.w.weight */
+  const float* time_b;             /* [ORCA_D] time_encoder.w.bias */
+  const float* att_blob[ORCA_ENGINE_MAX_LAYERS];   /* orca_tgat_pack output per layer */
+  const float* gru_blob;           /* orca_gru_pack output */
+  float* memory;                   /* [n_nodes, ORCA_D]   modules/memory.py:18 */
+  float* last_update;              /* [n_nodes]           :19 */
+  float* messages;                 /* [n_nodes, 300+d_e]  :22 */
+  float* msg_ts;                   /* [n_nodes]           :23 */
+  uint8_t* pending;                /* [n_nodes]           :21 (host bool array upstream) */
+  float* overlay;                  /* [n_nodes, ORCA_D]   GRU(message, memory) rows of get_updated_memory */
+  float* hist[ORCA_ENGINE_MAX_LAYERS - 1];         /* [n_nodes, ORCA_D] per inner layer, modules/history.py:11 */
+  int64_t* slot;                   /* [n_nodes] election scratch (epochs handed out by the engine) */
+  int32_t* worklist;               /* [n_nodes] */
+  int32_t* count;                  /* [1] */
+  int64_t q_max;                   /* capacity of the work buffers in root queries */
+  int64_t* nodes;                  /* [q_max]  [src;dst;neg]        tgn_model.py:99 */
+  double* qts;                     /* [q_max]  [t;t;t]              :102 */
+  int32_t* nodes32;                /* [q_max] */
+  int32_t* nbr;                    /* [q_max*K] sampler outputs of this rank's slice */
+  int32_t* eid;                    /* [q_max*K] */
+  float* et;                       /* [q_max*K] */
+  float* dt;                       /* [q_max*K] */
+  float* emb[2];                   /* [q_max, ORCA_D] each: layer outputs ping-pong (layer l -> emb[(l+1)&1]) */
+} orca_engine_desc;
+
+int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** out);
+/* Measurement aid: while enabled, the sampler / GRU / attention launches of the step are bracketed with HIP
+ * events on the launch stream; orca_engine_profile_read waits for them and returns count and mean ms. */
+#define ORCA_PROF_SAMPLE 0
+#define ORCA_PROF_GRU 1
+#define ORCA_PROF_TGAT 2
+#define ORCA_PROF_CLASSES 3
+int orca_engine_profile(orca_engine_t* e, int enable);
+int orca_engine_profile_read(orca_engine_t* e, int cls, int64_t* launches, double* mean_ms);
+int orca_engine_destroy(orca_engine_t* e);
+int orca_engine_set_csr(orca_engine_t* e, const orca_csr_t* csr);           /* tgn_model.py:193-195 */
+/* hands out n consecutive epochs of the shared `slot` table (for callers that use it between steps) */
+int64_t orca_engine_take_epochs(orca_engine_t* e, int64_t n);
+/* Builds the Q = 3*bs root queries [src;dst;neg] x [t;t;t]; for this rank's slice [lo,hi) of them: samples
+ * the K most recent neighbours, (train) applies GRU(message, memory) for the rows it will read into the
+ * overlay, runs attention layer 1 -> emb[0][lo:hi).  embedding_module.py:156-177 */
+int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                      const double* ts, int64_t bs, int64_t lo, int64_t hi, int train, void* stream);
+/* layer in 2..n_layers: pushes ALL Q rows of the previous layer's output into the layer's history table
+ * (callers with several ranks all-gather emb[layer&1] first), then attention over the pulled rows for the
+ * slice -> emb[(layer+1)&1][lo:hi).  embedding_module.py:103-113,177-181 */
+int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t hi, void* stream);
+/* Memory persist for the batch's positives and raw-message build + store, in the train or eval order the
+ * batch was begun with.  tgn_model.py:127-145 */
+int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* eidx,
+                       const double* ts, void* stream);
+
 /* ---- offline cache planner: utils/cache.py:19-89 (read_batches) + :92-166 (MRD_numba) ------- */
 
 /* HOST function (all pointers are host memory).  For the E training interactions (src, dst) cut into

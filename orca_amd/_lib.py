@@ -26,6 +26,20 @@ class TgatInputs(ctypes.Structure):
       "dt", "time_w", "time_b", "src_time", "nbr_time")]
 
 
+ORCA_ENGINE_MAX_LAYERS = 4
+
+
+class EngineDesc(ctypes.Structure):
+  """orca_engine_desc (include/orca_hip.h)."""
+  _fields_ = ([("n_nodes", i64), ("n_layers", ctypes.c_int32), ("K", ctypes.c_int32), ("d_e", ctypes.c_int32),
+               ("reserved", ctypes.c_int32), ("csr", vp), ("edge_feats", vp), ("time_w", vp), ("time_b", vp),
+               ("att_blob", vp * ORCA_ENGINE_MAX_LAYERS), ("gru_blob", vp), ("memory", vp), ("last_update", vp),
+               ("messages", vp), ("msg_ts", vp), ("pending", vp), ("overlay", vp),
+               ("hist", vp * (ORCA_ENGINE_MAX_LAYERS - 1)), ("slot", vp), ("worklist", vp), ("count", vp),
+               ("q_max", i64), ("nodes", vp), ("qts", vp), ("nodes32", vp), ("nbr", vp), ("eid", vp), ("et", vp),
+               ("dt", vp), ("emb", vp * 2)])
+
+
 # name -> (restype, argtypes); every symbol include/orca_hip.h declares
 SIGNATURES = {
     "orca_last_error": (ctypes.c_char_p, []),
@@ -58,6 +72,15 @@ SIGNATURES = {
     "orca_history_push": (i32, [vp, vp, vp, i64, vp, i64, i64, vp]),
     "orca_gather_rows": (i32, [vp, i64, vp, vp, i64, vp, vp]),
     "orca_scatter_rows": (i32, [vp, i64, vp, i64, vp, vp]),
+    "orca_engine_create": (i32, [ctypes.POINTER(EngineDesc), ctypes.POINTER(vp)]),
+    "orca_engine_destroy": (i32, [vp]),
+    "orca_engine_profile": (i32, [vp, i32]),
+    "orca_engine_profile_read": (i32, [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]),
+    "orca_engine_set_csr": (i32, [vp, vp]),
+    "orca_engine_take_epochs": (i64, [vp, i64]),
+    "orca_engine_begin": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
+    "orca_engine_layer": (i32, [vp, i32, i64, i64, vp]),
+    "orca_engine_finish": (i32, [vp, vp, vp, vp, vp, vp]),
     "orca_mrd_plan_host": (i32, [i64, i64, i32, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]),
 }
 

@@ -1,0 +1,223 @@
+// Native driver of one TGN batch step in the embedding-reuse (Orca-P) formulation: the launch sequence of
+// model/tgn_model.py:95-147 + modules/embedding_module.py:154-182 issued from C++ on one stream, so a
+// step costs three library calls instead of ~25 Python-dispatched launches (the step is a few hundred
+// microseconds of GPU time: host dispatch, not the kernels, was the limit).  All tables and work buffers
+// are caller-owned (orca_engine_desc); the handle only remembers pointers and the scratch-epoch counter.
+//
+// The step is cut where ranks of a multi-GPU run have to exchange rows:
+//   orca_engine_begin  : build [src;dst;neg] queries, sample, GRU overlay, attention layer 1   -> emb[0][lo:hi)
+//   orca_engine_layer  : history push of ALL Q rows of the previous layer (global order), attention layer l
+//   orca_engine_finish : persist memory update + raw-message build/store (train or eval order)
+#include <new>
+#include <vector>
+#include "common.h"
+
+struct orca_engine {
+  orca_engine_desc d;
+  int64_t epoch;       // next unused value of the `slot` scratch table
+  int64_t bs, Q;       // current batch
+  int train;
+  bool profile;        // bracket the sampler / GRU / attention launches with HIP events
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ORCA_PROF_CLASSES];
+};
+
+namespace {
+
+__global__ void k_build_queries(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                const int64_t* __restrict__ neg, const double* __restrict__ ts, int64_t bs,
+                                int64_t* __restrict__ nodes, double* __restrict__ qts, int32_t* __restrict__ nodes32) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * bs) return;
+  const int64_t e = i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs);
+  const int64_t v = i < bs ? src[e] : (i < 2 * bs ? dst[e] : neg[e]);   // tgn_model.py:99
+  nodes[i] = v;
+  nodes32[i] = (int32_t)v;
+  qts[i] = ts[e];                                                       // :102
+}
+
+// RAII bracket: records an event pair on the launch stream around one kernel when profiling is on
+struct Timed {
+  orca_engine* e; int cls; hipStream_t s; hipEvent_t a, b; bool on;
+  Timed(orca_engine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_), a(nullptr), b(nullptr), on(e_->profile) {
+    if (on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
+    else on = false;
+  }
+  ~Timed() {
+    if (!on) return;
+    (void)hipEventRecord(b, s);
+    e->ev[cls].emplace_back(a, b);
+  }
+};
+
+int64_t take_epochs(orca_engine* e, int64_t n) {
+  int64_t s = e->epoch;
+  e->epoch += n + 1;
+  return s;
+}
+
+}  // namespace
+
+ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** out) {
+  ORCA_REQUIRE(desc && out, "orca_engine_create: null pointer");
+  const orca_engine_desc& d = *desc;
+  ORCA_REQUIRE(d.n_nodes > 0 && d.n_layers >= 1 && d.n_layers <= ORCA_ENGINE_MAX_LAYERS && d.K >= 1 && d.K <= ORCA_MAX_K &&
+               d.d_e >= 1 && d.d_e <= ORCA_MAX_DE && d.q_max > 0, "orca_engine_create: bad sizes");
+  ORCA_REQUIRE(d.edge_feats && d.time_w && d.time_b && d.gru_blob && d.memory && d.last_update && d.messages &&
+               d.msg_ts && d.pending && d.overlay && d.slot && d.worklist && d.count && d.nodes && d.qts && d.nodes32 &&
+               d.nbr && d.eid && d.et && d.dt && d.emb[0] && d.emb[1], "orca_engine_create: null table or work buffer");
+  for (int l = 0; l < d.n_layers; ++l) ORCA_REQUIRE(d.att_blob[l], "orca_engine_create: missing attention blob %d", l);
+  for (int l = 0; l + 1 < d.n_layers; ++l) ORCA_REQUIRE(d.hist[l], "orca_engine_create: missing history table %d", l);
+  orca_engine* e = new (std::nothrow) orca_engine();
+  if (!e) { orca_set_error("orca_engine_create: out of host memory"); return ORCA_ENOMEM; }
+  e->d = d;
+  e->epoch = 1;
+  e->bs = e->Q = 0;
+  e->train = 1;
+  e->profile = false;
+  *out = e;
+  return ORCA_OK;
+}
+
+ORCA_API int orca_engine_profile(orca_engine_t* e, int enable) {
+  ORCA_REQUIRE(e, "orca_engine_profile: null handle");
+  e->profile = enable != 0;
+  return ORCA_OK;
+}
+
+ORCA_API int orca_engine_profile_read(orca_engine_t* e, int cls, int64_t* launches, double* mean_ms) {
+  ORCA_REQUIRE(e && cls >= 0 && cls < ORCA_PROF_CLASSES && launches && mean_ms, "orca_engine_profile_read: bad arguments");
+  double total = 0.0;
+  int64_t n = 0;
+  for (auto& p : e->ev[cls]) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+      total += ms;
+      ++n;
+    }
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  e->ev[cls].clear();
+  *launches = n;
+  *mean_ms = n ? total / (double)n : 0.0;
+  return ORCA_OK;
+}
+
+ORCA_API int orca_engine_destroy(orca_engine_t* e) {
+  if (e) {
+    int64_t n; double ms;
+    for (int c = 0; c < ORCA_PROF_CLASSES; ++c) (void)orca_engine_profile_read(e, c, &n, &ms);
+  }
+  delete e;
+  return ORCA_OK;
+}
+
+ORCA_API int orca_engine_set_csr(orca_engine_t* e, const orca_csr_t* csr) {
+  ORCA_REQUIRE(e, "orca_engine_set_csr: null handle");
+  e->d.csr = csr;
+  return ORCA_OK;
+}
+
+ORCA_API int64_t orca_engine_take_epochs(orca_engine_t* e, int64_t n) {
+  if (!e || n < 0) return -1;
+  return take_epochs(e, n);
+}
+
+ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                               const double* ts, int64_t bs, int64_t lo, int64_t hi, int train, void* stream_) {
+  ORCA_REQUIRE(e && e->d.csr, "orca_engine_begin: no neighbour finder set");
+  const orca_engine_desc& d = e->d;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t Q = 3 * bs;
+  ORCA_REQUIRE(bs >= 0 && Q <= d.q_max && 0 <= lo && lo <= hi && hi <= Q, "orca_engine_begin: batch of %lld interactions "
+               "(slice %lld..%lld) does not fit q_max=%lld", (long long)bs, (long long)lo, (long long)hi, (long long)d.q_max);
+  e->bs = bs; e->Q = Q; e->train = train;
+  if (bs == 0) return ORCA_OK;
+  ORCA_REQUIRE(src && dst && neg && ts, "orca_engine_begin: null batch array");
+  k_build_queries<<<(unsigned)ceil_div64(Q, 256), 256, 0, stream>>>(src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32);
+  ORCA_LAUNCH_CHECK();
+  const int64_t n = hi - lo;
+  if (n == 0) return ORCA_OK;
+  const int K = d.K;
+  int rc;
+  {
+    Timed t(e, ORCA_PROF_SAMPLE, stream);
+    rc = orca_sample_recent(d.csr, d.nodes + lo, d.qts + lo, n, K, d.nbr, d.eid, d.et, d.dt, nullptr, stream_);   // embedding_module.py:157
+  }
+  if (rc != ORCA_OK) return rc;
+  orca_tgat_inputs in{};
+  in.src_table = d.memory; in.src_idx = d.nodes32 + lo;
+  in.nbr_table = d.memory; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;
+  in.edge_table = d.edge_feats; in.edge_idx = d.eid;
+  in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b;
+  if (train) {   // :159-161 get_updated_memory(unique(neighbors ∪ sources)) -> overlay rows
+    const int64_t cand = n * (K + 1);
+    rc = orca_worklist_build(d.nbr, n * K, d.nodes + lo, n, d.pending, d.slot, take_epochs(e, cand), d.n_nodes, d.worklist,
+                             d.count, stream_);
+    if (rc != ORCA_OK) return rc;
+    {
+      Timed t(e, ORCA_PROF_GRU, stream);
+      rc = orca_gru_update(d.gru_blob, 3 * ORCA_D + d.d_e, d.worklist, cand < d.n_nodes ? cand : d.n_nodes, d.count,
+                           d.messages, d.memory, d.overlay, nullptr, nullptr, stream_);
+    }
+    if (rc != ORCA_OK) return rc;
+    in.src_overlay = d.overlay; in.src_flags = d.pending;
+    in.nbr_overlay = d.overlay; in.nbr_flags = d.pending;
+  }
+  Timed t(e, ORCA_PROF_TGAT, stream);
+  return orca_tgat_forward(d.att_blob[0], d.d_e, &in, n, K, d.emb[0] + lo * ORCA_D, nullptr, stream_);   // :177 / :181
+}
+
+ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t hi, void* stream_) {
+  ORCA_REQUIRE(e, "orca_engine_layer: null handle");
+  const orca_engine_desc& d = e->d;
+  ORCA_REQUIRE(layer >= 2 && layer <= d.n_layers, "orca_engine_layer: layer %d outside [2,%d]", layer, d.n_layers);
+  ORCA_REQUIRE(0 <= lo && lo <= hi && hi <= e->Q, "orca_engine_layer: bad slice");
+  if (e->Q == 0) return ORCA_OK;
+  const float* prev = d.emb[layer & 1];            // layer 2 reads emb[0], layer 3 reads emb[1], ...
+  float* next = d.emb[(layer + 1) & 1];
+  float* h = d.hist[layer - 2];
+  // embedding_module.py:103-113 push of every root's layer-(l-1) embedding, last occurrence wins (H7)
+  int rc = orca_history_push(h, prev, d.nodes, e->Q, d.slot, take_epochs(e, e->Q), d.n_nodes, stream_);
+  if (rc != ORCA_OK || hi == lo) return rc;
+  orca_tgat_inputs in{};
+  in.src_table = prev + lo * ORCA_D;               // dense rows of this rank's slice
+  in.nbr_table = h; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;   // pull (history.py:32-36) fused into the gather
+  in.edge_table = d.edge_feats; in.edge_idx = d.eid;
+  in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b;
+  Timed t(e, ORCA_PROF_TGAT, (hipStream_t)stream_);
+  return orca_tgat_forward(d.att_blob[layer - 1], d.d_e, &in, hi - lo, d.K, next + lo * ORCA_D, nullptr, stream_);
+}
+
+ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* eidx,
+                                const double* ts, void* stream_) {
+  ORCA_REQUIRE(e, "orca_engine_finish: null handle");
+  const orca_engine_desc& d = e->d;
+  const int64_t bs = e->bs;
+  if (bs == 0) return ORCA_OK;
+  ORCA_REQUIRE(src && dst && eidx && ts, "orca_engine_finish: null batch array");
+  const int msg_dim = 3 * ORCA_D + d.d_e;
+  auto persist = [&]() -> int {   // memory_updater.update_memory (:25-39) + clear_messages (memory.py:49-50)
+    int rc = orca_worklist_build(nullptr, 0, d.nodes, 2 * bs, d.pending, d.slot, take_epochs(e, 2 * bs), d.n_nodes,
+                                 d.worklist, d.count, stream_);
+    if (rc != ORCA_OK) return rc;
+    {
+      Timed t(e, ORCA_PROF_GRU, (hipStream_t)stream_);
+      rc = orca_gru_update(d.gru_blob, msg_dim, d.worklist, 2 * bs < d.n_nodes ? 2 * bs : d.n_nodes, d.count, d.messages,
+                           d.memory, d.memory, d.last_update, d.msg_ts, stream_);
+    }
+    if (rc != ORCA_OK) return rc;
+    return orca_set_flags(d.pending, d.nodes, nullptr, 2 * bs, nullptr, 0, stream_);
+  };
+  auto store = [&]() -> int {     // tgn_model.py:131-141,172-191 + memory.py:25-28
+    return orca_message_store(src, dst, eidx, ts, bs, d.memory, d.last_update, d.edge_feats, d.d_e, d.time_w, d.time_b,
+                              d.slot, take_epochs(e, 2 * bs), d.n_nodes, d.messages, d.msg_ts, d.pending, stream_);
+  };
+  int rc;
+  if (e->train) {                 // tgn_model.py:127-141
+    if ((rc = persist()) != ORCA_OK) return rc;
+    return store();
+  }
+  if ((rc = store()) != ORCA_OK) return rc;   // :131-145
+  return persist();
+}

@@ -15,12 +15,15 @@ contiguous slice of the batch's (node, t) queries; the rows that later stages re
 resolution (last occurrence wins) is applied after the gather in global query order, so N-rank
 results equal 1-rank results.
 """
+import ctypes
+
 import numpy as np
 import torch
 
+from . import _lib
 from . import dist as dist_utils
 from . import ops
-from ._lib import ORCA_D, OrcaError
+from ._lib import ORCA_D, OrcaError, check, ptr, stream
 
 D = ORCA_D
 
@@ -69,6 +72,9 @@ class OrcaEngine:
     self.csr = None
     self.test_mode = False
     self.batch_counter = 0
+    self._native = None      # orca_engine_t: the C++ step driver (created on first use, regrown with the batch)
+    self._q_max = 0
+    self._prof_native = False
     self.prof = None     # set to {} to bracket the kernels with HIP events (bench.py roofline)
 
   def _timed(self, name, fn, *a, **k):
@@ -106,6 +112,8 @@ class OrcaEngine:
   def set_neighbor_finder(self, csr):
     """tgn_model.py:193-195; csr is an ops.CSR (or a shim NeighborFinder carrying .csr)."""
     self.csr = getattr(csr, "csr", csr)
+    if self._native is not None:
+      check(_lib.load().orca_engine_set_csr(self._native, self.csr._h), "orca_engine_set_csr")
 
   # modules/memory.py:17-23, modules/history.py:14-20
   def reset_state(self):
@@ -130,9 +138,117 @@ class OrcaEngine:
 
   # -------------------------------------------------------------------------------------------
   def _slot_epoch(self, n):
+    """n consecutive epochs of the `slot` election table (shared with the native driver)"""
+    if self._native is not None:
+      return int(_lib.load().orca_engine_take_epochs(self._native, int(n)))
     e = self.slot_epoch
     self.slot_epoch += int(n) + 1
     return e
+
+  # ---- native step driver (csrc/engine.hip) -------------------------------------------------------
+  def _ensure_native(self, Q):
+    """(re)creates the orca_engine_t with work buffers for Q root queries (padded to the rank grid)"""
+    per = (Q + self.world - 1) // self.world
+    need = max(per * self.world, 1)
+    if self._native is not None and need <= self._q_max:
+      return
+    L = _lib.load()
+    if self._native is not None:
+      self.slot_epoch = int(L.orca_engine_take_epochs(self._native, 0))
+      L.orca_engine_destroy(self._native)
+      self._native = None
+    dev, K = self.device, self.K
+    q_max = max(need, 2 * self._q_max)
+    self._w = dict(nodes=torch.zeros(q_max, dtype=torch.int64, device=dev),
+                   qts=torch.zeros(q_max, dtype=torch.float64, device=dev),
+                   nodes32=torch.zeros(q_max, dtype=torch.int32, device=dev),
+                   nbr=torch.zeros(q_max * K, dtype=torch.int32, device=dev),
+                   eid=torch.zeros(q_max * K, dtype=torch.int32, device=dev),
+                   et=torch.zeros(q_max * K, dtype=torch.float32, device=dev),
+                   dt=torch.zeros(q_max * K, dtype=torch.float32, device=dev),
+                   emb=[torch.zeros(q_max, D, dtype=torch.float32, device=dev) for _ in range(2)])
+    d = _lib.EngineDesc()
+    d.n_nodes, d.n_layers, d.K, d.d_e = self.N, self.L, K, self.d_e
+    d.csr = self.csr._h if self.csr is not None else None
+    d.edge_feats, d.time_w, d.time_b = ptr(self.edge_feats), ptr(self.time_w), ptr(self.time_b)
+    for i, b in enumerate(self.att_blobs):
+      d.att_blob[i] = ptr(b)
+    d.gru_blob = ptr(self.gru_blob)
+    d.memory, d.last_update, d.messages = ptr(self.memory), ptr(self.last_update), ptr(self.messages)
+    d.msg_ts, d.pending, d.overlay = ptr(self.msg_ts), ptr(self.pending), ptr(self.overlay)
+    for i, h in enumerate(self.hist):
+      d.hist[i] = ptr(h)
+    d.slot, d.worklist, d.count = ptr(self.slot), ptr(self.worklist), ptr(self.count)
+    d.q_max = q_max
+    w = self._w
+    d.nodes, d.qts, d.nodes32 = ptr(w["nodes"]), ptr(w["qts"]), ptr(w["nodes32"])
+    d.nbr, d.eid, d.et, d.dt = ptr(w["nbr"]), ptr(w["eid"]), ptr(w["et"]), ptr(w["dt"])
+    d.emb[0], d.emb[1] = ptr(w["emb"][0]), ptr(w["emb"][1])
+    h = _lib.vp()
+    check(L.orca_engine_create(ctypes.byref(d), ctypes.byref(h)), "orca_engine_create")
+    L.orca_engine_take_epochs(h, self.slot_epoch)       # continue after the epochs already used on `slot`
+    self._native, self._q_max = h, q_max
+    if self._prof_native:
+      L.orca_engine_profile(h, 1)
+
+  def profile_kernels(self, on=True):
+    """bench.py: bracket the sampler / GRU / attention launches of the native step with HIP events"""
+    self._prof_native = bool(on)
+    if self._native is not None:
+      _lib.load().orca_engine_profile(self._native, int(on))
+
+  def profile_read(self):
+    """{kernel: (launches, mean ms)} measured since profile_kernels(True); waits for the events"""
+    out = {}
+    if self._native is None:
+      return out
+    for name, cls in (("sample_recent", 0), ("gru_update", 1), ("tgat_forward", 2)):
+      n, ms = _lib.i64(), ctypes.c_double()
+      check(_lib.load().orca_engine_profile_read(self._native, cls, ctypes.byref(n), ctypes.byref(ms)), "profile_read")
+      if n.value:
+        out[name] = (n.value, ms.value)
+    return out
+
+  def __del__(self):
+    try:
+      if self._native is not None:
+        _lib.load().orca_engine_destroy(self._native)
+        self._native = None
+    except Exception:
+      pass
+
+  def _step_reuse_native(self, src, dst, neg, ts, eidx, train):
+    """Path B + memory/messages through the C++ driver: begin -> (all-gather) -> layer ... -> finish"""
+    L = _lib.load()
+    bs = src.numel()
+    Q = 3 * bs
+    self._ensure_native(Q)
+    lo, hi, per = self._slice(Q)
+    st = stream()
+    check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(ts), bs, lo, hi, int(train), st),
+          "orca_engine_begin")
+    emb = self._w["emb"]
+    for layer in range(2, self.L + 1):
+      self._gather_in_place(emb[layer & 1], per)
+      check(L.orca_engine_layer(self._native, layer, lo, hi, st), "orca_engine_layer")
+    out = emb[(self.L + 1) & 1]
+    self._gather_in_place(out, per)
+    check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
+    return out[:Q]
+
+  def _gather_in_place(self, buf, per):
+    """every rank's rows [rank*per, rank*per+per) of buf -> all ranks (RCCL all-gather, in place)"""
+    if self.world == 1:
+      return
+    import torch.distributed as dist
+    full = buf[:self.world * per]
+    mine = full[self.rank * per:(self.rank + 1) * per]
+    if dist.get_backend(self.group) == "gloo":      # tests: gloo has no device all_gather
+      hf = torch.empty(full.shape, dtype=full.dtype)
+      dist.all_gather_into_tensor(hf, mine.cpu(), group=self.group)
+      full.copy_(hf)
+    else:
+      dist.all_gather_into_tensor(full, mine, group=self.group)
 
   def _build_worklist(self, ids32, ids64, bound):
     """distinct ids of (ids32 ∪ ids64) that hold a pending message -> self.worklist[:count]."""
@@ -282,6 +398,9 @@ class OrcaEngine:
     elif not self.test_mode:
       self._flush_all_pending()
       self.test_mode = True
+    if self.reuse and self.budget == 0 and self.prof is None:
+      # Path B end to end in the native driver (embedding, memory persist, message store)
+      return self._step_reuse_native(src, dst, neg, ts, eidx, train)
     if self.reuse and self.budget != 0:                # :114-120
       if self.world != 1:
         raise OrcaError("budgeted reuse (Path C) runs on one rank")
