@@ -158,6 +158,12 @@ int orca_gru_update(const float* blob, int msg_dim, const int32_t* ids, int64_t 
                     const float* x, const float* h, float* out, float* last_update, const float* msg_ts,
                     void* stream);
 
+/* dst_table[id] = src_table[id] (rows of ORCA_D floats) and, if last_update != NULL, last_update[id] =
+ * msg_ts[id], for the first min(n, *n_dev) ids of a work-list: commits GRU rows held in the overlay into
+ * the persistent memory (modules/memory_updater.py:36-39). */
+int orca_commit_rows(const int32_t* ids, int64_t n, const int32_t* n_dev, const float* src_table,
+                     float* dst_table, float* last_update, const float* msg_ts, void* stream);
+
 /* ---- node-id bookkeeping that the reference does with NumPy on the host ------------------- */
 
 /* Writes to worklist every distinct id of the concatenation of ids32 (n32 int32 values, e.g. the

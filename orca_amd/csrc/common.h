@@ -39,8 +39,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // W[nt*16 + (l&15)][kb*16 + 4*(l>>4) + s], s = 0..3 (zero outside the matrix).  One wave-wide
 // 16-byte load therefore fetches the B operands of four v_mfma_f32_16x16x4_f32 steps, fully
 // coalesced.  The A operand uses the same k permutation (lane l: A[l&15][kb*16 + 4*(l>>4) + s]).
-__host__ __device__ static inline int pw_tiles(int n) { return (n + 15) / 16; }
-__host__ __device__ static inline int64_t pw_floats(int N, int Kd) { return (int64_t)pw_tiles(N) * pw_tiles(Kd) * 256; }
+__host__ __device__ constexpr int pw_tiles(int n) { return (n + 15) / 16; }
+__host__ __device__ constexpr int64_t pw_floats(int N, int Kd) { return (int64_t)pw_tiles(N) * pw_tiles(Kd) * 256; }
 
 // One wave accumulates up to NT 16x16 output tiles of C = A(16 x 16*KB) * PW.
 // a_row: LDS pointer to this lane's A row (row l&15) already offset by 4*(l>>4) floats.

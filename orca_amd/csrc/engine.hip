@@ -17,6 +17,7 @@ struct orca_engine {
   int64_t epoch;       // next unused value of the `slot` scratch table
   int64_t bs, Q;       // current batch
   int train;
+  bool overlay_covers_batch;   // begin() ran in train order over the whole batch: overlay holds every pending root
   bool profile;        // bracket the sampler / GRU / attention launches with HIP events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ORCA_PROF_CLASSES];
 };
@@ -73,6 +74,7 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   e->epoch = 1;
   e->bs = e->Q = 0;
   e->train = 1;
+  e->overlay_covers_batch = false;
   e->profile = false;
   *out = e;
   return ORCA_OK;
@@ -132,6 +134,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   ORCA_REQUIRE(bs >= 0 && Q <= d.q_max && 0 <= lo && lo <= hi && hi <= Q, "orca_engine_begin: batch of %lld interactions "
                "(slice %lld..%lld) does not fit q_max=%lld", (long long)bs, (long long)lo, (long long)hi, (long long)d.q_max);
   e->bs = bs; e->Q = Q; e->train = train;
+  e->overlay_covers_batch = train && lo == 0 && hi == Q;
   if (bs == 0) return ORCA_OK;
   ORCA_REQUIRE(src && dst && neg && ts, "orca_engine_begin: null batch array");
   k_build_queries<<<(unsigned)ceil_div64(Q, 256), 256, 0, stream>>>(src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32);
@@ -198,14 +201,20 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
   ORCA_REQUIRE(src && dst && eidx && ts, "orca_engine_finish: null batch array");
   const int msg_dim = 3 * ORCA_D + d.d_e;
   auto persist = [&]() -> int {   // memory_updater.update_memory (:25-39) + clear_messages (memory.py:49-50)
+    const int64_t bound = 2 * bs < d.n_nodes ? 2 * bs : d.n_nodes;
     int rc = orca_worklist_build(nullptr, 0, d.nodes, 2 * bs, d.pending, d.slot, take_epochs(e, 2 * bs), d.n_nodes,
                                  d.worklist, d.count, stream_);
     if (rc != ORCA_OK) return rc;
-    {
+    // GRU(message, memory) of the pending positives goes to the overlay table, then the rows are committed.
+    // When this rank's begin() covered the whole batch in train order, the overlay already holds exactly
+    // these rows (same messages, same memory: positives are roots of the batch) and the GRU is not repeated.
+    if (!e->overlay_covers_batch) {
       Timed t(e, ORCA_PROF_GRU, (hipStream_t)stream_);
-      rc = orca_gru_update(d.gru_blob, msg_dim, d.worklist, 2 * bs < d.n_nodes ? 2 * bs : d.n_nodes, d.count, d.messages,
-                           d.memory, d.memory, d.last_update, d.msg_ts, stream_);
+      rc = orca_gru_update(d.gru_blob, msg_dim, d.worklist, bound, d.count, d.messages, d.memory, d.overlay, nullptr,
+                           nullptr, stream_);
+      if (rc != ORCA_OK) return rc;
     }
+    rc = orca_commit_rows(d.worklist, bound, d.count, d.overlay, d.memory, d.last_update, d.msg_ts, stream_);
     if (rc != ORCA_OK) return rc;
     return orca_set_flags(d.pending, d.nodes, nullptr, 2 * bs, nullptr, 0, stream_);
   };

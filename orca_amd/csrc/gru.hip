@@ -45,15 +45,16 @@ __global__ void k_gru_bias(float* dst, const float* b_ih, const float* b_hh) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-constexpr int KS = 2;             // the reduction (message | memory columns) is split over KS wave groups
 constexpr int GP = 2;             // k-blocks of weights fetched ahead (double buffered in registers)
+constexpr int KS2 = 2;            // the reduction (message | memory columns) is split over KS wave groups
 
-// Workgroup = 16*MT rows x (KS*7) waves.  Wave (ks, t) accumulates, for hidden units 16t..16t+15 and its
+// In-place-safe variant (out may alias h: a row is read and written by ONE workgroup).
+// Workgroup = 16*MT rows x (2*7) waves.  Wave (ks, t) accumulates, for hidden units 16t..16t+15 and its
 // share of the k-blocks, the four pre-activations r, z, i_n, h_n; group 1 hands its partial sums to
 // group 0 through LDS, which applies the gates.  Small MT = many short dependent MFMA chains in flight
 // (the row counts here are a few thousand: latency, not throughput, is what has to be engineered).
 template <int MT>
-__global__ __launch_bounds__(KS * NWG * 64) void k_gru_update(const float* __restrict__ blob, int msg_dim,
+__global__ __launch_bounds__(KS2 * NWG * 64) void k_gru_rows(const float* __restrict__ blob, int msg_dim,
                                                               const int32_t* __restrict__ ids, int64_t n_max,
                                                               const int32_t* __restrict__ n_dev,
                                                               const float* __restrict__ x, const float* h, float* out,
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(KS * NWG * 64) void k_gru_update(const float* __res
   }
   __syncthreads();
   // gather [x(msg_dim) 0.. | h(100) 0..] rows into LDS
-  for (int m = wave; m < TRows; m += KS * NWG) {
+  for (int m = wave; m < TRows; m += KS2 * NWG) {
     const int64_t id = s_id[m];
     float* row = lds + m * L.AS;
     for (int c = lane; c < L.XP; c += 64) row[c] = (id >= 0 && c < msg_dim) ? x[id * msg_dim + c] : 0.0f;
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(KS * NWG * 64) void k_gru_update(const float* __res
   // steps 0..KBx-1 walk the message columns (gates r, z, i_n), steps KBx.. the memory columns (r, z, h_n);
   // the A row is laid out [x | h] so step s reads A columns 16s..16s+15 either way
   const int n_steps = L.KBx + L.KBh;
-  const int s_lo = ks * ((n_steps + KS - 1) / KS);
-  const int s_hi = min(n_steps, s_lo + (n_steps + KS - 1) / KS);
+  const int s_lo = ks * ((n_steps + KS2 - 1) / KS2);
+  const int s_hi = min(n_steps, s_lo + (n_steps + KS2 - 1) / KS2);
   auto bload = [&](int s, f32x4 (&b)[3]) {
     const bool xs = s < L.KBx;
     const f32x4* base = xs ? px : ph;
@@ -176,6 +177,131 @@ __global__ __launch_bounds__(KS * NWG * 64) void k_gru_update(const float* __res
   }
 }
 
+
+constexpr int RW = 4;             // 16-row sub-tiles per workgroup (they share one hidden-unit tile)
+constexpr int KH = 2;             // each sub-tile's reduction is walked by KH waves, half each
+constexpr int GS = 4;             // steps of operands fetched ahead (ring of registers)
+
+// Out-of-place GRU: workgroup = (64 rows) x (one 16-wide tile of hidden units), 8 waves: wave (w, kh) owns
+// rows 16w..16w+15 and half kh of the reduction.  No LDS staging of operands: the A fragments (16 B per lane
+// straight from the [message | memory] rows in HBM/L2) and the B fragments (packed weights, shared by the
+// waves through L1) stream GS steps ahead of the MFMAs -- the kernel is bound by the latency of those
+// fetches, so what counts is how many are in flight.  Halves are summed through LDS (one barrier).
+// 7 workgroups per row tile give every CU work at the few-thousand-row counts of a batch, and 64-row tiles
+// keep the weight traffic from L2 at 111 KB per workgroup.  A row is read by 7 workgroups and written by
+// each of them: `out` must not alias `h` (orca_gru_update routes the in-place case to k_gru_rows).
+__global__ __launch_bounds__(RW * KH * 64) void k_gru_stream(const float* __restrict__ blob, int msg_dim,
+                                                        const int32_t* __restrict__ ids, int64_t n_max,
+                                                        const int32_t* __restrict__ n_dev,
+                                                        const float* __restrict__ x, const float* __restrict__ h,
+                                                        float* __restrict__ out, float* last_update,
+                                                        const float* __restrict__ msg_ts) {
+  const GBlob L = gru_layout(msg_dim);
+  __shared__ f32x4 s_part[RW][4][64];
+  const int t = blockIdx.x % NWG;                       // hidden-unit tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % RW, kh = (tid >> 6) / RW;
+  const int64_t r0 = ((int64_t)(blockIdx.x / NWG) * RW + wave) * 16;
+  const f32x4* blob4 = reinterpret_cast<const f32x4*>(blob);
+  const f32x4* px = blob4 + L.pw_x / 4;
+  const f32x4* ph = blob4 + L.pw_h / 4;
+  const int n_all = L.KBx + L.KBh;
+  const int s_beg = kh * ((n_all + KH - 1) / KH);
+  const int n_steps = min(n_all, s_beg + (n_all + KH - 1) / KH);   // this wave walks steps [s_beg, n_steps)
+  auto bload = [&](int s, f32x4 (&b)[3]) {
+    const bool xs = s < L.KBx;
+    const f32x4* base = xs ? px : ph;
+    const int kb = xs ? s : s - L.KBx, KBm = xs ? L.KBx : L.KBh;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) b[g] = base[((int64_t)(g * NWG + t) * KBm + kb) * 64 + lane];
+  };
+  // weights, biases and the (possibly stale beyond *n_dev, but always valid) ids depend on nothing: fetch
+  // them before the row count is known
+  f32x4 bq[GS][3], aq[GS];
+#pragma unroll
+  for (int g = 0; g < GS; ++g)
+    if (s_beg + g < n_steps) bload(s_beg + g, bq[g]);
+  const int64_t ra = r0 + (lane & 15);
+  const int64_t id_raw = ra < n_max ? (ids ? (int64_t)ids[ra] : ra) : -1;
+  const float* bias = blob + L.bias;
+  const int u = t * 16 + (lane & 15);
+  const float br = bias[u], bz = bias[112 + u], bi = bias[224 + u], bh = bias[336 + u];   // padded to 112: in range
+
+  int64_t n = n_max;
+  if (n_dev) {
+    int64_t nd = *n_dev;
+    n = nd < n ? nd : n;
+  }
+  if ((int64_t)(blockIdx.x / NWG) * RW * 16 >= n) return;   // workgroup-uniform (there is a barrier below)
+  // lane l feeds MFMA row l&15: its node id, and (epilogue) rows 4*(l>>4)+r
+  const int64_t id_a = ra < n ? id_raw : -1;
+  const float* xrow = x + (id_a < 0 ? 0 : id_a) * msg_dim + 4 * (lane >> 4);
+  const float* hrow = h + (id_a < 0 ? 0 : id_a) * D + 4 * (lane >> 4);
+  // A fragment of step s: 4 consecutive floats of this lane's row, zero beyond the row / for padding rows
+  auto aload = [&](int s) -> f32x4 {
+    const bool xs = s < L.KBx;
+    const int c = (xs ? s : s - L.KBx) * 16 + 4 * (lane >> 4);
+    const int width = xs ? msg_dim : D;                  // both are multiples of 4: a float4 is in or out
+    if (id_a < 0 || c >= width) return f32x4{0.f, 0.f, 0.f, 0.f};
+    return *reinterpret_cast<const f32x4*>((xs ? xrow : hrow) + (xs ? s : s - L.KBx) * 16);
+  };
+#pragma unroll
+  for (int g = 0; g < GS; ++g)
+    if (s_beg + g < n_steps) aq[g] = aload(s_beg + g);
+  // epilogue operands: ids of the 4 output rows of this lane and their previous memory
+  int64_t id_o[4];
+  float hp[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t ro = r0 + 4 * (lane >> 4) + r;
+    id_o[r] = ro < n ? (ids ? (int64_t)ids[ro] : ro) : -1;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) hp[r] = (id_o[r] >= 0 && u < D) ? h[id_o[r] * D + u] : 0.f;
+
+  f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, ai = ar, ah = ar;
+  for (int s0 = s_beg; s0 < n_steps; s0 += GS) {
+#pragma unroll
+    for (int g = 0; g < GS; ++g) {
+      const int s = s0 + g;
+      if (s < n_steps) {
+        const f32x4 a = aq[g];
+        f32x4 b[3] = {bq[g][0], bq[g][1], bq[g][2]};
+        if (s + GS < n_steps) {          // refill this ring slot with the operands of step s + GS
+          aq[g] = aload(s + GS);
+          bload(s + GS, bq[g]);
+        }
+        const bool xs = s < L.KBx;       // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[0][k], ar, 0, 0, 0);
+          az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[1][k], az, 0, 0, 0);
+          if (xs) ai = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[2][k], ai, 0, 0, 0);
+          else    ah = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[2][k], ah, 0, 0, 0);
+        }
+      }
+    }
+  }
+  // the second half hands its partial pre-activations to the first
+  if (kh == 1) {
+    s_part[wave][0][lane] = ar; s_part[wave][1][lane] = az; s_part[wave][2][lane] = ai; s_part[wave][3][lane] = ah;
+  }
+  __syncthreads();
+  if (kh != 0) return;
+  ar += s_part[wave][0][lane]; az += s_part[wave][1][lane]; ai += s_part[wave][2][lane]; ah += s_part[wave][3][lane];
+  // fused gate epilogue (torch.nn.GRUCell, gate order r, z, n)
+  if (u < D) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (id_o[r] < 0) continue;
+      const float rr = sigmoidf_(ar[r] + br);
+      const float zz = sigmoidf_(az[r] + bz);
+      const float nn = tanhf(ai[r] + bi + rr * (ah[r] + bh));
+      out[id_o[r] * D + u] = (1.0f - zz) * nn + zz * hp[r];
+    }
+  }
+  if (t == 0 && last_update && lane < 16 && id_a >= 0) last_update[id_a] = msg_ts[id_a];
+}
+
 }  // namespace
 
 ORCA_API int64_t orca_gru_blob_floats(int msg_dim) {
@@ -205,20 +331,28 @@ ORCA_API int orca_gru_pack(int msg_dim, const float* w_ih, const float* w_hh, co
   return ORCA_OK;
 }
 
-template <int MT>
-static int gru_launch(const float* blob, int msg_dim, const int32_t* ids, int64_t n, const int32_t* n_dev, const float* x,
-                      const float* h, float* out, float* last_update, const float* msg_ts, hipStream_t stream) {
+static int gru_launch_stream(const float* blob, int msg_dim, const int32_t* ids, int64_t n, const int32_t* n_dev,
+                             const float* x, const float* h, float* out, float* last_update, const float* msg_ts,
+                             hipStream_t stream) {
+  ORCA_REQUIRE(msg_dim % 4 == 0, "orca_gru_update: the streaming kernel needs msg_dim %% 4 == 0");
+  k_gru_stream<<<(unsigned)(ceil_div64(n, 16 * RW) * NWG), RW * KH * 64, 0, stream>>>(blob, msg_dim, ids, n, n_dev, x, h, out,
+                                                                              last_update, msg_ts);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+static int gru_launch_rows(const float* blob, int msg_dim, const int32_t* ids, int64_t n, const int32_t* n_dev,
+                           const float* x, const float* h, float* out, float* last_update, const float* msg_ts,
+                           hipStream_t stream) {
   GBlob L = gru_layout(msg_dim);
-  const int rows = 16 * MT;
-  size_t lds_bytes = (size_t)rows * L.AS * sizeof(float) + (size_t)NWG * 4 * MT * 64 * sizeof(f32x4);
+  size_t lds_bytes = (size_t)16 * L.AS * sizeof(float) + (size_t)NWG * 4 * 64 * sizeof(f32x4);
   static bool attr_set = false;
   if (!attr_set) {
-    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_gru_update<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_gru_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     attr_set = true;
   }
-  ORCA_REQUIRE(lds_bytes <= 160 * 1024 - 256, "orca_gru_update: LDS budget exceeded (%zu B)", lds_bytes);
-  k_gru_update<MT><<<(unsigned)ceil_div64(n, rows), KS * NWG * 64, lds_bytes, stream>>>(blob, msg_dim, ids, n, n_dev, x, h,
-                                                                                    out, last_update, msg_ts);
+  k_gru_rows<1><<<(unsigned)ceil_div64(n, 16), KS2 * NWG * 64, lds_bytes, stream>>>(blob, msg_dim, ids, n, n_dev, x, h, out,
+                                                                                 last_update, msg_ts);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -231,8 +365,40 @@ ORCA_API int orca_gru_update(const float* blob, int msg_dim, const int32_t* ids,
   ORCA_REQUIRE(blob && x && h && out, "orca_gru_update: null pointer");
   ORCA_REQUIRE(msg_dim >= 1 && msg_dim <= 3 * D + ORCA_MAX_DE, "orca_gru_update: msg_dim=%d unsupported", msg_dim);
   ORCA_REQUIRE(!last_update || msg_ts, "orca_gru_update: last_update without msg_ts");
-  // 16-row tiles keep every CU busy with short chains while the row count is small; above ~1.5 waves of
-  // workgroups the 32-row tile halves the weight traffic from L2
-  if (n_dev || n <= 6144) return gru_launch<1>(blob, msg_dim, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
-  return gru_launch<2>(blob, msg_dim, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
+  // in place (out aliases h): a row must be read and written by one workgroup
+  if (out == h) return gru_launch_rows(blob, msg_dim, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
+  // out of place: (64-row tile) x (hidden tile) workgroups streaming their operands; rows narrower than a
+  // multiple of 4 floats (the zero-feature datasets: msg_dim 301) take the row kernel as well
+  if (msg_dim % 4 != 0)
+    return gru_launch_rows(blob, msg_dim, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
+  return gru_launch_stream(blob, msg_dim, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
+}
+
+// out_table[id] = src_table[id] (+ last_update[id] = msg_ts[id]) for the ids of a device-counted work-list:
+// commits rows the GRU wrote to the overlay into the persistent memory (memory_updater.py:36-39)
+namespace {
+__global__ __launch_bounds__(256) void k_commit_rows(const int32_t* __restrict__ ids, int64_t n_max,
+                                                     const int32_t* __restrict__ n_dev, const float* __restrict__ src,
+                                                     float* __restrict__ dst, float* last_update,
+                                                     const float* __restrict__ msg_ts) {
+  int64_t n = n_max;
+  if (n_dev) { int64_t nd = *n_dev; n = nd < n ? nd : n; }
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int64_t id = ids[r];
+  for (int c = lane; c < D; c += 64) dst[id * D + c] = src[id * D + c];
+  if (last_update && lane == 0) last_update[id] = msg_ts[id];
+}
+}  // namespace
+
+ORCA_API int orca_commit_rows(const int32_t* ids, int64_t n, const int32_t* n_dev, const float* src_table,
+                              float* dst_table, float* last_update, const float* msg_ts, void* stream) {
+  ORCA_REQUIRE(n >= 0, "orca_commit_rows: n < 0");
+  if (n == 0) return ORCA_OK;
+  ORCA_REQUIRE(ids && src_table && dst_table && (!last_update || msg_ts), "orca_commit_rows: null pointer");
+  k_commit_rows<<<(unsigned)ceil_div64(n, 4), 256, 0, (hipStream_t)stream>>>(ids, n, n_dev, src_table, dst_table,
+                                                                            last_update, msg_ts);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
 }

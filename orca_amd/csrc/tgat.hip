@@ -29,8 +29,8 @@ struct Blob {   // float offsets inside the packed parameter blob
   int64_t pw_q, b_q, pw_kt, pw_v, b_v, b_vp, pw_o, b_o, pw_1, b_1, pw_2, b_2, ln_w, ln_b, total;
 };
 
-__host__ __device__ inline Blob blob_layout(int d_e) {
-  Blob L;
+__host__ __device__ constexpr Blob blob_layout(int d_e) {
+  Blob L{};
   L.kdim = QD + d_e;
   L.NTk = pw_tiles(L.kdim + 1);     // n-tiles of the folded key map (+1: the q.bk column)
   L.KP = L.NTk * 16;
@@ -154,73 +154,97 @@ __device__ __forceinline__ void for_acc(const f32x4& acc, int tile, int lane, F 
   for (int r = 0; r < 4; ++r) f(m0 + r, n, acc[r]);
 }
 
-// One wave's share of a projection: up to NT 16x16 output tiles of C = A(16 x 16*KB) * PW, the B operands
-// streamed from L2 G k-blocks ahead (double buffered in registers).  prefetch() only needs the weights, so
-// it is issued BEFORE the barrier that publishes the A operand: the first group's L2 round trip hides
-// behind the barrier wait instead of starting every phase.
-template <int NT, int G>
+// One wave's share of a projection: NT 16x16 output tiles of C = A(16 x 16*KB) * PW, the B operands streamed
+// from L2 G k-blocks ahead in a register ring.  prefetch() only needs the weights, so it is issued BEFORE the
+// barrier that publishes the A operand: the first group's L2 round trip hides behind the barrier wait.
+// KBC > 0 = compile-time k-block count: the whole chain is unrolled and BRANCH-FREE (the compiler's
+// s_waitcnt placement gives up at control flow -- with run-time trip counts every step ended in vmcnt(0),
+// i.e. no prefetch at all); KBC = 0 is the generic run-time fallback.  A job is either active with all NT
+// tiles live (ALL) or carries a run-time live count nt.
+template <int NT, int G, int KBC, bool ALL>
 struct WaveGemm {
   const f32x4* bp[NT];
-  f32x4 cur[G][NT];
+  f32x4 ring[G][NT];
   float bias[NT];      // bias of this lane's output column n = tile*16 + (lane & 15), fetched with the weights
   int tile[NT];
   int KB, nt;
 
   __device__ __forceinline__ void prefetch(const f32x4* __restrict__ pw, int KB_, int first_tile, int tile_stride,
                                            int n_tiles, int lane, const float* __restrict__ bias_vec = nullptr) {
-    KB = KB_;
+    KB = KBC ? KBC : KB_;
     nt = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       tile[t] = first_tile + t * tile_stride;
       if (first_tile >= 0 && tile[t] < n_tiles) nt = t + 1;
     }
+    if (ALL && nt) nt = NT;
+    if (nt == 0) return;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bp[t] = pw + (int64_t)(t < nt ? tile[t] : 0) * KB * 64 + lane;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bias[t] = (bias_vec && t < nt) ? bias_vec[tile[t] * 16 + (lane & 15)] : 0.f;
+    for (int t = 0; t < NT; ++t) {
+      const int tl = (ALL || t < nt) ? tile[t] : tile[0];        // dead tiles alias a live one: loads stay valid
+      bp[t] = pw + (int64_t)tl * KB * 64 + lane;
+      bias[t] = bias_vec ? bias_vec[tl * 16 + (lane & 15)] : 0.f;
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (g < KB && t < nt) cur[g][t] = bp[t][g * 64];
+      for (int t = 0; t < NT; ++t) ring[g][t] = bp[t][(g < KB ? g : KB - 1) * 64];
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // a_row: LDS pointer to this lane's A row (row l&15) already offset by 4*(l>>4) floats.
   template <typename F>
   __device__ __forceinline__ void run(const float* a_row, int lane, F epilogue) {
     if (nt == 0) return;
-    f32x4 acc[NT], nxt[G][NT];
+    f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kb0 = 0; kb0 < KB; kb0 += G) {
+    if constexpr (KBC > 0) {
 #pragma unroll
-      for (int g = 0; g < G; ++g)
+      for (int kb = 0; kb < KBC; ++kb) {
+        const int g = kb % G;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(a_row + kb * 16);
+        f32x4 b[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          if (kb0 + G + g < KB && t < nt) nxt[g][t] = bp[t][(kb0 + G + g) * 64];
+        for (int t = 0; t < NT; ++t) b[t] = ring[g][t];
+        if (kb + G < KBC) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (kb0 + g < KB) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(a_row + (kb0 + g) * 16);
+          for (int t = 0; t < NT; ++t) ring[g][t] = bp[t][(kb + G) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the refill ahead of the MFMAs (the scheduler sinks it otherwise)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-              if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], cur[g][t][s], acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
+      }
+    } else {
+      for (int kb0 = 0; kb0 < KB; kb0 += G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int kb = kb0 + g;
+          if (kb < KB) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(a_row + kb * 16);
+            f32x4 b[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[t] = ring[g][t];
+            const int kn = kb + G < KB ? kb + G : KB - 1;          // clamped: no branch around the loads
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ring[g][t] = bp[t][kn * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
           }
         }
       }
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) cur[g][t] = nxt[g][t];
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-      if (t < nt) {
-        const float b = bias[t];
-        for_acc(acc[t], tile[t], lane, [&](int m, int n, float v) { epilogue(m, n, v + b); });
+      if (ALL || t < nt) {
+        const float bb = bias[t];
+        for_acc(acc[t], tile[t], lane, [&](int m, int n, float v) { epilogue(m, n, v + bb); });
       }
   }
 };
@@ -342,8 +366,10 @@ __device__ __forceinline__ float half_sum(float v) {
 
 // KT = compile-time neighbour count (10, the reference's default n_degree: every per-slot predicate and
 // the second-chunk code fold away) or 0 = run-time K <= ORCA_MAX_K.
-template <int KT>
-__global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restrict__ blob, int d_e,
+// DE = compile-time edge width (172, the Wikipedia / Reddit / benchmark width: every k-block count of the
+// projection chains becomes a constant) or 0 = run-time d_e <= ORCA_MAX_DE.
+template <int KT, int DE>
+__global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restrict__ blob, int d_e_rt,
                                                           orca_tgat_inputs in, int64_t Q, int K_rt,
                                                           float* __restrict__ out, float* __restrict__ out_w,
                                                           long long* __restrict__ phase_clock) {
@@ -357,7 +383,11 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   };
   stamp();
   const int K = KT ? KT : K_rt;
-  const Blob L = blob_layout(d_e);
+  const int d_e = DE ? DE : d_e_rt;
+  constexpr Blob LC = blob_layout(DE ? DE : 1);   // compile-time layout when DE is fixed
+  const Blob L = DE ? LC : blob_layout(d_e);
+  constexpr int KBK = DE ? LC.KBk : 0;           // k-blocks of the value map (0 = run time)
+  constexpr bool FOLD_ALL = DE && LC.NTk == 24;  // every (head, slot) wave of P2 owns exactly 3 live tiles
   const int kdim = L.kdim;
   const int KPS = L.KP + 4;                       // row stride of the q~ / x-bar buffer
   float* bufQ = lds;                              // [TQ][ASTR]  query vector, later o (concat heads)
@@ -378,7 +408,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   // LayerNorm affine parameters (P8) and the q-projection weights depend on nothing: fetch them right away
   const float ln_ga = blob[L.ln_w + lane], ln_ba = blob[L.ln_b + lane];
   const float ln_gb = blob[c1 < D ? L.ln_w + c1 : L.ln_w], ln_bb = blob[c1 < D ? L.ln_b + c1 : L.ln_b];
-  WaveGemm<1, 6> g1;
+  WaveGemm<1, 7, 13, true> g1;
   g1.prefetch(blob4 + L.pw_q / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_q);
 
   // ---- T0: this wave's query: neighbour slots, source row, L2 touches, time encodings ------------
@@ -456,7 +486,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   // ---- P2: q~_h = Wk_h^T (0.1 q_h)  (column kdim carries (0.1 q_h).bk_h): wave (h = w&1, slot = w>>1)
   //      owns tiles slot, slot+8, slot+16 of head h -> bufT
   const int h2 = wave & 1;
-  WaveGemm<3, 2> g2;
+  WaveGemm<3, 3, 7, FOLD_ALL> g2;
   g2.prefetch(blob4 + (L.pw_kt + (int64_t)h2 * pw_floats(kdim + 1, D)) / 4, NT100, wave >> 1, NW / 2, L.NTk, lane);
   __syncthreads();
   stamp();
@@ -582,7 +612,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   }
   // ---- P4: o_h = Wv_h x-bar_h + bv_h  ->  bufQ[:, h*100 + d]: wave -> (head, tile) of 2 x 7 ----------
   const int h4 = wave / NT100, t4 = wave - h4 * NT100;
-  WaveGemm<1, 6> g4;
+  WaveGemm<1, 8, KBK, true> g4;
   g4.prefetch(blob4 + (L.pw_v + (int64_t)(h4 & 1) * NT100 * L.KBk * 256) / 4, L.KBk, wave < 2 * NT100 ? t4 : -1, 1, NT100, lane,
               blob + L.b_vp + (h4 & 1) * 112);
   __syncthreads();
@@ -593,7 +623,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     });
   }
   // ---- P5: attn = Wo o + bo, zeroed for all-padded neighbourhoods (:52) -> bufM[:, 0:200] -------
-  WaveGemm<1, 6> g5;
+  WaveGemm<1, 7, 13, true> g5;
   g5.prefetch(blob4 + L.pw_o / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_o);
   __syncthreads();
   stamp();
@@ -603,7 +633,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     });
   }
   // ---- P6: h1 = relu(fc1 [attn | src] + b1) -> bufP[:, 0:112] -----------------------------------
-  WaveGemm<1, 6> g6;
+  WaveGemm<1, 7, 19, true> g6;
   g6.prefetch(blob4 + L.pw_1 / 4, pw_tiles(3 * D), wave < NT100 ? wave : -1, NW, NT100, lane, blob + L.b_1);
   __syncthreads();
   stamp();
@@ -612,7 +642,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
            [&](int m, int n, float v) { bufP[m * ASTR + n] = (n < D) ? fmaxf(v, 0.0f) : 0.0f; });
   }
   // ---- P7: y = fc2 h1 + b2 -> bufQ[:, 0:100] -----------------------------------------------------
-  WaveGemm<1, 7> g7;
+  WaveGemm<1, 7, 7, true> g7;
   g7.prefetch(blob4 + L.pw_2 / 4, NT100, wave < NT100 ? wave : -1, NW, NT100, lane, blob + L.b_2);
   __syncthreads();
   stamp();
@@ -667,17 +697,21 @@ ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_input
   size_t lds_bytes = (size_t)(2 * TQ * ASTR + TQ * MSTR + TQ * 2 * (L.KP + 4)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    const int lim = 160 * 1024 - 256;
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<10, 172>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<10, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     attr_set = true;
   }
   ORCA_REQUIRE(lds_bytes <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds_bytes);
-  if (K == 10)
-    k_tgat_forward<10><<<(unsigned)ceil_div64(Q, TQ), NW * 64, lds_bytes, (hipStream_t)stream>>>(blob, d_e, *in, Q, K, out,
-                                                                                                 out_weights, g_phase_clock);
+  const unsigned grid = (unsigned)ceil_div64(Q, TQ);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 10 && d_e == 172)
+    k_tgat_forward<10, 172><<<grid, NW * 64, lds_bytes, st>>>(blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
+  else if (K == 10)
+    k_tgat_forward<10, 0><<<grid, NW * 64, lds_bytes, st>>>(blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
   else
-    k_tgat_forward<0><<<(unsigned)ceil_div64(Q, TQ), NW * 64, lds_bytes, (hipStream_t)stream>>>(blob, d_e, *in, Q, K, out,
-                                                                                                out_weights, g_phase_clock);
+    k_tgat_forward<0, 0><<<grid, NW * 64, lds_bytes, st>>>(blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
