@@ -142,6 +142,8 @@ int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_inputs* in, in
 /* Profiling aid (no counterpart in the reference): when buf != NULL (device int64 [ceil(Q/16) * 16]) later
  * orca_tgat_forward launches write the 100 MHz real-time counter at each internal phase boundary. */
 int orca_debug_tgat_phase_clock(void* buf);
+/* same for the streaming GRU kernel: device int64 [ceil(n/64)*7 * 4 waves * 4 stamps] */
+int orca_debug_gru_phase_clock(void* buf);
 
 /* ---- GRU memory updater: modules/memory_updater.py:25-86 --------------------------------- */
 

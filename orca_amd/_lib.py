@@ -59,6 +59,7 @@ SIGNATURES = {
     "orca_tgat_pack": (i32, [i32] + [vp] * 14),
     "orca_tgat_forward": (i32, [vp, i32, ctypes.POINTER(TgatInputs), i64, i32, vp, vp, vp]),
     "orca_debug_tgat_phase_clock": (i32, [vp]),
+    "orca_debug_gru_phase_clock": (i32, [vp]),
     "orca_gru_blob_floats": (i64, [i32]),
     "orca_gru_pack": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "orca_gru_update": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp]),

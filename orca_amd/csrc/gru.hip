@@ -7,6 +7,8 @@
 // math (sigmoid, tanh, blend with the old memory) happens in the accumulator registers and the new
 // memory row is written straight to its table: in place (persist) or into the overlay table that
 // replaces the reference's per-batch full-table clone (memory_updater.py:72,76).
+#include <type_traits>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -178,128 +180,152 @@ __global__ __launch_bounds__(KS2 * NWG * 64) void k_gru_rows(const float* __rest
 }
 
 
-constexpr int RW = 4;             // 16-row sub-tiles per workgroup (they share one hidden-unit tile)
-constexpr int KH = 2;             // each sub-tile's reduction is walked by KH waves, half each
-constexpr int GS = 4;             // steps of operands fetched ahead (ring of registers)
+constexpr int RW = 4;             // 16-row sub-tiles (waves) per workgroup; they share one hidden-unit tile
+constexpr int GS = 5;             // steps of operands fetched ahead (ring of registers)
 
-// Out-of-place GRU: workgroup = (64 rows) x (one 16-wide tile of hidden units), 8 waves: wave (w, kh) owns
-// rows 16w..16w+15 and half kh of the reduction.  No LDS staging of operands: the A fragments (16 B per lane
-// straight from the [message | memory] rows in HBM/L2) and the B fragments (packed weights, shared by the
-// waves through L1) stream GS steps ahead of the MFMAs -- the kernel is bound by the latency of those
-// fetches, so what counts is how many are in flight.  Halves are summed through LDS (one barrier).
-// 7 workgroups per row tile give every CU work at the few-thousand-row counts of a batch, and 64-row tiles
-// keep the weight traffic from L2 at 111 KB per workgroup.  A row is read by 7 workgroups and written by
-// each of them: `out` must not alias `h` (orca_gru_update routes the in-place case to k_gru_rows).
-__global__ __launch_bounds__(RW * KH * 64) void k_gru_stream(const float* __restrict__ blob, int msg_dim,
+// Out-of-place GRU: workgroup = (64 rows) x (one 16-wide tile of hidden units); wave w owns rows 16w..16w+15
+// and walks the whole reduction for them.  No LDS, no barrier: the A fragments (16 B per lane straight from
+// the [message | memory] rows in HBM/L2) and the B fragments (packed weights, shared by the 4 waves through
+// L1) stream GS steps ahead of the MFMAs in a register ring.  MSG (the message width) is a template
+// parameter so that the 37-step chain is fully unrolled and BRANCH-FREE -- loads are clamped and their
+// results fixed up when consumed, never skipped -- because the compiler's s_waitcnt placement collapses to
+// vmcnt(0) at any control flow (and at any use right after a load), which serialises every step on a full
+// memory round trip.  7 workgroups per row tile give every CU work at the few-thousand-row counts of a
+// batch; 64-row tiles keep the weight traffic from L2 at 111 KB per workgroup.  A row is read by 7
+// workgroups and written by each of them: `out` must not alias `h` (orca_gru_update routes the in-place
+// case to k_gru_rows).
+template <int MSG>
+__global__ __launch_bounds__(RW * 64) void k_gru_stream(const float* __restrict__ blob,
                                                         const int32_t* __restrict__ ids, int64_t n_max,
                                                         const int32_t* __restrict__ n_dev,
                                                         const float* __restrict__ x, const float* __restrict__ h,
                                                         float* __restrict__ out, float* last_update,
-                                                        const float* __restrict__ msg_ts) {
-  const GBlob L = gru_layout(msg_dim);
-  __shared__ f32x4 s_part[RW][4][64];
+                                                        const float* __restrict__ msg_ts,
+                                                        long long* __restrict__ phase_clock) {
+  const long long clk0 = phase_clock ? wall_clock64() : 0;
+  static_assert(MSG % 4 == 0, "a float4 A fragment must not straddle the end of a row");
+  constexpr int KBx = (MSG + 15) / 16, KBh = (D + 15) / 16, NS = KBx + KBh;
+  constexpr int64_t PW_X = 0, PW_H = 3 * (int64_t)NWG * KBx * 256, BIAS = PW_H + 3 * (int64_t)NWG * KBh * 256;
   const int t = blockIdx.x % NWG;                       // hidden-unit tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % RW, kh = (tid >> 6) / RW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t r0 = ((int64_t)(blockIdx.x / NWG) * RW + wave) * 16;
   const f32x4* blob4 = reinterpret_cast<const f32x4*>(blob);
-  const f32x4* px = blob4 + L.pw_x / 4;
-  const f32x4* ph = blob4 + L.pw_h / 4;
-  const int n_all = L.KBx + L.KBh;
-  const int s_beg = kh * ((n_all + KH - 1) / KH);
-  const int n_steps = min(n_all, s_beg + (n_all + KH - 1) / KH);   // this wave walks steps [s_beg, n_steps)
-  auto bload = [&](int s, f32x4 (&b)[3]) {
-    const bool xs = s < L.KBx;
-    const f32x4* base = xs ? px : ph;
-    const int kb = xs ? s : s - L.KBx, KBm = xs ? L.KBx : L.KBh;
-#pragma unroll
-    for (int g = 0; g < 3; ++g) b[g] = base[((int64_t)(g * NWG + t) * KBm + kb) * 64 + lane];
-  };
-  // weights, biases and the (possibly stale beyond *n_dev, but always valid) ids depend on nothing: fetch
-  // them before the row count is known
+  const f32x4* px = blob4 + PW_X / 4 + (int64_t)t * KBx * 64 + lane;      // gate g at + g*NWG*KBx*64
+  const f32x4* ph = blob4 + PW_H / 4 + (int64_t)t * KBh * 64 + lane;
+  const int kq = 4 * (lane >> 4);
+  // ---- everything that depends on nothing: first GS steps of weights, biases, ids (valid memory up to n_max) --
   f32x4 bq[GS][3], aq[GS];
 #pragma unroll
-  for (int g = 0; g < GS; ++g)
-    if (s_beg + g < n_steps) bload(s_beg + g, bq[g]);
-  const int64_t ra = r0 + (lane & 15);
-  const int64_t id_raw = ra < n_max ? (ids ? (int64_t)ids[ra] : ra) : -1;
-  const float* bias = blob + L.bias;
+  for (int g = 0; g < GS; ++g) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bq[g][k] = px[((int64_t)k * NWG * KBx + g) * 64];   // GS <= KBx: message steps
+  }
+  const float* bias = blob + BIAS;
   const int u = t * 16 + (lane & 15);
   const float br = bias[u], bz = bias[112 + u], bi = bias[224 + u], bh = bias[336 + u];   // padded to 112: in range
-
+  const int64_t last = n_max - 1;
+  const int64_t ra = r0 + (lane & 15);
+  const int64_t id_a_raw = ids[ra < last ? ra : last];
+  int64_t id_o_raw[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t ro = r0 + kq + r;
+    id_o_raw[r] = ids[ro < last ? ro : last];
+  }
   int64_t n = n_max;
   if (n_dev) {
-    int64_t nd = *n_dev;
+    const int64_t nd = *n_dev;
     n = nd < n ? nd : n;
   }
-  if ((int64_t)(blockIdx.x / NWG) * RW * 16 >= n) return;   // workgroup-uniform (there is a barrier below)
-  // lane l feeds MFMA row l&15: its node id, and (epilogue) rows 4*(l>>4)+r
-  const int64_t id_a = ra < n ? id_raw : -1;
-  const float* xrow = x + (id_a < 0 ? 0 : id_a) * msg_dim + 4 * (lane >> 4);
-  const float* hrow = h + (id_a < 0 ? 0 : id_a) * D + 4 * (lane >> 4);
-  // A fragment of step s: 4 consecutive floats of this lane's row, zero beyond the row / for padding rows
-  auto aload = [&](int s) -> f32x4 {
-    const bool xs = s < L.KBx;
-    const int c = (xs ? s : s - L.KBx) * 16 + 4 * (lane >> 4);
-    const int width = xs ? msg_dim : D;                  // both are multiples of 4: a float4 is in or out
-    if (id_a < 0 || c >= width) return f32x4{0.f, 0.f, 0.f, 0.f};
-    return *reinterpret_cast<const f32x4*>((xs ? xrow : hrow) + (xs ? s : s - L.KBx) * 16);
+  if (r0 >= n) return;                                   // wave-uniform; there is no barrier in this kernel
+  // lane l feeds MFMA row l&15 (node id_a); in the epilogue it owns rows 4*(l>>4)+r (nodes id_o[r])
+  const bool live_a = ra < n;
+  const float* xrow = x + (live_a ? id_a_raw : 0) * MSG;
+  const float* hrow = h + (live_a ? id_a_raw : 0) * D;
+  // A fragment of step s (compile-time): 4 consecutive floats of this lane's row.  The load is clamped into
+  // the row and NOT predicated; columns beyond the row are zeroed when the fragment is consumed, and rows
+  // beyond n need no zeroing at all: an MFMA output row depends on its own A row only and those rows are
+  // never stored.
+  auto aload = [&](auto S) -> f32x4 {
+    constexpr int s = decltype(S)::value;
+    constexpr bool xs = s < KBx;
+    constexpr int kb = xs ? s : s - KBx, width = xs ? MSG : D;
+    constexpr bool full = kb * 16 + 16 <= width;       // the whole k-block lies inside the row
+    const int c = kb * 16 + kq;
+    const float* row = xs ? xrow : hrow;
+    return *reinterpret_cast<const f32x4*>(row + (full ? c : (c < width ? c : 0)));
   };
+  auto afix = [&](auto S, f32x4 v) -> f32x4 {
+    constexpr int s = decltype(S)::value;
+    constexpr bool xs = s < KBx;
+    constexpr int kb = xs ? s : s - KBx, width = xs ? MSG : D;
+    if constexpr (kb * 16 + 16 <= width) return v;
+    const bool ok = kb * 16 + kq < width;
+    return f32x4{ok ? v[0] : 0.f, ok ? v[1] : 0.f, ok ? v[2] : 0.f, ok ? v[3] : 0.f};
+  };
+  auto bload = [&](auto S, f32x4 (&b)[3]) {
+    constexpr int s = decltype(S)::value;
+    constexpr bool xs = s < KBx;
+    constexpr int kb = xs ? s : s - KBx, KBm = xs ? KBx : KBh;
+    const f32x4* base = xs ? px : ph;
 #pragma unroll
-  for (int g = 0; g < GS; ++g)
-    if (s_beg + g < n_steps) aq[g] = aload(s_beg + g);
-  // epilogue operands: ids of the 4 output rows of this lane and their previous memory
-  int64_t id_o[4];
+    for (int k = 0; k < 3; ++k) b[k] = base[((int64_t)k * NWG * KBm + kb) * 64];
+  };
+  auto ring_fill = [&](auto S) {      // operands of step S into its ring slot
+    constexpr int s = decltype(S)::value;
+    if constexpr (s < NS) {
+      aq[s % GS] = aload(S);
+      if constexpr (s >= GS) bload(S, bq[s % GS]);     // the first GS steps' weights are already on their way
+    }
+  };
   float hp[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int64_t ro = r0 + 4 * (lane >> 4) + r;
-    id_o[r] = ro < n ? (ids ? (int64_t)ids[ro] : ro) : -1;
+    const bool ok = r0 + kq + r < n && u < D;
+    hp[r] = h[(ok ? id_o_raw[r] : 0) * D + (u < D ? u : 0)];
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) hp[r] = (id_o[r] >= 0 && u < D) ? h[id_o[r] * D + u] : 0.f;
+  // prologue: A of the first GS steps
+  [&]<int... I>(std::integer_sequence<int, I...>) { (ring_fill(std::integral_constant<int, I>{}), ...); }
+  (std::make_integer_sequence<int, GS>{});
+  __builtin_amdgcn_sched_barrier(0);
+  const long long clk1 = phase_clock ? wall_clock64() : 0;
 
   f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, ai = ar, ah = ar;
-  for (int s0 = s_beg; s0 < n_steps; s0 += GS) {
+  auto step = [&](auto S) {
+    constexpr int s = decltype(S)::value;
+    const f32x4 a = afix(S, aq[s % GS]);
+    const f32x4 b0 = bq[s % GS][0], b1 = bq[s % GS][1], b2 = bq[s % GS][2];
+    ring_fill(std::integral_constant<int, s + GS>{});
+    __builtin_amdgcn_sched_barrier(0);   // keep the refill ahead of this step's MFMAs
 #pragma unroll
-    for (int g = 0; g < GS; ++g) {
-      const int s = s0 + g;
-      if (s < n_steps) {
-        const f32x4 a = aq[g];
-        f32x4 b[3] = {bq[g][0], bq[g][1], bq[g][2]};
-        if (s + GS < n_steps) {          // refill this ring slot with the operands of step s + GS
-          aq[g] = aload(s + GS);
-          bload(s + GS, bq[g]);
-        }
-        const bool xs = s < L.KBx;       // wave-uniform
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[0][k], ar, 0, 0, 0);
-          az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[1][k], az, 0, 0, 0);
-          if (xs) ai = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[2][k], ai, 0, 0, 0);
-          else    ah = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[2][k], ah, 0, 0, 0);
-        }
-      }
+    for (int k = 0; k < 4; ++k) {
+      ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b0[k], ar, 0, 0, 0);
+      az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b1[k], az, 0, 0, 0);
+      if constexpr (s < KBx) ai = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b2[k], ai, 0, 0, 0);
+      else                   ah = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b2[k], ah, 0, 0, 0);
     }
-  }
-  // the second half hands its partial pre-activations to the first
-  if (kh == 1) {
-    s_part[wave][0][lane] = ar; s_part[wave][1][lane] = az; s_part[wave][2][lane] = ai; s_part[wave][3][lane] = ah;
-  }
-  __syncthreads();
-  if (kh != 0) return;
-  ar += s_part[wave][0][lane]; az += s_part[wave][1][lane]; ai += s_part[wave][2][lane]; ah += s_part[wave][3][lane];
+  };
+  [&]<int... I>(std::integer_sequence<int, I...>) { (step(std::integral_constant<int, I>{}), ...); }
+  (std::make_integer_sequence<int, NS>{});
+  const long long clk2 = phase_clock ? wall_clock64() : 0;
+
   // fused gate epilogue (torch.nn.GRUCell, gate order r, z, n)
   if (u < D) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (id_o[r] < 0) continue;
-      const float rr = sigmoidf_(ar[r] + br);
-      const float zz = sigmoidf_(az[r] + bz);
-      const float nn = tanhf(ai[r] + bi + rr * (ah[r] + bh));
-      out[id_o[r] * D + u] = (1.0f - zz) * nn + zz * hp[r];
+      if (r0 + kq + r < n) {
+        const float rr = sigmoidf_(ar[r] + br);
+        const float zz = sigmoidf_(az[r] + bz);
+        const float nn = tanhf(ai[r] + bi + rr * (ah[r] + bh));
+        out[id_o_raw[r] * D + u] = (1.0f - zz) * nn + zz * hp[r];
+      }
     }
   }
-  if (t == 0 && last_update && lane < 16 && id_a >= 0) last_update[id_a] = msg_ts[id_a];
+  if (t == 0 && last_update && lane < 16 && live_a) last_update[id_a_raw] = msg_ts[id_a_raw];
+  if (phase_clock && lane == 0) {
+    long long* pc = phase_clock + ((int64_t)blockIdx.x * RW + wave) * 4;
+    pc[0] = clk0; pc[1] = clk1; pc[2] = clk2; pc[3] = wall_clock64();
+  }
 }
 
 }  // namespace
@@ -331,12 +357,26 @@ ORCA_API int orca_gru_pack(int msg_dim, const float* w_ih, const float* w_hh, co
   return ORCA_OK;
 }
 
-static int gru_launch_stream(const float* blob, int msg_dim, const int32_t* ids, int64_t n, const int32_t* n_dev,
-                             const float* x, const float* h, float* out, float* last_update, const float* msg_ts,
-                             hipStream_t stream) {
-  ORCA_REQUIRE(msg_dim % 4 == 0, "orca_gru_update: the streaming kernel needs msg_dim %% 4 == 0");
-  k_gru_stream<<<(unsigned)(ceil_div64(n, 16 * RW) * NWG), RW * KH * 64, 0, stream>>>(blob, msg_dim, ids, n, n_dev, x, h, out,
-                                                                              last_update, msg_ts);
+static long long* g_gru_clock = nullptr;
+// Profiling aid: buf = device int64 [n_workgroups * 4 waves * 4] (or NULL); the streaming GRU kernel stamps the
+// 100 MHz counter at entry, after locating its rows, after the MFMA chain and at exit.
+ORCA_API int orca_debug_gru_phase_clock(void* buf) {
+  g_gru_clock = (long long*)buf;
+  return ORCA_OK;
+}
+
+static long long* g_gru_clock = nullptr;
+// Profiling aid: buf = device int64 [n_workgroups * 4 waves * 4] (or NULL); the streaming GRU kernel stamps the
+// 100 MHz counter at entry, after issuing its first loads, after the MFMA chain and at exit.
+ORCA_API int orca_debug_gru_phase_clock(void* buf) {
+  g_gru_clock = (long long*)buf;
+  return ORCA_OK;
+}
+
+static int gru_launch_stream(const float* blob, const int32_t* ids, int64_t n, const int32_t* n_dev, const float* x,
+                             const float* h, float* out, float* last_update, const float* msg_ts, hipStream_t stream) {
+  k_gru_stream<3 * D + 172><<<(unsigned)(ceil_div64(n, 16 * RW) * NWG), RW * 64, 0, stream>>>(blob, ids, n, n_dev, x, h, out,
+                                                                                          last_update, msg_ts, g_gru_clock);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -367,11 +407,11 @@ ORCA_API int orca_gru_update(const float* blob, int msg_dim, const int32_t* ids,
   ORCA_REQUIRE(!last_update || msg_ts, "orca_gru_update: last_update without msg_ts");
   // in place (out aliases h): a row must be read and written by one workgroup
   if (out == h) return gru_launch_rows(blob, msg_dim, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
-  // out of place: (64-row tile) x (hidden tile) workgroups streaming their operands; rows narrower than a
-  // multiple of 4 floats (the zero-feature datasets: msg_dim 301) take the row kernel as well
-  if (msg_dim % 4 != 0)
+  // out of place with an id list at the common message width (d_e = 172): (64-row tile) x (hidden tile)
+  // workgroups streaming their operands; anything else (other widths, ids == NULL) takes the row kernel
+  if (msg_dim != 3 * D + 172 || !ids)
     return gru_launch_rows(blob, msg_dim, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
-  return gru_launch_stream(blob, msg_dim, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
+  return gru_launch_stream(blob, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
 }
 
 // out_table[id] = src_table[id] (+ last_update[id] = msg_ts[id]) for the ids of a device-counted work-list:

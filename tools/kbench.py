@@ -100,6 +100,20 @@ def main():
   for n in (2730, 8192, 32768):
     ids = torch.randperm(N, device=dev)[:n].to(torch.int32)
     res[f"gru_{n}rows"] = timeit(lambda: ops.gru_update(gblob, msg_dim, ids, n, None, messages, memory, overlay))
+  # phase breakdown of the streaming GRU kernel
+  n = 2730
+  ids = torch.randperm(N, device=dev)[:n].to(torch.int32)
+  nw = ((n + 63) // 64) * 7 * 4
+  gclk = torch.zeros(nw * 4, dtype=torch.int64, device=dev)
+  _lib.load().orca_debug_gru_phase_clock(gclk.data_ptr())
+  ops.gru_update(gblob, msg_dim, ids, n, None, messages, memory, overlay)
+  torch.cuda.synchronize()
+  _lib.load().orca_debug_gru_phase_clock(None)
+  g = gclk.view(nw, 4).cpu().double()
+  g = g[g[:, 3] > 0]
+  print("gru waves", g.shape[0], "phases us (median): locate rows", float(((g[:, 1] - g[:, 0]) / 100).median()), "chain",
+        float(((g[:, 2] - g[:, 1]) / 100).median()), "epilogue", float(((g[:, 3] - g[:, 2]) / 100).median()), "| span",
+        float((g[:, 3].max() - g[:, 0].min()) / 100), "start skew", float((g[:, 0].max() - g[:, 0].min()) / 100))
   slot = torch.zeros(N + 1, dtype=torch.int64, device=dev)
   se = [1]
 
