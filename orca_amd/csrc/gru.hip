@@ -359,14 +359,6 @@ ORCA_API int orca_gru_pack(int msg_dim, const float* w_ih, const float* w_hh, co
 
 static long long* g_gru_clock = nullptr;
 // Profiling aid: buf = device int64 [n_workgroups * 4 waves * 4] (or NULL); the streaming GRU kernel stamps the
-// 100 MHz counter at entry, after locating its rows, after the MFMA chain and at exit.
-ORCA_API int orca_debug_gru_phase_clock(void* buf) {
-  g_gru_clock = (long long*)buf;
-  return ORCA_OK;
-}
-
-static long long* g_gru_clock = nullptr;
-// Profiling aid: buf = device int64 [n_workgroups * 4 waves * 4] (or NULL); the streaming GRU kernel stamps the
 // 100 MHz counter at entry, after issuing its first loads, after the MFMA chain and at exit.
 ORCA_API int orca_debug_gru_phase_clock(void* buf) {
   g_gru_clock = (long long*)buf;
