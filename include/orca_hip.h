@@ -166,6 +166,12 @@ int orca_gru_update(const float* blob, int msg_dim, const int32_t* ids, int64_t 
 int orca_commit_rows(const int32_t* ids, int64_t n, const int32_t* n_dev, const float* src_table,
                      float* dst_table, float* last_update, const float* msg_ts, void* stream);
 
+/* For every position p < n with pending[ids[p]]: memory[id] = overlay[id], last_update[id] = msg_ts[id]
+ * (duplicates copy the same values).  modules/memory_updater.py:25-39 when the overlay already holds
+ * GRU(message, memory) of those ids; pending flags are not cleared (see orca_engine_finish). */
+int orca_persist_overlay(const int64_t* ids, int64_t n, const uint8_t* pending, const float* overlay,
+                         float* memory, float* last_update, const float* msg_ts, int64_t n_nodes, void* stream);
+
 /* ---- node-id bookkeeping that the reference does with NumPy on the host ------------------- */
 
 /* Writes to worklist every distinct id of the concatenation of ids32 (n32 int32 values, e.g. the

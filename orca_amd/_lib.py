@@ -64,6 +64,7 @@ SIGNATURES = {
     "orca_gru_pack": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "orca_gru_update": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     "orca_commit_rows": (i32, [vp, i64, vp, vp, vp, vp, vp, vp]),
+    "orca_persist_overlay": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp]),
     "orca_worklist_build": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, vp]),
     "orca_fill_i32": (i32, [vp, i64, i32, vp]),
     "orca_fill_u8": (i32, [vp, i64, u8, vp]),

@@ -201,14 +201,18 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
   ORCA_REQUIRE(src && dst && eidx && ts, "orca_engine_finish: null batch array");
   const int msg_dim = 3 * ORCA_D + d.d_e;
   auto persist = [&]() -> int {   // memory_updater.update_memory (:25-39) + clear_messages (memory.py:49-50)
+    // When this rank's begin() covered the whole batch in train order, the overlay already holds
+    // GRU(message, memory) of every pending positive (same messages, same memory: positives are roots of the
+    // batch): the rows are committed by one kernel, and the flags need no clearing because the message store
+    // that follows sets them for exactly these ids.
+    if (e->overlay_covers_batch)
+      return orca_persist_overlay(d.nodes, 2 * bs, d.pending, d.overlay, d.memory, d.last_update, d.msg_ts, d.n_nodes,
+                                  stream_);
     const int64_t bound = 2 * bs < d.n_nodes ? 2 * bs : d.n_nodes;
     int rc = orca_worklist_build(nullptr, 0, d.nodes, 2 * bs, d.pending, d.slot, take_epochs(e, 2 * bs), d.n_nodes,
                                  d.worklist, d.count, stream_);
     if (rc != ORCA_OK) return rc;
-    // GRU(message, memory) of the pending positives goes to the overlay table, then the rows are committed.
-    // When this rank's begin() covered the whole batch in train order, the overlay already holds exactly
-    // these rows (same messages, same memory: positives are roots of the batch) and the GRU is not repeated.
-    if (!e->overlay_covers_batch) {
+    {   // GRU(message, memory) of the pending positives goes to the overlay table, then the rows are committed
       Timed t(e, ORCA_PROF_GRU, (hipStream_t)stream_);
       rc = orca_gru_update(d.gru_blob, msg_dim, d.worklist, bound, d.count, d.messages, d.memory, d.overlay, nullptr,
                            nullptr, stream_);

@@ -33,8 +33,9 @@ __device__ __forceinline__ int64_t worklist_id(const int32_t* ids32, int64_t n32
 }
 __global__ void k_worklist_claim(const int32_t* __restrict__ ids32, int64_t n32, const int64_t* __restrict__ ids64,
                                  int64_t n64, const uint8_t* __restrict__ flags, int64_t* slot, int64_t epoch,
-                                 int64_t n_nodes) {
+                                 int64_t n_nodes, int32_t* count) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *count = 0;            // the append pass (next kernel on the stream) counts from zero
   if (i >= n32 + n64) return;
   int64_t id = worklist_id(ids32, n32, ids64, i);
   if (id < 0 || id >= n_nodes || (flags && !flags[id])) return;
@@ -145,6 +146,24 @@ __global__ __launch_bounds__(256) void k_message_store(const int64_t* __restrict
   }
 }
 
+// memory_updater.update_memory (:25-39) when GRU(message, memory) of every pending id already sits in the
+// overlay: one wave per position of the id list copies the row and the message timestamp.  Duplicate ids
+// copy the same values (benign).  The pending flags are left alone: the caller stores new messages for the
+// same ids next, which sets them again (tgn_model.py:127-141).
+__global__ __launch_bounds__(256) void k_persist_overlay(const int64_t* __restrict__ ids, int64_t n,
+                                                         const uint8_t* __restrict__ pending,
+                                                         const float* __restrict__ overlay, float* __restrict__ memory,
+                                                         float* __restrict__ last_update,
+                                                         const float* __restrict__ msg_ts, int64_t n_nodes) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const int64_t id = ids[p];
+  if (id < 0 || id >= n_nodes || !pending[id]) return;
+  for (int c = lane; c < D; c += 64) memory[id * D + c] = overlay[id * D + c];
+  if (lane == 0) last_update[id] = msg_ts[id];
+}
+
 __global__ __launch_bounds__(256) void k_push_rows(float* __restrict__ emb, const float* __restrict__ x,
                                                    const int64_t* __restrict__ ids, int64_t n,
                                                    const int64_t* __restrict__ slot, int64_t epoch, int64_t n_nodes) {
@@ -209,10 +228,12 @@ ORCA_API int orca_worklist_build(const int32_t* ids32, int64_t n32, const int64_
                                  int32_t* worklist, int32_t* count, void* stream) {
   ORCA_REQUIRE(n32 >= 0 && n64 >= 0 && slot && worklist && count && n_nodes > 0, "orca_worklist_build: bad arguments");
   ORCA_REQUIRE((n32 == 0 || ids32) && (n64 == 0 || ids64), "orca_worklist_build: null id array");
-  ORCA_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream));
-  if (n32 + n64 == 0) return ORCA_OK;
+  if (n32 + n64 == 0) {
+    ORCA_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream));
+    return ORCA_OK;
+  }
   k_worklist_claim<<<blocks(n32 + n64, 256), 256, 0, (hipStream_t)stream>>>(ids32, n32, ids64, n64, flags, slot, epoch,
-                                                                            n_nodes);
+                                                                            n_nodes, count);
   k_worklist_append<<<blocks(n32 + n64, 256), 256, 0, (hipStream_t)stream>>>(ids32, n32, ids64, n64, flags, slot, epoch,
                                                                              n_nodes, worklist, count);
   ORCA_LAUNCH_CHECK();
@@ -262,6 +283,18 @@ ORCA_API int orca_message_store(const int64_t* src, const int64_t* dst, const in
   k_message_store<<<blocks(2 * bs, 4), 256, 0, (hipStream_t)stream>>>(src, dst, eidx, t, bs, memory, last_update,
                                                                       edge_feats, d_e, time_w, time_b, slot, epoch,
                                                                       n_nodes, messages, msg_ts, pending);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_persist_overlay(const int64_t* ids, int64_t n, const uint8_t* pending, const float* overlay,
+                                  float* memory, float* last_update, const float* msg_ts, int64_t n_nodes,
+                                  void* stream) {
+  ORCA_REQUIRE(n >= 0 && n_nodes > 0, "orca_persist_overlay: bad sizes");
+  if (n == 0) return ORCA_OK;
+  ORCA_REQUIRE(ids && pending && overlay && memory && last_update && msg_ts, "orca_persist_overlay: null pointer");
+  k_persist_overlay<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(ids, n, pending, overlay, memory, last_update, msg_ts,
+                                                                  n_nodes);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

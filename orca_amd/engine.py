@@ -390,9 +390,6 @@ class OrcaEngine:
     if self.csr is None:
       raise OrcaError("OrcaEngine: set_neighbor_finder() first")
     self.batch_counter += 1
-    nodes = torch.cat([src, dst, neg])
-    t3 = torch.cat([ts, ts, ts])
-    positives = nodes[:2 * src.numel()]
     if train:                                          # :105-112
       self.test_mode = False
     elif not self.test_mode:
@@ -401,6 +398,9 @@ class OrcaEngine:
     if self.reuse and self.budget == 0 and self.prof is None:
       # Path B end to end in the native driver (embedding, memory persist, message store)
       return self._step_reuse_native(src, dst, neg, ts, eidx, train)
+    nodes = torch.cat([src, dst, neg])
+    t3 = torch.cat([ts, ts, ts])
+    positives = nodes[:2 * src.numel()]
     if self.reuse and self.budget != 0:                # :114-120
       if self.world != 1:
         raise OrcaError("budgeted reuse (Path C) runs on one rank")
