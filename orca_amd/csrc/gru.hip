@@ -180,7 +180,7 @@ __global__ __launch_bounds__(KS2 * NWG * 64) void k_gru_rows(const float* __rest
 }
 
 
-constexpr int RW = 4;             // 16-row sub-tiles (waves) per workgroup; they share one hidden-unit tile
+constexpr int RW = 1;             // 16-row sub-tiles (waves) per workgroup: single-wave workgroups spread evenly over the CUs
 constexpr int GS = 5;             // steps of operands fetched ahead (ring of registers)
 
 // Out-of-place GRU: workgroup = (64 rows) x (one 16-wide tile of hidden units); wave w owns rows 16w..16w+15
