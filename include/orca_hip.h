@@ -260,6 +260,8 @@ typedef struct {
   float* et;                       /* [q_max*K] */
   float* dt;                       /* [q_max*K] */
   float* emb[2];                   /* [q_max, ORCA_D] each: layer outputs ping-pong (layer l -> emb[(l+1)&1]) */
+  uint8_t* winners;                /* [2*q_max] last-occurrence flags of the push / message-store id lists; may be
+                                      NULL (the elections then run on `slot` with global atomics) */
 } orca_engine_desc;
 
 int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** out);

@@ -29,6 +29,30 @@ void orca_set_error(const char* fmt, ...);
 
 #define ORCA_LAUNCH_CHECK() ORCA_HIP_TRY(hipGetLastError())
 
+// ---- library-internal entry points (hidden visibility; used by the native step driver) -------------
+// First pass of orca_worklist_build fused into the sampler: every sampled neighbour / root whose flag is set
+// stores slot[id] = epoch + position, positions numbered [neighbours (Q*K) ; roots (Q)]; *count is zeroed.
+struct orca_claim {
+  const uint8_t* flags;
+  int64_t* slot;
+  int64_t epoch, n_nodes;
+  int32_t* count;
+};
+int orca_sample_recent_claim(const orca_csr_t* c, const int64_t* nodes, const double* ts, int64_t Q, int K,
+                             int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt, int* err_flag,
+                             const orca_claim* claim, void* stream);
+// second pass alone (the claim pass ran elsewhere with the same epoch and position numbering)
+int orca_worklist_append(const int32_t* ids32, int64_t n32, const int64_t* ids64, int64_t n64, const uint8_t* flags,
+                         const int64_t* slot, int64_t epoch, int64_t n_nodes, int32_t* worklist, int32_t* count,
+                         void* stream);
+// orca_history_push / orca_message_store with the last-occurrence winners precomputed (winner[p] != 0)
+int orca_history_push_winners(float* emb, const float* x, const int64_t* ids, int64_t n, const uint8_t* winner,
+                              int64_t n_nodes, void* stream);
+int orca_message_store_winners(const int64_t* src, const int64_t* dst, const int64_t* eidx, const double* t, int64_t bs,
+                               const float* memory, const float* last_update, const float* edge_feats, int d_e,
+                               const float* time_w, const float* time_b, const uint8_t* winner, int64_t n_nodes,
+                               float* messages, float* msg_ts, uint8_t* pending, void* stream);
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

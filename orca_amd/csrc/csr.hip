@@ -321,12 +321,16 @@ __global__ __launch_bounds__(256) void k_sample_recent(const int64_t* __restrict
                                                        const double* __restrict__ qts, int64_t Q, int K,
                                                        int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid,
                                                        float* __restrict__ o_et, float* __restrict__ o_dt,
-                                                       int* err_flag) {
+                                                       int* err_flag, orca_claim claim) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= Q) return;
   const int64_t v = nodes[q];
   const double t = qts[q];
+  if (claim.slot) {   // first pass of the distinct-id work-list over [neighbours ; roots] (state.hip)
+    if (q == 0 && lane == 0) *claim.count = 0;
+    if (lane == 0 && v >= 0 && v < claim.n_nodes && (!claim.flags || claim.flags[v])) claim.slot[v] = claim.epoch + Q * K + q;
+  }
   int64_t lo = 0, i = 0;
   if (v >= 0 && v < n_rows) {
     lo = indptr[v];
@@ -349,20 +353,28 @@ __global__ __launch_bounds__(256) void k_sample_recent(const int64_t* __restrict
     o_eid[o] = e;
     o_et[o] = et;
     if (o_dt) o_dt[o] = (float)(t - (double)et);   // embedding_module.py:130-131
+    if (claim.slot && n >= 0 && n < claim.n_nodes && (!claim.flags || claim.flags[n])) claim.slot[n] = claim.epoch + o;
   }
 }
 
-ORCA_API int orca_sample_recent(const orca_csr_t* c, const int64_t* nodes, const double* ts, int64_t Q, int K,
-                                int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt, int* err_flag,
-                                void* stream) {
+int orca_sample_recent_claim(const orca_csr_t* c, const int64_t* nodes, const double* ts, int64_t Q, int K,
+                             int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt, int* err_flag,
+                             const orca_claim* claim, void* stream) {
   ORCA_REQUIRE(c && Q >= 0 && K >= 1, "orca_sample_recent: bad arguments (Q=%lld K=%d)", (long long)Q, K);
   if (Q == 0) return ORCA_OK;
   ORCA_REQUIRE(nodes && ts && out_nbr && out_eidx && out_et, "orca_sample_recent: null pointer");
   const int wpb = 4;
   k_sample_recent<<<(unsigned)ceil_div64(Q, wpb), wpb * 64, 0, (hipStream_t)stream>>>(
-      c->indptr, c->nbr, c->eid, c->ts, c->n_rows, nodes, ts, Q, K, out_nbr, out_eidx, out_et, out_dt, err_flag);
+      c->indptr, c->nbr, c->eid, c->ts, c->n_rows, nodes, ts, Q, K, out_nbr, out_eidx, out_et, out_dt, err_flag,
+      claim ? *claim : orca_claim{});
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
+}
+
+ORCA_API int orca_sample_recent(const orca_csr_t* c, const int64_t* nodes, const double* ts, int64_t Q, int K,
+                                int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt, int* err_flag,
+                                void* stream) {
+  return orca_sample_recent_claim(c, nodes, ts, Q, K, out_nbr, out_eidx, out_et, out_dt, err_flag, nullptr, stream);
 }
 
 __global__ __launch_bounds__(256) void k_find_before(const int64_t* __restrict__ indptr, const double* __restrict__ ts,

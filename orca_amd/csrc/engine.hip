@@ -18,19 +18,68 @@ struct orca_engine {
   int64_t bs, Q;       // current batch
   int train;
   bool overlay_covers_batch;   // begin() ran in train order over the whole batch: overlay holds every pending root
+  bool winners_valid;          // begin() elected the last occurrences of the push / message-store id lists
   bool profile;        // bracket the sampler / GRU / attention launches with HIP events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ORCA_PROF_CLASSES];
 };
 
 namespace {
 
-__global__ void k_build_queries(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
-                                const int64_t* __restrict__ neg, const double* __restrict__ ts, int64_t bs,
-                                int64_t* __restrict__ nodes, double* __restrict__ qts, int32_t* __restrict__ nodes32) {
+// Last-occurrence election of a whole id list inside ONE workgroup: an LDS hash table keyed by id holds the
+// highest position seen (LDS atomics: hub ids of a power-law batch repeat hundreds of times, and the same
+// election with global atomicMax serialises on them at L2).  winner[p] = 1 iff p is the last position of its id.
+constexpr int ELECT_THREADS = 1024;
+constexpr int ELECT_SLOTS = 8192;          // 2 x 32 KiB of LDS
+constexpr int64_t ELECT_MAX = 6144;        // ids per list (load factor <= 0.75)
+
+template <typename GetId>
+__device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64_t n, int64_t n_nodes, GetId get,
+                                             uint8_t* __restrict__ winner) {
+  for (int i = threadIdx.x; i < ELECT_SLOTS; i += ELECT_THREADS) { keys[i] = -1; vals[i] = -1; }
+  __syncthreads();
+  for (int64_t p = threadIdx.x; p < n; p += ELECT_THREADS) {
+    const int64_t id = get(p);
+    if (id < 0 || id >= n_nodes) continue;
+    uint32_t h = ((uint32_t)id * 2654435761u) >> 19;
+    for (;;) {
+      const int32_t old = atomicCAS(&keys[h], -1, (int32_t)id);
+      if (old == -1 || old == (int32_t)id) break;
+      h = (h + 1) & (ELECT_SLOTS - 1);
+    }
+    atomicMax(&vals[h], (int32_t)p);
+  }
+  __syncthreads();
+  for (int64_t p = threadIdx.x; p < n; p += ELECT_THREADS) {
+    const int64_t id = get(p);
+    uint8_t w = 0;
+    if (id >= 0 && id < n_nodes) {
+      uint32_t h = ((uint32_t)id * 2654435761u) >> 19;
+      while (keys[h] != (int32_t)id) h = (h + 1) & (ELECT_SLOTS - 1);
+      w = vals[h] == (int32_t)p;
+    }
+    winner[p] = w;
+  }
+}
+
+// blocks [0, nb): the root queries [src;dst;neg] x [t;t;t] (tgn_model.py:99-102).
+// block nb   (elect only): winners of the history push over all 3*bs roots (embedding_module.py:103-113, H7)
+// block nb+1 (elect only): winners of the raw-message store over [src;dst]  (message_aggregator.py last-message)
+__global__ __launch_bounds__(ELECT_THREADS) void k_build_queries(const int64_t* __restrict__ src,
+                                                                 const int64_t* __restrict__ dst,
+                                                                 const int64_t* __restrict__ neg,
+                                                                 const double* __restrict__ ts, int64_t bs,
+                                                                 int64_t* __restrict__ nodes, double* __restrict__ qts,
+                                                                 int32_t* __restrict__ nodes32, int nb, int64_t n_nodes,
+                                                                 uint8_t* __restrict__ win_push,
+                                                                 uint8_t* __restrict__ win_msg) {
+  __shared__ int32_t keys[ELECT_SLOTS], vals[ELECT_SLOTS];
+  auto root = [&](int64_t i) { return i < bs ? src[i] : (i < 2 * bs ? dst[i - bs] : neg[i - 2 * bs]); };
+  if ((int)blockIdx.x == nb) { elect_in_lds(keys, vals, 3 * bs, n_nodes, root, win_push); return; }
+  if ((int)blockIdx.x == nb + 1) { elect_in_lds(keys, vals, 2 * bs, n_nodes, root, win_msg); return; }
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 3 * bs) return;
   const int64_t e = i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs);
-  const int64_t v = i < bs ? src[e] : (i < 2 * bs ? dst[e] : neg[e]);   // tgn_model.py:99
+  const int64_t v = root(i);                                            // tgn_model.py:99
   nodes[i] = v;
   nodes32[i] = (int32_t)v;
   qts[i] = ts[e];                                                       // :102
@@ -75,6 +124,7 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   e->bs = e->Q = 0;
   e->train = 1;
   e->overlay_covers_batch = false;
+  e->winners_valid = false;
   e->profile = false;
   *out = e;
   return ORCA_OK;
@@ -135,17 +185,24 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
                "(slice %lld..%lld) does not fit q_max=%lld", (long long)bs, (long long)lo, (long long)hi, (long long)d.q_max);
   e->bs = bs; e->Q = Q; e->train = train;
   e->overlay_covers_batch = train && lo == 0 && hi == Q;
+  e->winners_valid = d.winners && Q <= ELECT_MAX;
   if (bs == 0) return ORCA_OK;
   ORCA_REQUIRE(src && dst && neg && ts, "orca_engine_begin: null batch array");
-  k_build_queries<<<(unsigned)ceil_div64(Q, 256), 256, 0, stream>>>(src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32);
+  const int nb = (int)ceil_div64(Q, ELECT_THREADS);
+  k_build_queries<<<(unsigned)(nb + (e->winners_valid ? 2 : 0)), ELECT_THREADS, 0, stream>>>(
+      src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32, nb, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr);
   ORCA_LAUNCH_CHECK();
   const int64_t n = hi - lo;
   if (n == 0) return ORCA_OK;
   const int K = d.K;
   int rc;
-  {
+  const int64_t cand = n * (K + 1);
+  const int64_t claim_epoch = train ? take_epochs(e, cand) : 0;
+  {   // the sampler also runs the claim pass of the overlay work-list over [neighbours ; roots] (train order)
+    orca_claim claim{d.pending, d.slot, claim_epoch, d.n_nodes, d.count};
     Timed t(e, ORCA_PROF_SAMPLE, stream);
-    rc = orca_sample_recent(d.csr, d.nodes + lo, d.qts + lo, n, K, d.nbr, d.eid, d.et, d.dt, nullptr, stream_);   // embedding_module.py:157
+    rc = orca_sample_recent_claim(d.csr, d.nodes + lo, d.qts + lo, n, K, d.nbr, d.eid, d.et, d.dt, nullptr,
+                                  train ? &claim : nullptr, stream_);   // embedding_module.py:157
   }
   if (rc != ORCA_OK) return rc;
   orca_tgat_inputs in{};
@@ -154,9 +211,8 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
   in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b;
   if (train) {   // :159-161 get_updated_memory(unique(neighbors ∪ sources)) -> overlay rows
-    const int64_t cand = n * (K + 1);
-    rc = orca_worklist_build(d.nbr, n * K, d.nodes + lo, n, d.pending, d.slot, take_epochs(e, cand), d.n_nodes, d.worklist,
-                             d.count, stream_);
+    rc = orca_worklist_append(d.nbr, n * K, d.nodes + lo, n, d.pending, d.slot, claim_epoch, d.n_nodes, d.worklist,
+                              d.count, stream_);
     if (rc != ORCA_OK) return rc;
     {
       Timed t(e, ORCA_PROF_GRU, stream);
@@ -181,7 +237,8 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
   float* next = d.emb[(layer + 1) & 1];
   float* h = d.hist[layer - 2];
   // embedding_module.py:103-113 push of every root's layer-(l-1) embedding, last occurrence wins (H7)
-  int rc = orca_history_push(h, prev, d.nodes, e->Q, d.slot, take_epochs(e, e->Q), d.n_nodes, stream_);
+  int rc = e->winners_valid ? orca_history_push_winners(h, prev, d.nodes, e->Q, d.winners, d.n_nodes, stream_)
+                            : orca_history_push(h, prev, d.nodes, e->Q, d.slot, take_epochs(e, e->Q), d.n_nodes, stream_);
   if (rc != ORCA_OK || hi == lo) return rc;
   orca_tgat_inputs in{};
   in.src_table = prev + lo * ORCA_D;               // dense rows of this rank's slice
@@ -223,6 +280,9 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
     return orca_set_flags(d.pending, d.nodes, nullptr, 2 * bs, nullptr, 0, stream_);
   };
   auto store = [&]() -> int {     // tgn_model.py:131-141,172-191 + memory.py:25-28
+    if (e->winners_valid)
+      return orca_message_store_winners(src, dst, eidx, ts, bs, d.memory, d.last_update, d.edge_feats, d.d_e, d.time_w,
+                                        d.time_b, d.winners + d.q_max, d.n_nodes, d.messages, d.msg_ts, d.pending, stream_);
     return orca_message_store(src, dst, eidx, ts, bs, d.memory, d.last_update, d.edge_feats, d.d_e, d.time_w, d.time_b,
                               d.slot, take_epochs(e, 2 * bs), d.n_nodes, d.messages, d.msg_ts, d.pending, stream_);
   };

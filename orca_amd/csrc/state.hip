@@ -41,9 +41,15 @@ __global__ void k_worklist_claim(const int32_t* __restrict__ ids32, int64_t n32,
   if (id < 0 || id >= n_nodes || (flags && !flags[id])) return;
   slot[id] = epoch + i;
 }
-__global__ void k_worklist_append(const int32_t* __restrict__ ids32, int64_t n32, const int64_t* __restrict__ ids64,
-                                  int64_t n64, const uint8_t* __restrict__ flags, const int64_t* __restrict__ slot,
-                                  int64_t epoch, int64_t n_nodes, int32_t* worklist, int32_t* count) {
+__global__ __launch_bounds__(1024) void k_worklist_append(const int32_t* __restrict__ ids32, int64_t n32,
+                                                           const int64_t* __restrict__ ids64, int64_t n64,
+                                                           const uint8_t* __restrict__ flags,
+                                                           const int64_t* __restrict__ slot, int64_t epoch,
+                                                           int64_t n_nodes, int32_t* worklist, int32_t* count) {
+  // one atomicAdd per 1024-thread workgroup: the counter is a single address, and per-wave atomics on it
+  // serialise at L2 (704 of them cost more than the rest of the kernel)
+  __shared__ int wave_n[16];
+  __shared__ int block_base;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool take = false;
   int64_t id = -1;
@@ -52,13 +58,16 @@ __global__ void k_worklist_append(const int32_t* __restrict__ ids32, int64_t n32
     take = id >= 0 && id < n_nodes && (!flags || flags[id]) && slot[id] == epoch + i;
   }
   const unsigned long long m = __ballot(take);
-  if (m == 0ull) return;
-  const int lane = threadIdx.x & 63;
-  const int leader = __ffsll((long long)m) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(count, __popcll(m));
-  base = __shfl(base, leader, 64);
-  if (take) worklist[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)id;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_n[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) { int c = wave_n[w]; wave_n[w] = tot; tot += c; }
+    block_base = tot ? atomicAdd(count, tot) : 0;
+  }
+  __syncthreads();
+  if (take) worklist[block_base + wave_n[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)id;
 }
 
 __global__ void k_set_flags(uint8_t* flags, const int64_t* ids64, const int32_t* ids32, int64_t n,
@@ -118,6 +127,7 @@ __global__ __launch_bounds__(256) void k_message_store(const int64_t* __restrict
                                                        const float* __restrict__ edge_feats, int d_e,
                                                        const float* __restrict__ tw, const float* __restrict__ tb,
                                                        const int64_t* __restrict__ slot, int64_t epoch,
+                                                       const uint8_t* __restrict__ winner,
                                                        int64_t n_nodes, float* __restrict__ messages,
                                                        float* __restrict__ msg_ts, uint8_t* __restrict__ pending) {
   const int lane = threadIdx.x & 63;
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(256) void k_message_store(const int64_t* __restrict
   const int64_t e = p < bs ? p : p - bs;
   const int64_t id = p < bs ? src[e] : dst[e];
   const int64_t partner = p < bs ? dst[e] : src[e];
-  if (id < 0 || id >= n_nodes || slot[id] != epoch + p) return;   // not the last occurrence of id
+  if (id < 0 || id >= n_nodes || (winner ? !winner[p] : slot[id] != epoch + p)) return;   // not the last occurrence of id
   const int msg_dim = 3 * D + d_e;
   float* row = messages + id * msg_dim;
   const float tf = (float)t[e];                                   // tgn_model.py:181
@@ -166,12 +176,13 @@ __global__ __launch_bounds__(256) void k_persist_overlay(const int64_t* __restri
 
 __global__ __launch_bounds__(256) void k_push_rows(float* __restrict__ emb, const float* __restrict__ x,
                                                    const int64_t* __restrict__ ids, int64_t n,
-                                                   const int64_t* __restrict__ slot, int64_t epoch, int64_t n_nodes) {
+                                                   const int64_t* __restrict__ slot, int64_t epoch,
+                                                   const uint8_t* __restrict__ winner, int64_t n_nodes) {
   const int lane = threadIdx.x & 63;
   const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= n) return;
   const int64_t id = ids[p];
-  if (id < 0 || id >= n_nodes || slot[id] != epoch + p) return;
+  if (id < 0 || id >= n_nodes || (winner ? !winner[p] : slot[id] != epoch + p)) return;
   for (int c = lane; c < D; c += 64) emb[id * D + c] = x[p * D + c];
 }
 
@@ -234,8 +245,18 @@ ORCA_API int orca_worklist_build(const int32_t* ids32, int64_t n32, const int64_
   }
   k_worklist_claim<<<blocks(n32 + n64, 256), 256, 0, (hipStream_t)stream>>>(ids32, n32, ids64, n64, flags, slot, epoch,
                                                                             n_nodes, count);
-  k_worklist_append<<<blocks(n32 + n64, 256), 256, 0, (hipStream_t)stream>>>(ids32, n32, ids64, n64, flags, slot, epoch,
-                                                                             n_nodes, worklist, count);
+  k_worklist_append<<<blocks(n32 + n64, 1024), 1024, 0, (hipStream_t)stream>>>(ids32, n32, ids64, n64, flags, slot, epoch,
+                                                                               n_nodes, worklist, count);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+int orca_worklist_append(const int32_t* ids32, int64_t n32, const int64_t* ids64, int64_t n64, const uint8_t* flags,
+                         const int64_t* slot, int64_t epoch, int64_t n_nodes, int32_t* worklist, int32_t* count,
+                         void* stream) {
+  if (n32 + n64 == 0) return ORCA_OK;
+  k_worklist_append<<<blocks(n32 + n64, 1024), 1024, 0, (hipStream_t)stream>>>(ids32, n32, ids64, n64, flags, slot, epoch,
+                                                                               n_nodes, worklist, count);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -282,7 +303,19 @@ ORCA_API int orca_message_store(const int64_t* src, const int64_t* dst, const in
   k_elect2<<<blocks(2 * bs, 256), 256, 0, (hipStream_t)stream>>>(src, dst, bs, slot, epoch, n_nodes);
   k_message_store<<<blocks(2 * bs, 4), 256, 0, (hipStream_t)stream>>>(src, dst, eidx, t, bs, memory, last_update,
                                                                       edge_feats, d_e, time_w, time_b, slot, epoch,
-                                                                      n_nodes, messages, msg_ts, pending);
+                                                                      nullptr, n_nodes, messages, msg_ts, pending);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+int orca_message_store_winners(const int64_t* src, const int64_t* dst, const int64_t* eidx, const double* t, int64_t bs,
+                               const float* memory, const float* last_update, const float* edge_feats, int d_e,
+                               const float* time_w, const float* time_b, const uint8_t* winner, int64_t n_nodes,
+                               float* messages, float* msg_ts, uint8_t* pending, void* stream) {
+  if (bs == 0) return ORCA_OK;
+  k_message_store<<<blocks(2 * bs, 4), 256, 0, (hipStream_t)stream>>>(src, dst, eidx, t, bs, memory, last_update,
+                                                                      edge_feats, d_e, time_w, time_b, nullptr, 0,
+                                                                      winner, n_nodes, messages, msg_ts, pending);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -304,7 +337,15 @@ ORCA_API int orca_history_push(float* emb, const float* x, const int64_t* ids, i
   ORCA_REQUIRE(n >= 0 && n_nodes > 0 && (n == 0 || (emb && x && ids && slot)), "orca_history_push: bad arguments");
   if (n == 0) return ORCA_OK;
   k_elect<<<blocks(n, 256), 256, 0, (hipStream_t)stream>>>(ids, n, slot, epoch, n_nodes);
-  k_push_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(emb, x, ids, n, slot, epoch, n_nodes);
+  k_push_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(emb, x, ids, n, slot, epoch, nullptr, n_nodes);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+int orca_history_push_winners(float* emb, const float* x, const int64_t* ids, int64_t n, const uint8_t* winner,
+                              int64_t n_nodes, void* stream) {
+  if (n == 0) return ORCA_OK;
+  k_push_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(emb, x, ids, n, nullptr, 0, winner, n_nodes);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

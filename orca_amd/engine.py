@@ -166,7 +166,8 @@ class OrcaEngine:
                    eid=torch.zeros(q_max * K, dtype=torch.int32, device=dev),
                    et=torch.zeros(q_max * K, dtype=torch.float32, device=dev),
                    dt=torch.zeros(q_max * K, dtype=torch.float32, device=dev),
-                   emb=[torch.zeros(q_max, D, dtype=torch.float32, device=dev) for _ in range(2)])
+                   emb=[torch.zeros(q_max, D, dtype=torch.float32, device=dev) for _ in range(2)],
+                   winners=torch.zeros(2 * q_max, dtype=torch.uint8, device=dev))
     d = _lib.EngineDesc()
     d.n_nodes, d.n_layers, d.K, d.d_e = self.N, self.L, K, self.d_e
     d.csr = self.csr._h if self.csr is not None else None
@@ -184,6 +185,7 @@ class OrcaEngine:
     d.nodes, d.qts, d.nodes32 = ptr(w["nodes"]), ptr(w["qts"]), ptr(w["nodes32"])
     d.nbr, d.eid, d.et, d.dt = ptr(w["nbr"]), ptr(w["eid"]), ptr(w["et"]), ptr(w["dt"])
     d.emb[0], d.emb[1] = ptr(w["emb"][0]), ptr(w["emb"][1])
+    d.winners = ptr(w["winners"])
     h = _lib.vp()
     check(L.orca_engine_create(ctypes.byref(d), ctypes.byref(h)), "orca_engine_create")
     L.orca_engine_take_epochs(h, self.slot_epoch)       # continue after the epochs already used on `slot`
