@@ -45,6 +45,9 @@ def parse():
   ap.add_argument("--no-reuse", action="store_true", help="Path A (exact TGN recursion) instead of Path B")
   ap.add_argument("--cpu-batches", type=int, default=200, help="batches of the CPU baseline sample (0 = skip)")
   ap.add_argument("--no-kernel-events", action="store_true")
+  ap.add_argument("--event-stride", type=int, default=8,
+                  help="attach HIP events to the kernels of every n-th timed step (the event plumbing costs ~20 us of "
+                       "host time per step it is on)")
   return ap.parse_args()
 
 
@@ -141,7 +144,7 @@ def main():
     for b in batches[:args.warmup]:
       eng.compute_temporal_embeddings(*b, train=True)
     if not args.no_kernel_events:
-      eng.profile_kernels(True)       # native driver (Path B)
+      eng.profile_kernels(True, args.event_stride)       # native driver (Path B)
       if args.no_reuse:
         eng.prof = {}                 # Python-dispatched path (Path A)
     barrier()

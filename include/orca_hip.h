@@ -265,8 +265,9 @@ typedef struct {
 } orca_engine_desc;
 
 int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** out);
-/* Measurement aid: while enabled, the sampler / GRU / attention launches of the step are bracketed with HIP
- * events on the launch stream; orca_engine_profile_read waits for them and returns count and mean ms. */
+/* Measurement aid: enable = n > 0 attaches a HIP event pair to the sampler / GRU / attention dispatches of every
+ * n-th step (the events take the kernel's own begin / end timestamps on the launch stream); 0 switches it off.
+ * orca_engine_profile_read waits for the recorded pairs and returns their count and mean duration in ms. */
 #define ORCA_PROF_SAMPLE 0
 #define ORCA_PROF_GRU 1
 #define ORCA_PROF_TGAT 2

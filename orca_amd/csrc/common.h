@@ -1,6 +1,7 @@
 // Internal helpers shared by the HIP translation units of liborca_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -52,6 +53,18 @@ int orca_message_store_winners(const int64_t* src, const int64_t* dst, const int
                                const float* memory, const float* last_update, const float* edge_feats, int d_e,
                                const float* time_w, const float* time_b, const uint8_t* winner, int64_t n_nodes,
                                float* messages, float* msg_ts, uint8_t* pending, void* stream);
+
+// Measurement hook of the step driver: when a (start, stop) event pair is armed on this thread, the next
+// ORCA_LAUNCH_TIMED launch attaches it to its own dispatch (hipExtLaunchKernelGGL: the events take the kernel's
+// begin / end timestamps, no marker packets are added to the stream) and disarms it.
+struct orca_launch_events { hipEvent_t start, stop; };
+extern thread_local orca_launch_events orca_armed_events;
+#define ORCA_LAUNCH_TIMED(kernel, grid, block, lds, stream, ...)                                      \
+  do {                                                                                                \
+    orca_launch_events _ev = orca_armed_events;                                                       \
+    orca_armed_events = orca_launch_events{nullptr, nullptr};                                         \
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), (uint32_t)(lds), stream, _ev.start, _ev.stop, 0, __VA_ARGS__); \
+  } while (0)
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

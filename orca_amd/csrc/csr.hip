@@ -364,9 +364,9 @@ int orca_sample_recent_claim(const orca_csr_t* c, const int64_t* nodes, const do
   if (Q == 0) return ORCA_OK;
   ORCA_REQUIRE(nodes && ts && out_nbr && out_eidx && out_et, "orca_sample_recent: null pointer");
   const int wpb = 4;
-  k_sample_recent<<<(unsigned)ceil_div64(Q, wpb), wpb * 64, 0, (hipStream_t)stream>>>(
-      c->indptr, c->nbr, c->eid, c->ts, c->n_rows, nodes, ts, Q, K, out_nbr, out_eidx, out_et, out_dt, err_flag,
-      claim ? *claim : orca_claim{});
+  ORCA_LAUNCH_TIMED(k_sample_recent, (unsigned)ceil_div64(Q, wpb), wpb * 64, 0, (hipStream_t)stream,
+                    c->indptr, c->nbr, c->eid, c->ts, c->n_rows, nodes, ts, Q, K, out_nbr, out_eidx, out_et, out_dt, err_flag,
+                    claim ? *claim : orca_claim{});
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

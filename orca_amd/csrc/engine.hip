@@ -19,9 +19,13 @@ struct orca_engine {
   int train;
   bool overlay_covers_batch;   // begin() ran in train order over the whole batch: overlay holds every pending root
   bool winners_valid;          // begin() elected the last occurrences of the push / message-store id lists
-  bool profile;        // bracket the sampler / GRU / attention launches with HIP events
+  int profile;         // > 0: every profile-th step has HIP events attached to its sampler / GRU / attention launches
+  int64_t step;        // steps begun since profiling was switched on
+  bool timed_step;     // this step is one of those
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ORCA_PROF_CLASSES];
 };
+
+thread_local orca_launch_events orca_armed_events = {nullptr, nullptr};
 
 namespace {
 
@@ -85,17 +89,21 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_build_queries(const int64_t* 
   qts[i] = ts[e];                                                       // :102
 }
 
-// RAII bracket: records an event pair on the launch stream around one kernel when profiling is on
+// RAII bracket: while profiling is on, arms an event pair that the next timed launch (sampler / GRU / attention)
+// attaches to its own dispatch -- the pair then holds that kernel's begin and end timestamps
 struct Timed {
-  orca_engine* e; int cls; hipStream_t s; hipEvent_t a, b; bool on;
-  Timed(orca_engine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_), a(nullptr), b(nullptr), on(e_->profile) {
-    if (on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
+  orca_engine* e; int cls; hipEvent_t a, b; bool on;
+  Timed(orca_engine* e_, int cls_, hipStream_t) : e(e_), cls(cls_), a(nullptr), b(nullptr), on(e_->timed_step) {
+    if (on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) orca_armed_events = orca_launch_events{a, b};
     else on = false;
   }
   ~Timed() {
     if (!on) return;
-    (void)hipEventRecord(b, s);
-    e->ev[cls].emplace_back(a, b);
+    const bool consumed = orca_armed_events.start != a;
+    orca_armed_events = orca_launch_events{nullptr, nullptr};
+    if (consumed) { e->ev[cls].emplace_back(a, b); return; }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
   }
 };
 
@@ -125,14 +133,18 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   e->train = 1;
   e->overlay_covers_batch = false;
   e->winners_valid = false;
-  e->profile = false;
+  e->profile = 0;
+  e->step = 0;
+  e->timed_step = false;
   *out = e;
   return ORCA_OK;
 }
 
 ORCA_API int orca_engine_profile(orca_engine_t* e, int enable) {
   ORCA_REQUIRE(e, "orca_engine_profile: null handle");
-  e->profile = enable != 0;
+  e->profile = enable > 0 ? enable : 0;
+  e->step = 0;
+  e->timed_step = false;
   return ORCA_OK;
 }
 
@@ -184,6 +196,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   ORCA_REQUIRE(bs >= 0 && Q <= d.q_max && 0 <= lo && lo <= hi && hi <= Q, "orca_engine_begin: batch of %lld interactions "
                "(slice %lld..%lld) does not fit q_max=%lld", (long long)bs, (long long)lo, (long long)hi, (long long)d.q_max);
   e->bs = bs; e->Q = Q; e->train = train;
+  e->timed_step = e->profile > 0 && (e->step++ % e->profile) == 0;
   e->overlay_covers_batch = train && lo == 0 && hi == Q;
   e->winners_valid = d.winners && Q <= ELECT_MAX;
   if (bs == 0) return ORCA_OK;

@@ -367,8 +367,8 @@ ORCA_API int orca_debug_gru_phase_clock(void* buf) {
 
 static int gru_launch_stream(const float* blob, const int32_t* ids, int64_t n, const int32_t* n_dev, const float* x,
                              const float* h, float* out, float* last_update, const float* msg_ts, hipStream_t stream) {
-  k_gru_stream<3 * D + 172><<<(unsigned)(ceil_div64(n, 16 * RW) * NWG), RW * 64, 0, stream>>>(blob, ids, n, n_dev, x, h, out,
-                                                                                          last_update, msg_ts, g_gru_clock);
+  ORCA_LAUNCH_TIMED((k_gru_stream<3 * D + 172>), (unsigned)(ceil_div64(n, 16 * RW) * NWG), RW * 64, 0, stream, blob, ids, n,
+                    n_dev, x, h, out, last_update, msg_ts, g_gru_clock);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -383,8 +383,8 @@ static int gru_launch_rows(const float* blob, int msg_dim, const int32_t* ids, i
     ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_gru_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     attr_set = true;
   }
-  k_gru_rows<1><<<(unsigned)ceil_div64(n, 16), KS2 * NWG * 64, lds_bytes, stream>>>(blob, msg_dim, ids, n, n_dev, x, h, out,
-                                                                                 last_update, msg_ts);
+  ORCA_LAUNCH_TIMED((k_gru_rows<1>), (unsigned)ceil_div64(n, 16), KS2 * NWG * 64, lds_bytes, stream, blob, msg_dim, ids, n,
+                    n_dev, x, h, out, last_update, msg_ts);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

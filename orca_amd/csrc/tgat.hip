@@ -707,11 +707,11 @@ ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_input
   const unsigned grid = (unsigned)ceil_div64(Q, TQ);
   hipStream_t st = (hipStream_t)stream;
   if (K == 10 && d_e == 172)
-    k_tgat_forward<10, 172><<<grid, NW * 64, lds_bytes, st>>>(blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
+    ORCA_LAUNCH_TIMED((k_tgat_forward<10, 172>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
   else if (K == 10)
-    k_tgat_forward<10, 0><<<grid, NW * 64, lds_bytes, st>>>(blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
+    ORCA_LAUNCH_TIMED((k_tgat_forward<10, 0>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
   else
-    k_tgat_forward<0, 0><<<grid, NW * 64, lds_bytes, st>>>(blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
+    ORCA_LAUNCH_TIMED((k_tgat_forward<0, 0>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

@@ -74,7 +74,7 @@ class OrcaEngine:
     self.batch_counter = 0
     self._native = None      # orca_engine_t: the C++ step driver (created on first use, regrown with the batch)
     self._q_max = 0
-    self._prof_native = False
+    self._prof_native = 0
     self.prof = None     # set to {} to bracket the kernels with HIP events (bench.py roofline)
 
   def _timed(self, name, fn, *a, **k):
@@ -191,13 +191,13 @@ class OrcaEngine:
     L.orca_engine_take_epochs(h, self.slot_epoch)       # continue after the epochs already used on `slot`
     self._native, self._q_max = h, q_max
     if self._prof_native:
-      L.orca_engine_profile(h, 1)
+      L.orca_engine_profile(h, self._prof_native)
 
-  def profile_kernels(self, on=True):
-    """bench.py: bracket the sampler / GRU / attention launches of the native step with HIP events"""
-    self._prof_native = bool(on)
+  def profile_kernels(self, on=True, every=1):
+    """bench.py: attach HIP events to the sampler / GRU / attention launches of every `every`-th native step"""
+    self._prof_native = int(every) if on else 0
     if self._native is not None:
-      _lib.load().orca_engine_profile(self._native, int(on))
+      _lib.load().orca_engine_profile(self._native, self._prof_native)
 
   def profile_read(self):
     """{kernel: (launches, mean ms)} measured since profile_kernels(True); waits for the events"""
