@@ -215,12 +215,14 @@ def test_attention_errors(ops, golden):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("msg_dim,n", [(472, 700), (301, 33), (472, 1)])
+@pytest.mark.parametrize("msg_dim,n", [(472, 700), (301, 33), (472, 1), (472, 7000)])
 def test_gru_vs_oracle(ops, msg_dim, n):
+  """n = 7000 is past both size switches of the out-of-place path: more row tiles than the split kernel's grid
+  covers in one pass (its workgroups loop) and, with an exact count, the one-wave-per-tile streaming kernel."""
   torch.manual_seed(msg_dim + n)
   cell = torch.nn.GRUCell(msg_dim, 100)
   P = {k: v.detach() for k, v in cell.state_dict().items()}
-  N = 2000
+  N = max(2000, n + 1000)
   rs = np.random.RandomState(n)
   x = torch.from_numpy(rs.randn(N, msg_dim).astype(np.float32))
   h = torch.from_numpy(rs.randn(N, 100).astype(np.float32))
@@ -246,6 +248,12 @@ def test_gru_vs_oracle(ops, msg_dim, n):
   ov = torch.zeros(N, 100, device=DEV)
   ops.gru_update(blob, msg_dim, ids32, n, None, x.to(DEV), h.to(DEV), ov)
   assert_close_fp32(ov.cpu()[ids].numpy(), ref.numpy(), 1e-5, "gru overlay")
+  assert np.all(ov.cpu().numpy()[untouched] == 0)
+  # overlay of a device-counted work-list (the engine's call: launch bound above the count)
+  ov2 = torch.zeros(N, 100, device=DEV)
+  ops.gru_update(blob, msg_dim, ids32, n + 50, n_dev, x.to(DEV), h.to(DEV), ov2)
+  assert_close_fp32(ov2.cpu()[ids].numpy(), ref.numpy(), 1e-5, "gru overlay, device count")
+  assert np.all(ov2.cpu().numpy()[untouched] == 0)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -103,7 +103,7 @@ def main():
   # phase breakdown of the streaming GRU kernel
   n = 2730
   ids = torch.randperm(N, device=dev)[:n].to(torch.int32)
-  nw = ((n + 63) // 64) * 7 * 4
+  nw = ((n + 15) // 16) * 7 * 4   # (16-row tile) x (hidden tile) workgroups of 4 waves
   gclk = torch.zeros(nw * 4, dtype=torch.int64, device=dev)
   _lib.load().orca_debug_gru_phase_clock(gclk.data_ptr())
   ops.gru_update(gblob, msg_dim, ids, n, None, messages, memory, overlay)
