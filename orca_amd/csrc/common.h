@@ -54,6 +54,24 @@ int orca_message_store_winners(const int64_t* src, const int64_t* dst, const int
                                const float* time_w, const float* time_b, const uint8_t* winner, int64_t n_nodes,
                                float* messages, float* msg_ts, uint8_t* pending, void* stream);
 
+// orca_tgat_forward with the step driver's extra row writes fused in (either half may be left null):
+//  persist: a query q < persist_n whose source row was read from the overlay (src_flags[row] set) also commits it:
+//           persist_memory[row] = that row, persist_last_update[row] = persist_msg_ts[row]  (memory_updater.py:25-39;
+//           safe inside the kernel because a flagged row of the memory table is read by nobody: flagged reads go
+//           to the overlay);
+//  push   : the output row of query q also goes to push_table[push_ids[q]] when push_winner[q] (history.py:26-30).
+struct orca_tgat_side {
+  float* persist_memory;
+  float* persist_last_update;
+  const float* persist_msg_ts;
+  int64_t persist_n;
+  float* push_table;
+  const int64_t* push_ids;
+  const uint8_t* push_winner;
+};
+int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
+                           float* out_weights, const orca_tgat_side* side, void* stream);
+
 // Measurement hook of the step driver: when a (start, stop) event pair is armed on this thread, the next
 // ORCA_LAUNCH_TIMED launch attaches it to its own dispatch (hipExtLaunchKernelGGL: the events take the kernel's
 // begin / end timestamps, no marker packets are added to the stream) and disarms it.

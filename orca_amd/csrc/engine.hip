@@ -11,6 +11,7 @@
 #include <new>
 #include <vector>
 #include "common.h"
+#include "sampler.h"
 
 struct orca_engine {
   orca_engine_desc d;
@@ -19,6 +20,8 @@ struct orca_engine {
   int train;
   bool overlay_covers_batch;   // begin() ran in train order over the whole batch: overlay holds every pending root
   bool winners_valid;          // begin() elected the last occurrences of the push / message-store id lists
+  bool persist_done;           // the memory persist of the batch was fused into attention layer 1
+  int pushed_layer;            // output of this layer is already in its history table (fused push), 0 = none
   int profile;         // > 0: every profile-th step has HIP events attached to its sampler / GRU / attention launches
   int64_t step;        // steps begun since profiling was switched on
   bool timed_step;     // this step is one of those
@@ -65,28 +68,36 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
   }
 }
 
-// blocks [0, nb): the root queries [src;dst;neg] x [t;t;t] (tgn_model.py:99-102).
+// First kernel of a step.  Block b < nb, wave w: root query i = 16 b + w of [src;dst;neg] x [t;t;t]
+// (tgn_model.py:99-102) is written to nodes / qts / nodes32 and, when i lies in this rank's slice [lo, hi), its K
+// most recent neighbours are sampled into row i - lo of the sampler outputs (embedding_module.py:157), with the
+// claim pass of the overlay work-list in train order.
 // block nb   (elect only): winners of the history push over all 3*bs roots (embedding_module.py:103-113, H7)
 // block nb+1 (elect only): winners of the raw-message store over [src;dst]  (message_aggregator.py last-message)
-__global__ __launch_bounds__(ELECT_THREADS) void k_build_queries(const int64_t* __restrict__ src,
-                                                                 const int64_t* __restrict__ dst,
-                                                                 const int64_t* __restrict__ neg,
-                                                                 const double* __restrict__ ts, int64_t bs,
-                                                                 int64_t* __restrict__ nodes, double* __restrict__ qts,
-                                                                 int32_t* __restrict__ nodes32, int nb, int64_t n_nodes,
-                                                                 uint8_t* __restrict__ win_push,
-                                                                 uint8_t* __restrict__ win_msg) {
+__global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
+    const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
+    const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
+    int32_t* __restrict__ nodes32, int nb, int64_t n_nodes, uint8_t* __restrict__ win_push, uint8_t* __restrict__ win_msg,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ c_nbr, const int32_t* __restrict__ c_eid,
+    const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int K, int32_t* __restrict__ o_nbr,
+    int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt, orca_claim claim) {
   __shared__ int32_t keys[ELECT_SLOTS], vals[ELECT_SLOTS];
   auto root = [&](int64_t i) { return i < bs ? src[i] : (i < 2 * bs ? dst[i - bs] : neg[i - 2 * bs]); };
   if ((int)blockIdx.x == nb) { elect_in_lds(keys, vals, 3 * bs, n_nodes, root, win_push); return; }
   if ((int)blockIdx.x == nb + 1) { elect_in_lds(keys, vals, 2 * bs, n_nodes, root, win_msg); return; }
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
   if (i >= 3 * bs) return;
   const int64_t e = i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs);
   const int64_t v = root(i);                                            // tgn_model.py:99
-  nodes[i] = v;
-  nodes32[i] = (int32_t)v;
-  qts[i] = ts[e];                                                       // :102
+  const double t = ts[e];                                               // :102
+  if (lane == 0) {
+    nodes[i] = v;
+    nodes32[i] = (int32_t)v;
+    qts[i] = t;
+  }
+  if (i < lo || i >= hi) return;
+  sample_recent_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, i - lo, hi - lo, K, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
 }
 
 // RAII bracket: while profiling is on, arms an event pair that the next timed launch (sampler / GRU / attention)
@@ -133,6 +144,8 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   e->train = 1;
   e->overlay_covers_batch = false;
   e->winners_valid = false;
+  e->persist_done = false;
+  e->pushed_layer = 0;
   e->profile = 0;
   e->step = 0;
   e->timed_step = false;
@@ -199,25 +212,28 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   e->timed_step = e->profile > 0 && (e->step++ % e->profile) == 0;
   e->overlay_covers_batch = train && lo == 0 && hi == Q;
   e->winners_valid = d.winners && Q <= ELECT_MAX;
+  e->persist_done = false;
+  e->pushed_layer = 0;
   if (bs == 0) return ORCA_OK;
   ORCA_REQUIRE(src && dst && neg && ts, "orca_engine_begin: null batch array");
-  const int nb = (int)ceil_div64(Q, ELECT_THREADS);
-  k_build_queries<<<(unsigned)(nb + (e->winners_valid ? 2 : 0)), ELECT_THREADS, 0, stream>>>(
-      src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32, nb, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr);
-  ORCA_LAUNCH_CHECK();
   const int64_t n = hi - lo;
-  if (n == 0) return ORCA_OK;
   const int K = d.K;
-  int rc;
   const int64_t cand = n * (K + 1);
-  const int64_t claim_epoch = train ? take_epochs(e, cand) : 0;
-  {   // the sampler also runs the claim pass of the overlay work-list over [neighbours ; roots] (train order)
-    orca_claim claim{d.pending, d.slot, claim_epoch, d.n_nodes, d.count};
+  const int64_t claim_epoch = (train && n > 0) ? take_epochs(e, cand) : 0;
+  int rc;
+  {
+    int64_t n_rows = 0;
+    const int64_t* indptr; const int32_t *c_nbr, *c_eid; const double* c_ts;
+    if ((rc = orca_csr_arrays(d.csr, &n_rows, nullptr, &indptr, &c_nbr, &c_eid, &c_ts)) != ORCA_OK) return rc;
+    const orca_claim claim = (train && n > 0) ? orca_claim{d.pending, d.slot, claim_epoch, d.n_nodes, d.count} : orca_claim{};
+    const int nb = (int)ceil_div64(Q, ELECT_THREADS / 64);
     Timed t(e, ORCA_PROF_SAMPLE, stream);
-    rc = orca_sample_recent_claim(d.csr, d.nodes + lo, d.qts + lo, n, K, d.nbr, d.eid, d.et, d.dt, nullptr,
-                                  train ? &claim : nullptr, stream_);   // embedding_module.py:157
+    ORCA_LAUNCH_TIMED(k_begin_queries, (unsigned)(nb + (e->winners_valid ? 2 : 0)), ELECT_THREADS, 0, stream, src, dst, neg, ts,
+                      bs, d.nodes, d.qts, d.nodes32, nb, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr,
+                      indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, K, d.nbr, d.eid, d.et, d.dt, claim);
+    ORCA_LAUNCH_CHECK();
   }
-  if (rc != ORCA_OK) return rc;
+  if (n == 0) return ORCA_OK;
   orca_tgat_inputs in{};
   in.src_table = d.memory; in.src_idx = d.nodes32 + lo;
   in.nbr_table = d.memory; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;
@@ -236,8 +252,20 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     in.src_overlay = d.overlay; in.src_flags = d.pending;
     in.nbr_overlay = d.overlay; in.nbr_flags = d.pending;
   }
+  // a rank that embeds the whole batch lets the attention kernel do the row writes that would otherwise be
+  // kernels of their own: the memory persist of the positives (train order) and the history push of its output
+  orca_tgat_side side{};
+  if (e->overlay_covers_batch) {
+    side.persist_memory = d.memory; side.persist_last_update = d.last_update; side.persist_msg_ts = d.msg_ts;
+    side.persist_n = 2 * bs;
+    e->persist_done = true;
+  }
+  if (lo == 0 && hi == Q && e->winners_valid && d.n_layers >= 2) {
+    side.push_table = d.hist[0]; side.push_ids = d.nodes; side.push_winner = d.winners;
+    e->pushed_layer = 1;
+  }
   Timed t(e, ORCA_PROF_TGAT, stream);
-  return orca_tgat_forward(d.att_blob[0], d.d_e, &in, n, K, d.emb[0] + lo * ORCA_D, nullptr, stream_);   // :177 / :181
+  return orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, n, K, d.emb[0] + lo * ORCA_D, nullptr, &side, stream_);   // :177 / :181
 }
 
 ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t hi, void* stream_) {
@@ -250,16 +278,23 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
   float* next = d.emb[(layer + 1) & 1];
   float* h = d.hist[layer - 2];
   // embedding_module.py:103-113 push of every root's layer-(l-1) embedding, last occurrence wins (H7)
-  int rc = e->winners_valid ? orca_history_push_winners(h, prev, d.nodes, e->Q, d.winners, d.n_nodes, stream_)
-                            : orca_history_push(h, prev, d.nodes, e->Q, d.slot, take_epochs(e, e->Q), d.n_nodes, stream_);
+  int rc = ORCA_OK;
+  if (e->pushed_layer != layer - 1)
+    rc = e->winners_valid ? orca_history_push_winners(h, prev, d.nodes, e->Q, d.winners, d.n_nodes, stream_)
+                          : orca_history_push(h, prev, d.nodes, e->Q, d.slot, take_epochs(e, e->Q), d.n_nodes, stream_);
   if (rc != ORCA_OK || hi == lo) return rc;
   orca_tgat_inputs in{};
   in.src_table = prev + lo * ORCA_D;               // dense rows of this rank's slice
   in.nbr_table = h; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;   // pull (history.py:32-36) fused into the gather
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
   in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b;
+  orca_tgat_side side{};
+  if (lo == 0 && hi == e->Q && e->winners_valid && layer < d.n_layers) {   // this layer's output feeds the next history
+    side.push_table = d.hist[layer - 1]; side.push_ids = d.nodes; side.push_winner = d.winners;
+    e->pushed_layer = layer;
+  }
   Timed t(e, ORCA_PROF_TGAT, (hipStream_t)stream_);
-  return orca_tgat_forward(d.att_blob[layer - 1], d.d_e, &in, hi - lo, d.K, next + lo * ORCA_D, nullptr, stream_);
+  return orca_tgat_forward_side(d.att_blob[layer - 1], d.d_e, &in, hi - lo, d.K, next + lo * ORCA_D, nullptr, &side, stream_);
 }
 
 ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* eidx,
@@ -275,6 +310,7 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
     // GRU(message, memory) of every pending positive (same messages, same memory: positives are roots of the
     // batch): the rows are committed by one kernel, and the flags need no clearing because the message store
     // that follows sets them for exactly these ids.
+    if (e->persist_done) return ORCA_OK;   // attention layer 1 committed the rows (orca_tgat_side)
     if (e->overlay_covers_batch)
       return orca_persist_overlay(d.nodes, 2 * bs, d.pending, d.overlay, d.memory, d.last_update, d.msg_ts, d.n_nodes,
                                   stream_);

@@ -1,0 +1,72 @@
+// Wave-level most-recent-K temporal neighbour sampler (device code shared by csr.hip and engine.hip).
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Sampler: one 64-lane wavefront per (node, t) query.
+//   1. 64-ary lower_bound on the node's float64 timestamps: every round the 64 lanes probe 64
+//      evenly spaced positions, a ballot counts the probes that are < t, and the range shrinks
+//      64x (5 dependent rounds cover 2^30 entries instead of 30 for a scalar binary search).
+//   2. lanes 0..K-1 gather the K entries ending at the bound (contiguous in HBM) and write the
+//      right-aligned, zero-padded outputs plus the fused Δt.
+// Algorithmic bytes per query: 16 (indptr pair) + 8*ceil(log2(deg+1)) (probes) + 16K read + 16K written.
+__device__ __forceinline__ int64_t wave_lower_bound(const double* __restrict__ ts, int64_t lo, int64_t hi, double t,
+                                                    int lane) {
+  // invariant: answer in [lo, hi]; elements < lo are < t, element hi (if any) is >= t
+  while (hi - lo > 64) {
+    int64_t n = hi - lo;
+    int64_t step = (n + 63) >> 6;
+    int64_t p = lo + (int64_t)(lane + 1) * step - 1;
+    bool inb = p < hi;
+    bool less = inb ? (ts[p] < t) : false;
+    unsigned long long m = __ballot(less);
+    int c = __popcll(m);  // probes are monotone: the first c lanes are true
+    int64_t nlo = lo + (int64_t)c * step;
+    int64_t nhi = nlo + step - 1;   // position of the first probe that is >= t
+    if (nhi > hi) nhi = hi;
+    lo = nlo < hi ? nlo : hi;
+    hi = nhi;
+  }
+  int64_t p = lo + lane;
+  bool less = (p < hi) ? (ts[p] < t) : false;
+  return lo + __popcll(__ballot(less));
+}
+
+// One wavefront answers one query (v, t): lower_bound on v's timestamps, then lanes 0..K-1 write row `q` of the
+// right-aligned, zero-padded outputs plus the fused delta-t.  With claim.slot set the wave also runs the first
+// pass of the distinct-id work-list over [neighbours (Q*K positions) ; roots (Q positions)] (state.hip).
+__device__ __forceinline__ void sample_recent_wave(const int64_t* __restrict__ indptr, const int32_t* __restrict__ nbr,
+                                                   const int32_t* __restrict__ eid, const double* __restrict__ ts,
+                                                   int64_t n_rows, int64_t v, double t, int64_t q, int64_t Q, int K,
+                                                   int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid,
+                                                   float* __restrict__ o_et, float* __restrict__ o_dt, int* err_flag,
+                                                   const orca_claim& claim, int lane) {
+  if (claim.slot) {
+    if (q == 0 && lane == 0) *claim.count = 0;
+    if (lane == 0 && v >= 0 && v < claim.n_nodes && (!claim.flags || claim.flags[v])) claim.slot[v] = claim.epoch + Q * K + q;
+  }
+  int64_t lo = 0, i = 0;
+  if (v >= 0 && v < n_rows) {
+    lo = indptr[v];
+    int64_t hi = indptr[v + 1];
+    i = wave_lower_bound(ts, lo, hi, t, lane);
+  } else if (err_flag && lane == 0) {
+    *err_flag = 1;
+  }
+  for (int j = lane; j < K; j += 64) {
+    int64_t idx = i - K + j;
+    int32_t n = 0, e = 0;
+    float et = 0.0f;
+    if (idx >= lo) {
+      n = nbr[idx];
+      e = eid[idx];
+      et = (float)ts[idx];
+    }
+    int64_t o = q * K + j;
+    o_nbr[o] = n;
+    o_eid[o] = e;
+    o_et[o] = et;
+    if (o_dt) o_dt[o] = (float)(t - (double)et);   // embedding_module.py:130-131
+    if (claim.slot && n >= 0 && n < claim.n_nodes && (!claim.flags || claim.flags[n])) claim.slot[n] = claim.epoch + o;
+  }
+}

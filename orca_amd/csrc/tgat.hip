@@ -372,7 +372,7 @@ template <int KT, int DE>
 __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restrict__ blob, int d_e_rt,
                                                           orca_tgat_inputs in, int64_t Q, int K_rt,
                                                           float* __restrict__ out, float* __restrict__ out_w,
-                                                          long long* __restrict__ phase_clock) {
+                                                          orca_tgat_side side, long long* __restrict__ phase_clock) {
   extern __shared__ __align__(16) float lds[];
   // optional profiling aid (orca_debug_tgat_phase_clock): wave 0 of each workgroup stamps the 100 MHz
   // real-time counter at every phase boundary
@@ -430,6 +430,11 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     const float* tab = (in.src_flags && in.src_flags[row]) ? in.src_overlay : in.src_table;
     sa = tab[row * D + lane];
     sb = c1 < D ? tab[row * D + c1] : 0.f;
+    if (side.persist_memory && q < side.persist_n && tab == in.src_overlay) {   // fused memory persist (common.h)
+      side.persist_memory[row * D + lane] = sa;
+      if (c1 < D) side.persist_memory[row * D + c1] = sb;
+      if (lane == 0) side.persist_last_update[row] = side.persist_msg_ts[row];
+    }
     if (in.dt) {    // embedding_module.py:126: the source's own time encoding is cos(0*w + b)
       sta = orca_cosf(orca_time_arg(0.0f, in.time_w[lane], in.time_b[lane]));
       stb = c1 < D ? orca_cosf(orca_time_arg(0.0f, in.time_w[c1], in.time_b[c1])) : 0.f;
@@ -663,8 +668,14 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     float da = ya - mean, db = c1 < D ? yb - mean : 0.f;
     float var = wave_sum(da * da + db * db) * (1.0f / D);
     float rstd = 1.0f / sqrtf(var + 1e-5f);
-    out[q * D + lane] = da * rstd * ln_ga + ln_ba;
-    if (c1 < D) out[q * D + c1] = db * rstd * ln_gb + ln_bb;
+    const float oa = da * rstd * ln_ga + ln_ba, ob = db * rstd * ln_gb + ln_bb;
+    out[q * D + lane] = oa;
+    if (c1 < D) out[q * D + c1] = ob;
+    if (side.push_table && side.push_winner[q]) {   // fused history push of the winner rows (common.h)
+      const int64_t id = side.push_ids[q];
+      side.push_table[id * D + lane] = oa;
+      if (c1 < D) side.push_table[id * D + c1] = ob;
+    }
   }
   stamp();
 }
@@ -681,6 +692,12 @@ ORCA_API int orca_debug_tgat_phase_clock(void* buf) {
 
 ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
                                float* out_weights, void* stream) {
+  return orca_tgat_forward_side(blob, d_e, in, Q, K, out, out_weights, nullptr, stream);
+}
+
+int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
+                           float* out_weights, const orca_tgat_side* side_, void* stream) {
+  const orca_tgat_side side = side_ ? *side_ : orca_tgat_side{};
   ORCA_REQUIRE(Q >= 0, "orca_tgat_forward: Q=%lld < 0", (long long)Q);
   if (Q == 0) return ORCA_OK;   // empty batch (an empty tensor has no address)
   ORCA_REQUIRE(blob && in && out, "orca_tgat_forward: null pointer");
@@ -707,11 +724,11 @@ ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_input
   const unsigned grid = (unsigned)ceil_div64(Q, TQ);
   hipStream_t st = (hipStream_t)stream;
   if (K == 10 && d_e == 172)
-    ORCA_LAUNCH_TIMED((k_tgat_forward<10, 172>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
+    ORCA_LAUNCH_TIMED((k_tgat_forward<10, 172>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, side, g_phase_clock);
   else if (K == 10)
-    ORCA_LAUNCH_TIMED((k_tgat_forward<10, 0>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
+    ORCA_LAUNCH_TIMED((k_tgat_forward<10, 0>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, side, g_phase_clock);
   else
-    ORCA_LAUNCH_TIMED((k_tgat_forward<0, 0>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, g_phase_clock);
+    ORCA_LAUNCH_TIMED((k_tgat_forward<0, 0>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, side, g_phase_clock);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
