@@ -280,9 +280,13 @@ int orca_engine_set_csr(orca_engine_t* e, const orca_csr_t* csr);           /* t
 int64_t orca_engine_take_epochs(orca_engine_t* e, int64_t n);
 /* Builds the Q = 3*bs root queries [src;dst;neg] x [t;t;t]; for this rank's slice [lo,hi) of them: samples
  * the K most recent neighbours, (train) applies GRU(message, memory) for the rows it will read into the
- * overlay, runs attention layer 1 -> emb[0][lo:hi).  embedding_module.py:156-177 */
+ * overlay, runs attention layer 1 -> emb[0][lo:hi).  embedding_module.py:156-177
+ * eidx (the batch's edge ids, tgn_model.py:95) may be NULL; when given, and the slice is the whole batch in
+ * train order, the raw-message store of orca_engine_finish is done by the last attention kernel.  The batch
+ * arrays must stay valid and unchanged until orca_engine_finish has been enqueued. */
 int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
-                      const double* ts, int64_t bs, int64_t lo, int64_t hi, int train, void* stream);
+                      const int64_t* eidx, const double* ts, int64_t bs, int64_t lo, int64_t hi, int train,
+                      void* stream);
 /* layer in 2..n_layers: pushes ALL Q rows of the previous layer's output into the layer's history table
  * (callers with several ranks all-gather emb[layer&1] first), then attention over the pulled rows for the
  * slice -> emb[(layer+1)&1][lo:hi).  embedding_module.py:103-113,177-181 */

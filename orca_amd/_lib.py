@@ -81,7 +81,7 @@ SIGNATURES = {
     "orca_engine_profile_read": (i32, [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]),
     "orca_engine_set_csr": (i32, [vp, vp]),
     "orca_engine_take_epochs": (i64, [vp, i64]),
-    "orca_engine_begin": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
+    "orca_engine_begin": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
     "orca_engine_layer": (i32, [vp, i32, i64, i64, vp]),
     "orca_engine_finish": (i32, [vp, vp, vp, vp, vp, vp]),
     "orca_mrd_plan_host": (i32, [i64, i64, i32, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]),

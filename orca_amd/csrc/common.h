@@ -60,6 +60,9 @@ int orca_message_store_winners(const int64_t* src, const int64_t* dst, const int
 //           safe inside the kernel because a flagged row of the memory table is read by nobody: flagged reads go
 //           to the overlay);
 //  push   : the output row of query q also goes to push_table[push_ids[q]] when push_winner[q] (history.py:26-30).
+//  store  : wave q < 2*store_bs also builds and stores the raw message of position q of [src;dst] when
+//           store_winner[q] (tgn_model.py:172-191 + memory.py:25-28).  Only for a kernel that reads none of the
+//           memory / message / pending tables (an inner-history layer), after the persist of the same batch.
 struct orca_tgat_side {
   float* persist_memory;
   float* persist_last_update;
@@ -68,6 +71,16 @@ struct orca_tgat_side {
   float* push_table;
   const int64_t* push_ids;
   const uint8_t* push_winner;
+  int64_t store_bs;                 // 0 = no store
+  const int64_t* store_nodes;       // [src;dst;..] ids of the batch
+  const double* store_ts;           // [t;t;..]
+  const int64_t* store_eidx;        // [bs]
+  const uint8_t* store_winner;      // [2*bs]
+  const float* store_memory;
+  const float* store_last_update;
+  float* store_messages;
+  float* store_msg_ts;
+  uint8_t* store_pending;
 };
 int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
                            float* out_weights, const orca_tgat_side* side, void* stream);
@@ -171,6 +184,35 @@ __device__ __forceinline__ float orca_cosf(float x) {
 }
 // t·ω + φ exactly as nn.Linear(1, D) rounds it: one rounded product, then the bias add (no fma contraction)
 __device__ __forceinline__ float orca_time_arg(float t, float w, float b) { return __fadd_rn(__fmul_rn(t, w), b); }
+
+// Raw message of one interaction side, built and stored by one wavefront (model/tgn_model.py:172-191 +
+// modules/memory.py:25-28): messages[id] = [memory[id] | memory[partner] | edge_feats[eidx] | cos(w (t - last_update[id]) + b)],
+// msg_ts[id] = t, pending[id] = 1.
+__device__ __forceinline__ void message_store_wave(int64_t id, int64_t partner, int64_t eidx, double t,
+                                                   const float* __restrict__ memory,
+                                                   const float* __restrict__ last_update,
+                                                   const float* __restrict__ edge_feats, int d_e,
+                                                   const float* __restrict__ tw, const float* __restrict__ tb,
+                                                   float* __restrict__ messages, float* __restrict__ msg_ts,
+                                                   uint8_t* __restrict__ pending, int lane) {
+  const int msg_dim = 3 * ORCA_D + d_e;
+  float* row = messages + id * msg_dim;
+  const float tf = (float)t;                                      // tgn_model.py:181
+  const float delta = tf - last_update[id];                       // :187
+  const float* ms = memory + id * ORCA_D;
+  const float* md = memory + partner * ORCA_D;
+  const float* ef = edge_feats + eidx * d_e;
+  for (int c = lane; c < ORCA_D; c += 64) {
+    row[c] = ms[c];
+    row[ORCA_D + c] = md[c];
+    row[2 * ORCA_D + d_e + c] = orca_cosf(orca_time_arg(delta, tw[c], tb[c]));   // :188
+  }
+  for (int c = lane; c < d_e; c += 64) row[2 * ORCA_D + c] = ef[c];
+  if (lane == 0) {
+    msg_ts[id] = tf;
+    pending[id] = 1;
+  }
+}
 
 // generic strided pack kernel launcher (pack.hip)
 int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd, const float* src,

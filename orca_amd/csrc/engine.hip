@@ -22,6 +22,8 @@ struct orca_engine {
   bool winners_valid;          // begin() elected the last occurrences of the push / message-store id lists
   bool persist_done;           // the memory persist of the batch was fused into attention layer 1
   int pushed_layer;            // output of this layer is already in its history table (fused push), 0 = none
+  bool store_done;             // the raw-message store of the batch was fused into the last attention layer
+  const int64_t* eidx;         // batch edge ids handed to begin() (may be null)
   int profile;         // > 0: every profile-th step has HIP events attached to its sampler / GRU / attention launches
   int64_t step;        // steps begun since profiling was switched on
   bool timed_step;     // this step is one of those
@@ -146,6 +148,8 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   e->winners_valid = false;
   e->persist_done = false;
   e->pushed_layer = 0;
+  e->store_done = false;
+  e->eidx = nullptr;
   e->profile = 0;
   e->step = 0;
   e->timed_step = false;
@@ -201,7 +205,8 @@ ORCA_API int64_t orca_engine_take_epochs(orca_engine_t* e, int64_t n) {
 }
 
 ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
-                               const double* ts, int64_t bs, int64_t lo, int64_t hi, int train, void* stream_) {
+                               const int64_t* eidx, const double* ts, int64_t bs, int64_t lo, int64_t hi, int train,
+                               void* stream_) {
   ORCA_REQUIRE(e && e->d.csr, "orca_engine_begin: no neighbour finder set");
   const orca_engine_desc& d = e->d;
   hipStream_t stream = (hipStream_t)stream_;
@@ -214,6 +219,8 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   e->winners_valid = d.winners && Q <= ELECT_MAX;
   e->persist_done = false;
   e->pushed_layer = 0;
+  e->store_done = false;
+  e->eidx = eidx;
   if (bs == 0) return ORCA_OK;
   ORCA_REQUIRE(src && dst && neg && ts, "orca_engine_begin: null batch array");
   const int64_t n = hi - lo;
@@ -293,6 +300,15 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
     side.push_table = d.hist[layer - 1]; side.push_ids = d.nodes; side.push_winner = d.winners;
     e->pushed_layer = layer;
   }
+  // train order, whole batch on this rank, memory already persisted by layer 1: the last layer reads none of the
+  // memory / message tables, so its waves also build and store the raw messages (tgn_model.py:131-141)
+  if (layer == d.n_layers && lo == 0 && hi == e->Q && e->train && e->persist_done && e->winners_valid && e->eidx) {
+    side.store_bs = e->bs; side.store_nodes = d.nodes; side.store_ts = d.qts; side.store_eidx = e->eidx;
+    side.store_winner = d.winners + d.q_max;
+    side.store_memory = d.memory; side.store_last_update = d.last_update;
+    side.store_messages = d.messages; side.store_msg_ts = d.msg_ts; side.store_pending = d.pending;
+    e->store_done = true;
+  }
   Timed t(e, ORCA_PROF_TGAT, (hipStream_t)stream_);
   return orca_tgat_forward_side(d.att_blob[layer - 1], d.d_e, &in, hi - lo, d.K, next + lo * ORCA_D, nullptr, &side, stream_);
 }
@@ -329,6 +345,7 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
     return orca_set_flags(d.pending, d.nodes, nullptr, 2 * bs, nullptr, 0, stream_);
   };
   auto store = [&]() -> int {     // tgn_model.py:131-141,172-191 + memory.py:25-28
+    if (e->store_done) return ORCA_OK;   // the last attention layer stored the messages (orca_tgat_side)
     if (e->winners_valid)
       return orca_message_store_winners(src, dst, eidx, ts, bs, d.memory, d.last_update, d.edge_feats, d.d_e, d.time_w,
                                         d.time_b, d.winners + d.q_max, d.n_nodes, d.messages, d.msg_ts, d.pending, stream_);

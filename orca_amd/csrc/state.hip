@@ -137,23 +137,7 @@ __global__ __launch_bounds__(256) void k_message_store(const int64_t* __restrict
   const int64_t id = p < bs ? src[e] : dst[e];
   const int64_t partner = p < bs ? dst[e] : src[e];
   if (id < 0 || id >= n_nodes || (winner ? !winner[p] : slot[id] != epoch + p)) return;   // not the last occurrence of id
-  const int msg_dim = 3 * D + d_e;
-  float* row = messages + id * msg_dim;
-  const float tf = (float)t[e];                                   // tgn_model.py:181
-  const float delta = tf - last_update[id];                       // :187
-  const float* ms = memory + id * D;
-  const float* md = memory + partner * D;
-  const float* ef = edge_feats + eidx[e] * d_e;
-  for (int c = lane; c < D; c += 64) {
-    row[c] = ms[c];
-    row[D + c] = md[c];
-    row[2 * D + d_e + c] = orca_cosf(orca_time_arg(delta, tw[c], tb[c]));   // :188
-  }
-  for (int c = lane; c < d_e; c += 64) row[2 * D + c] = ef[c];
-  if (lane == 0) {
-    msg_ts[id] = tf;
-    pending[id] = 1;
-  }
+  message_store_wave(id, partner, eidx[e], t[e], memory, last_update, edge_feats, d_e, tw, tb, messages, msg_ts, pending, lane);
 }
 
 // memory_updater.update_memory (:25-39) when GRU(message, memory) of every pending id already sits in the

@@ -462,6 +462,15 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       }
     }
   }
+  // (the store's own loads and stores ride along with the gathers of this stage)
+  if (q < 2 * side.store_bs && side.store_winner[q]) {   // fused raw-message store of position q (common.h)
+    const int64_t bs = side.store_bs;
+    const int64_t id = side.store_nodes[q], partner = side.store_nodes[q < bs ? q + bs : q - bs];
+    if (id >= 0)
+      message_store_wave(id, partner, side.store_eidx[q < bs ? q : q - bs], side.store_ts[q], side.store_memory,
+                         side.store_last_update, in.edge_table, d_e, in.time_w, in.time_b, side.store_messages,
+                         side.store_msg_ts, side.store_pending, lane);
+  }
   // the time encodings of slots 0..KC-1 need only dt: all VALU, computed while the loads above are in flight
   KeyTimes T;
   if (live_q) encode_key_times(T, in, S, 0, K, lane);

@@ -227,7 +227,7 @@ class OrcaEngine:
     self._ensure_native(Q)
     lo, hi, per = self._slice(Q)
     st = stream()
-    check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(ts), bs, lo, hi, int(train), st),
+    check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, lo, hi, int(train), st),
           "orca_engine_begin")
     emb = self._w["emb"]
     for layer in range(2, self.L + 1):
