@@ -165,22 +165,26 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // cos(x) for the time encoder (model/time_encoding.py:27).  Arguments reach 2.6e6 (Δt in seconds times
-// ω_0 = 1), where the libm cosf takes its slow Payne-Hanek path; here the range reduction
-// x = n·π/2 + r is done in fp64 (full rate on CDNA4; two-constant π/2, error < 1e-9 for |x| < 1e9) and the
-// kernel polynomials in fp32 (|r| <= π/4).  Absolute error < 2e-7, i.e. ~2 ulp of the O(1) result.
+// ω_0 = 1), where the libm cosf takes its slow Payne-Hanek path; here the range reduction x = n·π + r is done
+// in fp64 (two-constant π, error < 1e-9 for |x| < 2^31·π) and cos(r), |r| <= π/2, is ONE even polynomial of
+// degree 12 in fp32 (Chebyshev fit; with the fp32 Horner rounding its absolute error is < 9.1e-8), the sign
+// coming from the parity of n.  17 instructions, 7 of them fp64: the attention kernel evaluates 22 of these per
+// lane and query, which made its gather stage VALU-bound with the two-polynomial quadrant form.
 __device__ __forceinline__ float orca_cosf(float x) {
   const double xd = (double)x;
-  const double n = __builtin_rint(xd * 0.63661977236758134308);
-  double r = __builtin_fma(-n, 1.57079632679489655800e+00, xd);
-  r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
-  const int q = (int)((long long)n & 3LL);
+  const double n = __builtin_rint(xd * 0.31830988618379069122);
+  double r = __builtin_fma(-n, 3.14159265358979311600e+00, xd);
+  r = __builtin_fma(-n, 1.22464679914735320717e-16, r);
+  const unsigned sign = (unsigned)(int)n << 31;
   const float rf = (float)r;
-  const float r2 = rf * rf;
-  const float s = __builtin_fmaf(rf * r2, __builtin_fmaf(r2, __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), rf);
-  const float c = __builtin_fmaf(r2 * r2, __builtin_fmaf(r2, __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
-                                 __builtin_fmaf(r2, -0.5f, 1.0f));
-  const float v = (q & 1) ? s : c;
-  return (q == 1 || q == 2) ? -v : v;
+  const float u = rf * rf;
+  float p = __builtin_fmaf(u, 1.9906489790e-09f, -2.7524603752e-07f);
+  p = __builtin_fmaf(u, p, 2.4801038307e-05f);
+  p = __builtin_fmaf(u, p, -1.3888884569e-03f);
+  p = __builtin_fmaf(u, p, 4.1666667908e-02f);
+  p = __builtin_fmaf(u, p, -0.5f);
+  p = __builtin_fmaf(u, p, 1.0f);
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p) ^ sign);
 }
 // t·ω + φ exactly as nn.Linear(1, D) rounds it: one rounded product, then the bias add (no fma contraction)
 __device__ __forceinline__ float orca_time_arg(float t, float w, float b) { return __fadd_rn(__fmul_rn(t, w), b); }
