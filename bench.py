@@ -29,6 +29,25 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC = os.path.join(ROOT, "tools", "pmc_traffic.json")   # from separate rocprofv3 --pmc passes of this command
+
+
+def pmc_traffic(args):
+  """HBM bytes per k_tgat_forward launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950
+  correction of MI355X_MICROARCH.md), or None when the workload differs from the one the passes were taken on."""
+  try:
+    with open(PMC_TRAFFIC) as f:
+      t = json.load(f)
+  except (OSError, ValueError):
+    return None
+  w = t.get("workload", {})
+  same = (w.get("nodes") == args.nodes and w.get("edges") == args.edges and w.get("d_e") == args.d_e and
+          w.get("bs") == args.bs and w.get("k") == args.k and w.get("layers") == args.layers and
+          w.get("reuse") == (not args.no_reuse))
+  k = t.get("k_tgat_forward")
+  if not same or not k:
+    return None
+  return (2.0 * k["fetch_size_kb"] + k["write_size_kb"]) * 1024.0
 
 
 def parse():
@@ -187,7 +206,8 @@ def main():
       flops = synth.tgat_flops_per_query(args.d_e, args.k) * q_mean
       ach = flops / (ms * 1e-3) / 1e12
       out["roofline"] = {"kernel": "k_tgat_forward", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(args),
+                         "traffic_unit": "HBM bytes per launch (profiles/r01_pmc_hbm_traffic.md)",
                          "launches": n, "avg_launch_ms": ms, "queries_per_launch": q_mean,
                          "flops_per_query": synth.tgat_flops_per_query(args.d_e, args.k),
                          "bytes_per_query": synth.tgat_bytes_per_query(args.d_e, args.k),

@@ -22,8 +22,9 @@ def main(db, out, title):
           cells.append(s if len(s) <= 90 else s[:87] + "...")
       f.write("| " + " | ".join(cells) + " |\n")
     try:
-      rows = c.execute("select name, counter_name, avg(value), count(*) from counters_collection "
-                       "group by name, counter_name order by name").fetchall()
+      rows = c.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                       "where kernel_name like '%k_%' and kernel_name not like '%at::native%' and kernel_name not like '%rocprim%' "
+                       "group by kernel_name, counter_name order by kernel_name").fetchall()
     except sqlite3.Error:
       rows = []
     if rows:
