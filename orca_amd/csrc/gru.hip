@@ -1,12 +1,13 @@
 // GRU memory updater (modules/memory_updater.py:25-86 of the reference: nn.GRUCell(msg_dim -> 100)
-// applied to the nodes that hold a pending raw message) as one MFMA kernel with a fused gate epilogue.
-//
-// A workgroup owns TR = 16*MT rows (nodes).  Their [message | memory] rows are gathered once into
-// LDS; wave t (7 waves) owns hidden units 16t..16t+15 and accumulates, for each of its MT row tiles,
-// the four pre-activations r, z, i_n, h_n of those units on v_mfma_f32_16x16x4_f32 -- so the gate
-// math (sigmoid, tanh, blend with the old memory) happens in the accumulator registers and the new
-// memory row is written straight to its table: in place (persist) or into the overlay table that
-// replaces the reference's per-batch full-table clone (memory_updater.py:72,76).
+// applied to the nodes that hold a pending raw message) on v_mfma_f32_16x16x4_f32 with a fused gate epilogue:
+// the four pre-activations r, z, i_n, h_n of 16 rows x 16 hidden units accumulate in registers, so the gate
+// math (sigmoid, tanh, blend with the old memory) never leaves them and the new memory row is written
+// straight to its table: in place (persist) or into the overlay table that replaces the reference's
+// per-batch full-table clone (memory_updater.py:72,76).  Three kernels, chosen by orca_gru_update:
+//   k_gru_split  : out of place, device-counted or small row counts -- 4 waves split the reduction of one
+//                  (16 rows) x (16 hidden units) tile, looping grid;
+//   k_gru_stream : out of place, many rows -- one wave per tile, 37-step register ring;
+//   k_gru_rows   : in-place-safe (a row is read and written by one workgroup), any message width.
 #include <type_traits>
 #include <utility>
 #include "common.h"

@@ -1,8 +1,12 @@
 // Fused TGAT attention layer (model/temporal_attention.py:24-56 of the reference) for gfx950.
 //
-// One workgroup (8 waves) owns TQ = 16 queries and runs the whole layer on them without touching
-// HBM in between: gather -> time encoding -> projections on v_mfma_f32_16x16x4_f32 -> masked
-// softmax over the K neighbours with wave shuffles -> output projection -> MergeLayer -> LayerNorm.
+// One workgroup (16 waves) owns TQ = 16 queries -- one MFMA M tile -- and runs the whole layer on them
+// without touching HBM in between: gather -> time encoding -> projections on v_mfma_f32_16x16x4_f32 ->
+// masked softmax over the K neighbours with wave shuffles -> output projection -> MergeLayer -> LayerNorm.
+// In the per-query stages wave m owns query m; in the GEMM stages the 16 waves split the N tiles
+// (WaveGemm).  At the batch shape of the benchmark (4095 queries) that is one workgroup per CU: there is no
+// second tile to overlap stages with, so every stage requests the next stage's weights before its barrier
+// and the (K = 10, d_e = 172) specialisation unrolls every chain branch-free.
 //
 // Algebra.  nn.MultiheadAttention with one query per K keys computes, per head h,
 //   s_j = (0.1*q_h) . (Wk_h x_j + bk_h),  a = softmax_j(s),  o_h = sum_j a_j (Wv_h x_j + bv_h).
