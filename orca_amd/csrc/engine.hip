@@ -34,37 +34,54 @@ thread_local orca_launch_events orca_armed_events = {nullptr, nullptr};
 
 namespace {
 
-// Last-occurrence election of a whole id list inside ONE workgroup: an LDS hash table keyed by id holds the
-// highest position seen (LDS atomics: hub ids of a power-law batch repeat hundreds of times, and the same
-// election with global atomicMax serialises on them at L2).  winner[p] = 1 iff p is the last position of its id.
+// Last-occurrence election of an id list in LDS: a hash table keyed by id holds the highest position seen (LDS
+// atomics: hub ids of a power-law batch repeat hundreds of times, and the same election with global atomicMax
+// serialises on them at L2).  winner[p] = 1 iff p is the last position of its id.  A list longer than one table
+// holds is split over `parts` workgroups by id (part g owns the ids with id % parts == g): every workgroup scans
+// the whole list and elects its own ids.
 constexpr int ELECT_THREADS = 1024;
 constexpr int ELECT_SLOTS = 8192;          // 2 x 32 KiB of LDS
-constexpr int64_t ELECT_MAX = 6144;        // ids per list (load factor <= 0.75)
+constexpr int64_t ELECT_MAX = 6144;        // ids per table (load factor <= 0.75)
+constexpr int ELECT_PARTS_MAX = 8;         // lists up to 49,152 ids
 
+__device__ __forceinline__ int elect_part(int64_t id, int parts) { return (int)((((uint32_t)id * 0x85EBCA6Bu) >> 16) % (uint32_t)parts); }
+
+// An id that finds its table full (only possible when far more distinct ids hash to one part than the sizing
+// assumes) is elected by scanning the rest of the list for a later occurrence: slow, but a full table stays
+// full, so every occurrence of that id takes the same route and the result stays exact.
 template <typename GetId>
 __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64_t n, int64_t n_nodes, GetId get,
-                                             uint8_t* __restrict__ winner) {
+                                             uint8_t* __restrict__ winner, int part, int parts) {
   for (int i = threadIdx.x; i < ELECT_SLOTS; i += ELECT_THREADS) { keys[i] = -1; vals[i] = -1; }
   __syncthreads();
   for (int64_t p = threadIdx.x; p < n; p += ELECT_THREADS) {
     const int64_t id = get(p);
-    if (id < 0 || id >= n_nodes) continue;
+    if (id < 0 || id >= n_nodes || elect_part(id, parts) != part) continue;
     uint32_t h = ((uint32_t)id * 2654435761u) >> 19;
-    for (;;) {
+    int probes = 0;
+    for (; probes < ELECT_SLOTS; ++probes) {
       const int32_t old = atomicCAS(&keys[h], -1, (int32_t)id);
       if (old == -1 || old == (int32_t)id) break;
       h = (h + 1) & (ELECT_SLOTS - 1);
     }
-    atomicMax(&vals[h], (int32_t)p);
+    if (probes < ELECT_SLOTS) atomicMax(&vals[h], (int32_t)p);
   }
   __syncthreads();
   for (int64_t p = threadIdx.x; p < n; p += ELECT_THREADS) {
     const int64_t id = get(p);
+    const bool valid = id >= 0 && id < n_nodes;
+    if (valid ? elect_part(id, parts) != part : part != 0) continue;   // another part's id (invalid ids: part 0)
     uint8_t w = 0;
-    if (id >= 0 && id < n_nodes) {
+    if (valid) {
       uint32_t h = ((uint32_t)id * 2654435761u) >> 19;
-      while (keys[h] != (int32_t)id) h = (h + 1) & (ELECT_SLOTS - 1);
-      w = vals[h] == (int32_t)p;
+      int probes = 0;
+      while (probes < ELECT_SLOTS && keys[h] != (int32_t)id) { h = (h + 1) & (ELECT_SLOTS - 1); ++probes; }
+      if (probes < ELECT_SLOTS) {
+        w = vals[h] == (int32_t)p;
+      } else {
+        w = 1;
+        for (int64_t p2 = p + 1; p2 < n; ++p2) if (get(p2) == id) { w = 0; break; }
+      }
     }
     winner[p] = w;
   }
@@ -74,19 +91,20 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
 // (tgn_model.py:99-102) is written to nodes / qts / nodes32 and, when i lies in this rank's slice [lo, hi), its K
 // most recent neighbours are sampled into row i - lo of the sampler outputs (embedding_module.py:157), with the
 // claim pass of the overlay work-list in train order.
-// block nb   (elect only): winners of the history push over all 3*bs roots (embedding_module.py:103-113, H7)
-// block nb+1 (elect only): winners of the raw-message store over [src;dst]  (message_aggregator.py last-message)
+// blocks nb .. nb+parts-1        (elect only): winners of the history push over all 3*bs roots (embedding_module.py:103-113, H7)
+// blocks nb+parts .. nb+2parts-1 (elect only): winners of the raw-message store over [src;dst]  (tgn_model.py:174-176)
 __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
-    int32_t* __restrict__ nodes32, int nb, int64_t n_nodes, uint8_t* __restrict__ win_push, uint8_t* __restrict__ win_msg,
+    int32_t* __restrict__ nodes32, int nb, int parts, int64_t n_nodes, uint8_t* __restrict__ win_push,
+    uint8_t* __restrict__ win_msg,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ c_nbr, const int32_t* __restrict__ c_eid,
     const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int K, int32_t* __restrict__ o_nbr,
     int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt, orca_claim claim) {
   __shared__ int32_t keys[ELECT_SLOTS], vals[ELECT_SLOTS];
   auto root = [&](int64_t i) { return i < bs ? src[i] : (i < 2 * bs ? dst[i - bs] : neg[i - 2 * bs]); };
-  if ((int)blockIdx.x == nb) { elect_in_lds(keys, vals, 3 * bs, n_nodes, root, win_push); return; }
-  if ((int)blockIdx.x == nb + 1) { elect_in_lds(keys, vals, 2 * bs, n_nodes, root, win_msg); return; }
+  if ((int)blockIdx.x >= nb + parts) { elect_in_lds(keys, vals, 2 * bs, n_nodes, root, win_msg, (int)blockIdx.x - nb - parts, parts); return; }
+  if ((int)blockIdx.x >= nb) { elect_in_lds(keys, vals, 3 * bs, n_nodes, root, win_push, (int)blockIdx.x - nb, parts); return; }
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
   if (i >= 3 * bs) return;
@@ -216,7 +234,8 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   e->bs = bs; e->Q = Q; e->train = train;
   e->timed_step = e->profile > 0 && (e->step++ % e->profile) == 0;
   e->overlay_covers_batch = train && lo == 0 && hi == Q;
-  e->winners_valid = d.winners && Q <= ELECT_MAX;
+  const int parts = (int)ceil_div64(Q > 0 ? Q : 1, ELECT_MAX);
+  e->winners_valid = d.winners && parts <= ELECT_PARTS_MAX;
   e->persist_done = false;
   e->pushed_layer = 0;
   e->store_done = false;
@@ -235,8 +254,8 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     const orca_claim claim = (train && n > 0) ? orca_claim{d.pending, d.slot, claim_epoch, d.n_nodes, d.count} : orca_claim{};
     const int nb = (int)ceil_div64(Q, ELECT_THREADS / 64);
     Timed t(e, ORCA_PROF_SAMPLE, stream);
-    ORCA_LAUNCH_TIMED(k_begin_queries, (unsigned)(nb + (e->winners_valid ? 2 : 0)), ELECT_THREADS, 0, stream, src, dst, neg, ts,
-                      bs, d.nodes, d.qts, d.nodes32, nb, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr,
+    ORCA_LAUNCH_TIMED(k_begin_queries, (unsigned)(nb + (e->winners_valid ? 2 * parts : 0)), ELECT_THREADS, 0, stream, src, dst, neg, ts,
+                      bs, d.nodes, d.qts, d.nodes32, nb, parts, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr,
                       indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, K, d.nbr, d.eid, d.et, d.dt, claim);
     ORCA_LAUNCH_CHECK();
   }

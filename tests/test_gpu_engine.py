@@ -85,8 +85,8 @@ def test_config4_batch_shape_vs_oracle(golden, reuse, bs):
   """4096-query batches (bs = 1365 interactions + 1 padding query is the bench shape; here bs=1365),
   K = 10, 2 layers, 172-d edge features on a 20k-node / 300k-edge power-law graph: the HIP step
   against the oracle over several consecutive batches (state carried), plus properties.  bs = 2200
-  (6600 roots) is past the size the native driver elects last occurrences in LDS for, so it covers the
-  global-atomic elections."""
+  (6600 roots) is past what one LDS election table of the native driver holds, so it covers the
+  elections split over two workgroups."""
   from orca_amd import ops
   from orca_amd.engine import OrcaEngine
   g = golden("tgn.npz")
@@ -122,3 +122,40 @@ def test_config4_batch_shape_vs_oracle(golden, reuse, bs):
     inv = inv.reshape(-1)
     assert np.array_equal(emb, emb[first][inv])
   assert_close_fp32(eng.messages.cpu().numpy(), ref.messages.numpy(), 1e-5, "messages")
+
+
+def test_election_table_overflow_vs_oracle(golden):
+  """The native driver elects last occurrences in LDS hash tables, one per part of the ids (a hash of the id
+  picks the part).  Here every id of a 9000-root batch is chosen to fall into part 0 of 2, so that table
+  (8192 slots) overflows and the late ids take the exact fallback; the tail of each list repeats ids so
+  the fallback has real duplicates to resolve."""
+  from orca_amd import ops
+  from orca_amd.engine import OrcaEngine
+  g = golden("tgn.npz")
+  sd = {k[len("g172_sd."):]: g[k] for k in g.files if k.startswith("g172_sd.")}
+  N, E, bs, K = 60000, 120000, 3000, 10
+  src, dst, ts, eidx, ef = _synthetic(11, N, E, 172)
+  ids = np.arange(1, N + 1, dtype=np.int64)
+  part0 = ids[((((ids * 0x85EBCA6B) & 0xFFFFFFFF) >> 16) % 2) == 0]
+  assert part0.size >= 3 * bs
+  rs = np.random.RandomState(12)
+  pool = rs.permutation(part0)[:3 * bs]
+  b_src, b_dst, b_neg = pool[:bs].copy(), pool[bs:2 * bs].copy(), pool[2 * bs:].copy()
+  b_dst[-300:] = np.repeat(b_dst[-300:-150], 2)     # duplicates among the late ids of [src;dst]
+  b_neg[-400:] = np.tile(b_neg[-400:-200], 2)       # and of [src;dst;neg]
+  b_src[:50] = b_dst[-50:]                          # early ids that recur late
+  eng = OrcaEngine(sd, ef, N + 1, 2, K, True, 0, device=DEV)
+  eng.set_neighbor_finder(ops.CSR.from_edges_device(*(torch.from_numpy(x).to(DEV) for x in (src, dst, eidx, ts)), N + 1))
+  ref = O.OracleTGN(sd, ef, N + 1, 2, K, True, 0)
+  ref.neighbor_finder = O.OracleNeighborFinder(src, dst, eidx, ts, max_node_idx=N)
+  for b in range(2):       # the second batch reads the messages / history the first one stored
+    t = np.sort(rs.uniform(2.7e6 + b * 1e3, 2.7e6 + (b + 1) * 1e3, bs))
+    e = rs.randint(1, E + 1, bs).astype(np.int64)
+    emb = eng.compute_temporal_embeddings(b_src, b_dst, b_neg, t, e, True).cpu().numpy()
+    exp = ref.compute_temporal_embeddings(b_src, b_dst, b_neg, t, e, True).numpy()
+    assert_close_fp32(emb, exp, 1e-5, f"batch {b} emb")
+    assert_close_fp32(eng.memory.cpu().numpy(), ref.memory.numpy(), 1e-5, f"batch {b} memory")
+    assert_close_fp32(eng.hist[0].cpu().numpy(), ref.hist[0].numpy(), 1e-5, f"batch {b} history")
+    assert np.array_equal(eng.pending.cpu().numpy().astype(bool), ref.pending)
+  assert_close_fp32(eng.messages.cpu().numpy(), ref.messages.numpy(), 1e-5, "messages")
+  assert np.array_equal(eng.msg_ts.cpu().numpy(), ref.msg_ts.numpy())
