@@ -262,6 +262,10 @@ typedef struct {
   float* emb[2];                   /* [q_max, ORCA_D] each: layer outputs ping-pong (layer l -> emb[(l+1)&1]) */
   uint8_t* winners;                /* [2*q_max] last-occurrence flags of the push / message-store id lists; may be
                                       NULL (the elections then run on `slot` with global atomics) */
+  float* upd;                      /* [q_max, ORCA_D] or NULL: for a rank that embeds a slice in train order, the
+                                      updated memory row of each of its roots (rows lo..hi); the caller all-gathers
+                                      the buffer before orca_engine_finish, which then commits the positives' rows
+                                      from it instead of recomputing the GRU of every rank's positives */
 } orca_engine_desc;
 
 int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** out);

@@ -37,7 +37,7 @@ class EngineDesc(ctypes.Structure):
                ("messages", vp), ("msg_ts", vp), ("pending", vp), ("overlay", vp),
                ("hist", vp * (ORCA_ENGINE_MAX_LAYERS - 1)), ("slot", vp), ("worklist", vp), ("count", vp),
                ("q_max", i64), ("nodes", vp), ("qts", vp), ("nodes32", vp), ("nbr", vp), ("eid", vp), ("et", vp),
-               ("dt", vp), ("emb", vp * 2), ("winners", vp)])
+               ("dt", vp), ("emb", vp * 2), ("winners", vp), ("upd", vp)])
 
 
 # name -> (restype, argtypes); every symbol include/orca_hip.h declares

@@ -46,6 +46,10 @@ int orca_sample_recent_claim(const orca_csr_t* c, const int64_t* nodes, const do
 int orca_worklist_append(const int32_t* ids32, int64_t n32, const int64_t* ids64, int64_t n64, const uint8_t* flags,
                          const int64_t* slot, int64_t epoch, int64_t n_nodes, int32_t* worklist, int32_t* count,
                          void* stream);
+// memory[ids[p]] = rows[p], last_update[ids[p]] = msg_ts[ids[p]] for the positions whose id is pending (the
+// row commit of update_memory, memory_updater.py:36-39, from rows gathered by position)
+int orca_persist_rows(const int64_t* ids, int64_t n, const uint8_t* pending, const float* rows, float* memory,
+                      float* last_update, const float* msg_ts, int64_t n_nodes, void* stream);
 // orca_history_push / orca_message_store with the last-occurrence winners precomputed (winner[p] != 0)
 int orca_history_push_winners(float* emb, const float* x, const int64_t* ids, int64_t n, const uint8_t* winner,
                               int64_t n_nodes, void* stream);
@@ -81,6 +85,9 @@ struct orca_tgat_side {
   float* store_messages;
   float* store_msg_ts;
   uint8_t* store_pending;
+  float* src_rows_out;              // [Q, ORCA_D] or null: the (overlay-resolved) source row of every query, i.e. the
+                                    // root's memory after its pending message is applied -- what a multi-rank step
+                                    // all-gathers so that no rank has to redo the GRU of another rank's positives
 };
 int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
                            float* out_weights, const orca_tgat_side* side, void* stream);

@@ -22,6 +22,7 @@ struct orca_engine {
   bool winners_valid;          // begin() elected the last occurrences of the push / message-store id lists
   bool persist_done;           // the memory persist of the batch was fused into attention layer 1
   int pushed_layer;            // output of this layer is already in its history table (fused push), 0 = none
+  bool upd_rows;               // layer 1 wrote the updated memory rows of this rank's roots to d.upd (sliced train step)
   bool store_done;             // the raw-message store of the batch was fused into the last attention layer
   const int64_t* eidx;         // batch edge ids handed to begin() (may be null)
   int profile;         // > 0: every profile-th step has HIP events attached to its sampler / GRU / attention launches
@@ -167,6 +168,7 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   e->persist_done = false;
   e->pushed_layer = 0;
   e->store_done = false;
+  e->upd_rows = false;
   e->eidx = nullptr;
   e->profile = 0;
   e->step = 0;
@@ -239,6 +241,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   e->persist_done = false;
   e->pushed_layer = 0;
   e->store_done = false;
+  e->upd_rows = false;
   e->eidx = eidx;
   if (bs == 0) return ORCA_OK;
   ORCA_REQUIRE(src && dst && neg && ts, "orca_engine_begin: null batch array");
@@ -285,6 +288,10 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     side.persist_memory = d.memory; side.persist_last_update = d.last_update; side.persist_msg_ts = d.msg_ts;
     side.persist_n = 2 * bs;
     e->persist_done = true;
+  }
+  if (train && !e->overlay_covers_batch && d.upd) {   // a slice: hand the roots' updated rows to the other ranks
+    side.src_rows_out = d.upd + lo * ORCA_D;
+    e->upd_rows = true;
   }
   if (lo == 0 && hi == Q && e->winners_valid && d.n_layers >= 2) {
     side.push_table = d.hist[0]; side.push_ids = d.nodes; side.push_winner = d.winners;
@@ -346,6 +353,8 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
     // batch): the rows are committed by one kernel, and the flags need no clearing because the message store
     // that follows sets them for exactly these ids.
     if (e->persist_done) return ORCA_OK;   // attention layer 1 committed the rows (orca_tgat_side)
+    if (e->upd_rows && e->train)        // rows all-gathered from the ranks that own the roots (orca_engine_desc.upd)
+      return orca_persist_rows(d.nodes, 2 * bs, d.pending, d.upd, d.memory, d.last_update, d.msg_ts, d.n_nodes, stream_);
     if (e->overlay_covers_batch)
       return orca_persist_overlay(d.nodes, 2 * bs, d.pending, d.overlay, d.memory, d.last_update, d.msg_ts, d.n_nodes,
                                   stream_);

@@ -148,13 +148,15 @@ __global__ __launch_bounds__(256) void k_persist_overlay(const int64_t* __restri
                                                          const uint8_t* __restrict__ pending,
                                                          const float* __restrict__ overlay, float* __restrict__ memory,
                                                          float* __restrict__ last_update,
-                                                         const float* __restrict__ msg_ts, int64_t n_nodes) {
+                                                         const float* __restrict__ msg_ts, int64_t n_nodes,
+                                                         bool by_position) {
   const int lane = threadIdx.x & 63;
   const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= n) return;
   const int64_t id = ids[p];
   if (id < 0 || id >= n_nodes || !pending[id]) return;
-  for (int c = lane; c < D; c += 64) memory[id * D + c] = overlay[id * D + c];
+  const float* row = overlay + (by_position ? p : id) * D;   // a table indexed by id, or rows gathered per position
+  for (int c = lane; c < D; c += 64) memory[id * D + c] = row[c];
   if (lane == 0) last_update[id] = msg_ts[id];
 }
 
@@ -311,7 +313,16 @@ ORCA_API int orca_persist_overlay(const int64_t* ids, int64_t n, const uint8_t* 
   if (n == 0) return ORCA_OK;
   ORCA_REQUIRE(ids && pending && overlay && memory && last_update && msg_ts, "orca_persist_overlay: null pointer");
   k_persist_overlay<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(ids, n, pending, overlay, memory, last_update, msg_ts,
-                                                                  n_nodes);
+                                                                  n_nodes, false);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+int orca_persist_rows(const int64_t* ids, int64_t n, const uint8_t* pending, const float* rows, float* memory,
+                      float* last_update, const float* msg_ts, int64_t n_nodes, void* stream) {
+  if (n == 0) return ORCA_OK;
+  k_persist_overlay<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(ids, n, pending, rows, memory, last_update, msg_ts,
+                                                                  n_nodes, true);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

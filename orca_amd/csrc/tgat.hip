@@ -439,6 +439,10 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       if (c1 < D) side.persist_memory[row * D + c1] = sb;
       if (lane == 0) side.persist_last_update[row] = side.persist_msg_ts[row];
     }
+    if (side.src_rows_out) {
+      side.src_rows_out[q * D + lane] = sa;
+      if (c1 < D) side.src_rows_out[q * D + c1] = sb;
+    }
     if (in.dt) {    // embedding_module.py:126: the source's own time encoding is cos(0*w + b)
       sta = orca_cosf(orca_time_arg(0.0f, in.time_w[lane], in.time_b[lane]));
       stb = c1 < D ? orca_cosf(orca_time_arg(0.0f, in.time_w[c1], in.time_b[c1])) : 0.f;

@@ -167,7 +167,8 @@ class OrcaEngine:
                    et=torch.zeros(q_max * K, dtype=torch.float32, device=dev),
                    dt=torch.zeros(q_max * K, dtype=torch.float32, device=dev),
                    emb=[torch.zeros(q_max, D, dtype=torch.float32, device=dev) for _ in range(2)],
-                   winners=torch.zeros(2 * q_max, dtype=torch.uint8, device=dev))
+                   winners=torch.zeros(2 * q_max, dtype=torch.uint8, device=dev),
+                   upd=torch.zeros(q_max, D, dtype=torch.float32, device=dev) if self.world > 1 else None)
     d = _lib.EngineDesc()
     d.n_nodes, d.n_layers, d.K, d.d_e = self.N, self.L, K, self.d_e
     d.csr = self.csr._h if self.csr is not None else None
@@ -186,6 +187,7 @@ class OrcaEngine:
     d.nbr, d.eid, d.et, d.dt = ptr(w["nbr"]), ptr(w["eid"]), ptr(w["et"]), ptr(w["dt"])
     d.emb[0], d.emb[1] = ptr(w["emb"][0]), ptr(w["emb"][1])
     d.winners = ptr(w["winners"])
+    d.upd = ptr(w["upd"]) if w["upd"] is not None else None
     h = _lib.vp()
     check(L.orca_engine_create(ctypes.byref(d), ctypes.byref(h)), "orca_engine_create")
     L.orca_engine_take_epochs(h, self.slot_epoch)       # continue after the epochs already used on `slot`
@@ -230,6 +232,8 @@ class OrcaEngine:
     check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, lo, hi, int(train), st),
           "orca_engine_begin")
     emb = self._w["emb"]
+    if self.world > 1 and train:      # the roots' updated memory rows: finish() commits the positives from them
+      self._gather_in_place(self._w["upd"], per)
     for layer in range(2, self.L + 1):
       self._gather_in_place(emb[layer & 1], per)
       check(L.orca_engine_layer(self._native, layer, lo, hi, st), "orca_engine_layer")

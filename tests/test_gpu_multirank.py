@@ -50,6 +50,7 @@ def _worker(rank, world, port, q):
         c = single.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], train)
         ok = ok and torch.equal(a, c) and torch.equal(multi.memory, single.memory)
         ok = ok and torch.equal(multi.messages, single.messages) and torch.equal(multi.pending, single.pending)
+        ok = ok and torch.equal(multi.last_update, single.last_update) and torch.equal(multi.msg_ts, single.msg_ts)
         if reuse:
           ok = ok and torch.equal(multi.hist[0], single.hist[0])
     q.put((rank, bool(ok), ""))
