@@ -210,6 +210,7 @@ def main():
                          "traffic_unit": "HBM bytes per launch (profiles/r01_pmc_hbm_traffic.md)",
                          "launches": n, "avg_launch_ms": ms, "queries_per_launch": q_mean,
                          "flops_per_query": synth.tgat_flops_per_query(args.d_e, args.k),
+                         "flops_executed_per_query": synth.tgat_flops_executed_per_query(args.d_e, args.k),
                          "bytes_per_query": synth.tgat_bytes_per_query(args.d_e, args.k),
                          "hbm_gbs_algorithmic": synth.tgat_bytes_per_query(args.d_e, args.k) * q_mean / (ms * 1e-3) / 1e9}
       out["kernels_ms"] = {k: {"launches": v[0], "avg_ms": v[1]} for k, v in prof.items()}

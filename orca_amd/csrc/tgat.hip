@@ -14,8 +14,14 @@
 //   s_j = (Wk_h^T (0.1*q_h)) . x_j + (0.1*q_h).bk_h          o_h = Wv_h (sum_j a_j x_j) + bv_h
 // which is the same function (sum_j a_j = 1) at 1/10 of the multiply-adds for K = 10, and keeps the
 // [K, 200+d_e] key rows out of the matrix pipe: they are read twice by the owning wave (scores,
-// then the weighted sum) as plain coalesced rows.  The dense contractions that remain
-// (q, Wk^T q, Wv x, out_proj, fc1, fc2) run on MFMA with M = 16 queries.
+// then the weighted sum) as plain coalesced rows.
+// The linear tail is folded too.  Between the weighted key sum x-bar_h and the merger's ReLU everything is
+// linear:  fc1([Wo (Wv x-bar + bv) + bo | src]) = sum_h (W1a Wo_h Wv_h) x-bar_h + W1b src + b1 + W1a (Wo bv + bo),
+// so the value map, the output projection and fc1 are ONE matrix, multiplied out once in fp64 when the weights
+// are packed (orca_tgat_pack): a [100 x (2*k_dim + 1 + 100)] map instead of three stages with two barriers
+// and 1.7x its multiply-adds.  A query whose neighbours are all padding has attn = 0
+// (temporal_attention.py:52): its x-bar and the indicator column that carries the constant are zeroed.
+// The dense contractions that remain (q, Wk^T q, the folded tail, fc2) run on MFMA with M = 16 queries.
 #include "common.h"
 
 namespace {
@@ -25,12 +31,12 @@ constexpr int QD = 2 * D;          // query / embed dim 200
 constexpr int TQ = 16;             // queries per workgroup (one MFMA M tile)
 constexpr int NW = 16;             // waves per workgroup: one per query in the per-query stage
 constexpr int ASTR = 212;          // LDS row stride of the 200-wide activation buffers (== 4 mod 16)
-constexpr int MSTR = 308;          // LDS row stride of the 300-wide merger input
+constexpr int HSTR = 116;          // LDS row stride of the 112-wide hidden activation of the merger
 constexpr int MAXE = (ORCA_MAX_DE + 63) / 64;   // edge-feature registers per lane
 
 struct Blob {   // float offsets inside the packed parameter blob
-  int kdim, KP, NTk, KBk;
-  int64_t pw_q, b_q, pw_kt, pw_v, b_v, b_vp, pw_o, b_o, pw_1, b_1, pw_2, b_2, ln_w, ln_b, total;
+  int kdim, KP, NTk, KBk, KBT;
+  int64_t pw_q, b_q, pw_kt, pw_t, b_1, pw_2, b_2, ln_w, ln_b, total;
 };
 
 __host__ __device__ constexpr Blob blob_layout(int d_e) {
@@ -38,17 +44,15 @@ __host__ __device__ constexpr Blob blob_layout(int d_e) {
   L.kdim = QD + d_e;
   L.NTk = pw_tiles(L.kdim + 1);     // n-tiles of the folded key map (+1: the q.bk column)
   L.KP = L.NTk * 16;
-  L.KBk = L.NTk;                    // k-blocks of the value map (reduction over the same KP columns)
+  L.KBk = L.NTk;                    // k-blocks of one head's x-bar (the same KP columns)
+  // folded tail: reduction over [x-bar_0 (KP) | x-bar_1 (KP) | src (112)], padded to a multiple of 4 k-blocks so
+  // that it splits evenly over 2 or 4 waves
+  L.KBT = (2 * L.KBk + pw_tiles(D) + 3) / 4 * 4;
   int64_t o = 0;
   L.pw_q = o;  o += pw_floats(QD, QD);
   L.b_q = o;   o += 208;
   L.pw_kt = o; o += 2 * pw_floats(L.kdim + 1, D);
-  L.pw_v = o;  o += 2 * (int64_t)pw_tiles(D) * L.KBk * 256;
-  L.b_v = o;   o += 208;
-  L.b_vp = o;  o += 2 * 112;        // value bias per head, each padded to 112 (n-tile granularity)
-  L.pw_o = o;  o += pw_floats(QD, QD);
-  L.b_o = o;   o += 208;
-  L.pw_1 = o;  o += pw_floats(D, 3 * D);
+  L.pw_t = o;  o += (int64_t)pw_tiles(D) * L.KBT * 256;
   L.b_1 = o;   o += 112;
   L.pw_2 = o;  o += pw_floats(D, D);
   L.b_2 = o;   o += 112;
@@ -56,6 +60,43 @@ __host__ __device__ constexpr Blob blob_layout(int d_e) {
   L.ln_b = o;  o += 112;
   L.total = o;
   return L;
+}
+
+// ---- folding the linear tail (setup time, fp64 accumulation) ---------------------------------------------
+// U[h][n][d] = sum_j W1[n][j] Wo[j][h*100 + d]            (fc1_w [100, 300], o_w [200, 200], row-major)
+__global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restrict__ o_w, double* __restrict__ U) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * D * D) return;
+  const int h = i / (D * D), n = (i / D) % D, d = i % D;
+  double acc = 0.0;
+  for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * (double)o_w[j * QD + h * D + d];
+  U[i] = acc;
+}
+// F [100, KBT*16]: columns h*KP + c (c < kdim) = sum_d U[h][n][d] Wv[h*100 + d][c];  column kdim (head 0) = the
+// constant W1a (Wo bv + bo);  columns 2*KP + k (k < 100) = W1[n][200 + k];  zero elsewhere.
+__global__ void k_fold_f(const double* __restrict__ U, const float* __restrict__ v_w, const float* __restrict__ in_b,
+                         const float* __restrict__ o_w, const float* __restrict__ o_b, const float* __restrict__ fc1_w,
+                         int kdim, int KP, int width, float* __restrict__ F) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D * width) return;
+  const int n = i / width, col = i % width;
+  double acc = 0.0;
+  if (col < 2 * KP) {
+    const int h = col / KP, c = col - h * KP;
+    if (c < kdim) {
+      for (int d = 0; d < D; ++d) acc += U[(h * D + n) * D + d] * (double)v_w[(int64_t)(h * D + d) * kdim + c];
+    } else if (h == 0 && c == kdim) {
+      const float* bv = in_b + 2 * QD;
+      for (int j = 0; j < QD; ++j) {
+        double t = (double)o_b[j];
+        for (int k = 0; k < QD; ++k) t += (double)o_w[j * QD + k] * (double)bv[k];
+        acc += (double)fc1_w[n * 3 * D + j] * t;
+      }
+    }
+  } else if (col < 2 * KP + D) {
+    acc = (double)fc1_w[n * 3 * D + QD + (col - 2 * KP)];
+  }
+  F[i] = (float)acc;
 }
 
 __global__ void k_pack(float* __restrict__ dst, int KB, int n0, int n_cnt, int Kd, const float* __restrict__ src,
@@ -125,16 +166,25 @@ ORCA_API int orca_tgat_pack(int d_e, const float* q_w, const float* k_w, const f
     rc |= orca_pack_matrix(kt, L.NTk, KB100, 0, kdim, D, k_w + (int64_t)h * D * kdim, 1, kdim, s);
     // extra output column n = kdim: bk[h*100+d]  (gives the (0.1 q_h).bk_h score offset)
     rc |= orca_pack_matrix(kt, L.NTk, KB100, kdim, 1, D, in_b + QD + h * D, 0, 1, s);
-    // value map of head h: out n = d (< 100), reduction k = c (< kdim):  Wv[h*100+d][c]
-    float* pv = blob + L.pw_v + (int64_t)h * KB100 * L.KBk * 256;
-    rc |= orca_pack_matrix(pv, KB100, L.KBk, 0, D, kdim, v_w + (int64_t)h * D * kdim, kdim, 1, s);
   }
-  rc |= copy_pad(blob + L.b_v, in_b + 2 * QD, QD, 208, s);
-  rc |= copy_pad(blob + L.b_vp, in_b + 2 * QD, D, 112, s);
-  rc |= copy_pad(blob + L.b_vp + 112, in_b + 2 * QD + D, D, 112, s);
-  rc |= orca_pack_matrix(blob + L.pw_o, pw_tiles(QD), pw_tiles(QD), 0, QD, QD, o_w, QD, 1, s);
-  rc |= copy_pad(blob + L.b_o, o_b, QD, 208, s);
-  rc |= orca_pack_matrix(blob + L.pw_1, pw_tiles(D), pw_tiles(3 * D), 0, D, 3 * D, fc1_w, 3 * D, 1, s);
+  {   // the folded tail (see the head of this file): multiplied out in fp64 in scratch memory, then packed
+    const int width = L.KBT * 16;
+    double* U = nullptr;
+    float* F = nullptr;
+    ORCA_HIP_TRY(hipMalloc(&U, sizeof(double) * 2 * D * D));
+    if (hipMalloc(&F, sizeof(float) * D * width) != hipSuccess) {
+      (void)hipFree(U);
+      orca_set_error("orca_tgat_pack: out of device memory for the fold scratch");
+      return ORCA_ENOMEM;
+    }
+    k_fold_u<<<(2 * D * D + 255) / 256, 256, 0, s>>>(fc1_w, o_w, U);
+    k_fold_f<<<(D * width + 255) / 256, 256, 0, s>>>(U, v_w, in_b, o_w, o_b, fc1_w, kdim, L.KP, width, F);
+    rc |= orca_pack_matrix(blob + L.pw_t, pw_tiles(D), L.KBT, 0, D, width, F, width, 1, s);
+    const hipError_t e1 = hipStreamSynchronize(s);
+    (void)hipFree(U);
+    (void)hipFree(F);
+    ORCA_HIP_TRY(e1);
+  }
   rc |= copy_pad(blob + L.b_1, fc1_b, D, 112, s);
   rc |= orca_pack_matrix(blob + L.pw_2, pw_tiles(D), pw_tiles(D), 0, D, D, fc2_w, D, 1, s);
   rc |= copy_pad(blob + L.b_2, fc2_b, D, 112, s);
@@ -390,15 +440,15 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   const int d_e = DE ? DE : d_e_rt;
   constexpr Blob LC = blob_layout(DE ? DE : 1);   // compile-time layout when DE is fixed
   const Blob L = DE ? LC : blob_layout(d_e);
-  constexpr int KBK = DE ? LC.KBk : 0;           // k-blocks of the value map (0 = run time)
+  constexpr int KBT_C = DE ? LC.KBT : 0;         // k-blocks of the folded tail (0 = run time)
   constexpr bool FOLD_ALL = DE && LC.NTk == 24;  // every (head, slot) wave of P2 owns exactly 3 live tiles
   const int kdim = L.kdim;
-  const int KPS = L.KP + 4;                       // row stride of the q~ / x-bar buffer
-  float* bufQ = lds;                              // [TQ][ASTR]  query vector, later o (concat heads)
-  float* bufP = bufQ + TQ * ASTR;                 // [TQ][ASTR]  0.1*q, later relu(fc1)
-  float* bufM = bufP + TQ * ASTR;                 // [TQ][MSTR]  [attn_out(200) | src(100)]
-  float* bufT = bufM + TQ * MSTR;                 // [TQ][2][KPS] q~ then x-bar
-  __shared__ int s_invalid[TQ];
+  const int KPS = L.KP;                           // columns of one head's q~ / x-bar
+  const int RS = L.KBT * 16 + 4;                  // row stride of the tail input [x-bar_0 | x-bar_1 | src | 0]
+  float* bufQ = lds;                              // [TQ][ASTR]  query vector; tail partials; fc2 output
+  float* bufP = bufQ + TQ * ASTR;                 // [TQ][ASTR]  0.1*q; tail partials (continued)
+  float* bufM = bufP + TQ * ASTR;                 // [TQ][HSTR]  relu(fc1)
+  float* bufT = bufM + TQ * HSTR;                 // [TQ][RS]    q~ then x-bar (both heads), src, zero padding
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -486,14 +536,15 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     const int m = wave;
     bufQ[m * ASTR + lane] = sa;
     bufQ[m * ASTR + D + lane] = sta;
-    bufM[m * MSTR + QD + lane] = sa;
+    float* trow = bufT + m * RS + 2 * KPS;        // the merger's copy of src, behind the two x-bar blocks
+    trow[lane] = sa;
     if (c1 < D) {
       bufQ[m * ASTR + c1] = sb;
       bufQ[m * ASTR + D + c1] = stb;
-      bufM[m * MSTR + QD + c1] = sb;
+      trow[c1] = sb;
     }
     if (lane < ASTR - QD) bufQ[m * ASTR + QD + lane] = 0.f;
-    if (lane < MSTR - 3 * D) bufM[m * MSTR + 3 * D + lane] = 0.f;
+    for (int c = D + lane; c < RS - 2 * KPS; c += 64) trow[c] = 0.f;
     for (int c = lane; c < ASTR; c += 64) bufP[m * ASTR + c] = 0.f;
   }
   __syncthreads();
@@ -514,7 +565,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   stamp();
   {
     float* dstT = bufT + h2 * KPS;
-    g2.run(bufP + h2 * D + a_off * ASTR + a_k, lane, [&](int m, int n, float v) { dstT[m * 2 * KPS + n] = v; });
+    g2.run(bufP + h2 * D + a_off * ASTR + a_k, lane, [&](int m, int n, float v) { dstT[m * RS + n] = v; });
   }
   __syncthreads();
   stamp();
@@ -523,10 +574,9 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   asm volatile("" ::"v"(touch0), "v"(touch1));   // the touches are complete (and kept) up to here
   {
     const int m = wave;
-    float* xb0 = bufT + m * 2 * KPS;
+    float* xb0 = bufT + m * RS;
     float* xb1 = xb0 + KPS;
     if (!live_q) {
-      if (lane == 0) s_invalid[m] = 1;
       for (int c = lane; c < 2 * KPS; c += 64) xb0[c] = 0.0f;
     } else {
       KeyRows R;
@@ -537,7 +587,6 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
         livebits = 1ull;                                                 // :47 un-masks slot 0
         if (!in.nbr_ids && lane == 0) in.mask[q * K] = 0;
       }
-      if (lane == 0) s_invalid[m] = invalid ? 1 : 0;
       // this lane's columns of q~ (both heads): nbr part c, c+64; edge part; time part c, c+64
       const int tb = D + d_e;
       const float qn0a = xb0[lane], qn1a = xb1[lane];
@@ -583,7 +632,8 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       const bool lv1 = K > KC && hs >= 0 && ((livebits >> (hs + KC)) & 1ull);
       const float mx = half_max(fmaxf(lv0 ? sc[0] : -INFINITY, lv1 ? sc[1] : -INFINITY));
       const float e0 = lv0 ? expf(sc[0] - mx) : 0.f, e1 = lv1 ? expf(sc[1] - mx) : 0.f;
-      const float inv = 1.0f / (half_sum(e0 + e1) * 0.5f);
+      // an all-padded neighbourhood has attn = 0 (:52): its weights, hence x-bar, are zeroed (out_w too, below)
+      const float inv = invalid ? 0.f : 1.0f / (half_sum(e0 + e1) * 0.5f);
       const float a_c0 = e0 * inv, a_c1 = e1 * inv;      // attention weight of (head = lane>>5, slot hs [+KC])
       if (out_w) {                                                       // :51-53 (head average); wave-uniform
         const int jj = lane < K ? (lane < KC ? lane : lane - KC) : 0;
@@ -629,47 +679,45 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       }
       xb0[tb + lane] = at0; xb1[tb + lane] = at1;
       if (c1 < D) { xb0[tb + c1] = bt0; xb1[tb + c1] = bt1; }
-      if (lane == 0) { xb0[kdim] = 0.f; xb1[kdim] = 0.f; }
+      if (lane == 0) { xb0[kdim] = invalid ? 0.f : 1.f; xb1[kdim] = 0.f; }   // indicator column of the tail's constant
     }
   }
-  // ---- P4: o_h = Wv_h x-bar_h + bv_h  ->  bufQ[:, h*100 + d]: wave -> (head, tile) of 2 x 7 ----------
-  const int h4 = wave / NT100, t4 = wave - h4 * NT100;
-  WaveGemm<1, 8, KBK, true> g4;
-  g4.prefetch(blob4 + (L.pw_v + (int64_t)(h4 & 1) * NT100 * L.KBk * 256) / 4, L.KBk, wave < 2 * NT100 ? t4 : -1, 1, NT100, lane,
-              blob + L.b_vp + (h4 & 1) * 112);
+  // ---- P4: h1 = relu(F [x-bar_0 | x-bar_1 | src] + b1), F = the folded value map / out-proj / fc1 ----------
+  // 7 n-tiles x KBT k-blocks cut into 16 equal-cost pieces, 4 per SIMD: waves 0..11 take half the reduction of
+  // tiles 0..5, waves 12..15 a quarter of tile 6.  Partial tiles meet in LDS (the q / 0.1q buffers are dead by
+  // now) and are summed in a fixed order: no atomics, the result does not depend on timing.
+  float* part = bufQ;                               // [16 pieces][16 x 16]
+  const bool big = wave < 12;
+  const int t4 = big ? (wave >> 1) : 6;
+  const int kb4 = big ? (wave & 1) * (L.KBT / 2) : (wave - 12) * (L.KBT / 4);
+  const f32x4* pw4 = blob4 + L.pw_t / 4 + ((int64_t)t4 * L.KBT + kb4) * 64;
+  WaveGemm<1, 8, KBT_C / 2, true> g4b;
+  WaveGemm<1, 8, KBT_C / 4, true> g4s;
+  if (big) g4b.prefetch(pw4, L.KBT / 2, 0, 1, 1, lane);
+  else     g4s.prefetch(pw4, L.KBT / 4, 0, 1, 1, lane);
   __syncthreads();
   stamp();
   {
-    g4.run(bufT + a_off * 2 * KPS + a_k + h4 * KPS, lane, [&](int m, int n, float v) {
-      if (n < D) bufQ[m * ASTR + h4 * D + n] = v;
-    });
+    const float* a4 = bufT + a_off * RS + a_k + kb4 * 16;
+    float* dst = part + wave * 256;
+    if (big) g4b.run(a4, lane, [&](int m, int n, float v) { dst[m * 16 + n] = v; });
+    else     g4s.run(a4, lane, [&](int m, int n, float v) { dst[m * 16 + n] = v; });
   }
-  // ---- P5: attn = Wo o + bo, zeroed for all-padded neighbourhoods (:52) -> bufM[:, 0:200] -------
-  WaveGemm<1, 7, 13, true> g5;
-  g5.prefetch(blob4 + L.pw_o / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_o);
-  __syncthreads();
-  stamp();
-  {
-    g5.run(bufQ + a_off * ASTR + a_k, lane, [&](int m, int n, float v) {
-      if (n < QD) bufM[m * MSTR + n] = s_invalid[m] ? 0.0f : v;
-    });
-  }
-  // ---- P6: h1 = relu(fc1 [attn | src] + b1) -> bufP[:, 0:112] -----------------------------------
-  WaveGemm<1, 7, 19, true> g6;
-  g6.prefetch(blob4 + L.pw_1 / 4, pw_tiles(3 * D), wave < NT100 ? wave : -1, NW, NT100, lane, blob + L.b_1);
-  __syncthreads();
-  stamp();
-  {
-    g6.run(bufM + a_off * MSTR + a_k, lane,
-           [&](int m, int n, float v) { bufP[m * ASTR + n] = (n < D) ? fmaxf(v, 0.0f) : 0.0f; });
-  }
-  // ---- P7: y = fc2 h1 + b2 -> bufQ[:, 0:100] -----------------------------------------------------
   WaveGemm<1, 7, 7, true> g7;
   g7.prefetch(blob4 + L.pw_2 / 4, NT100, wave < NT100 ? wave : -1, NW, NT100, lane, blob + L.b_2);
   __syncthreads();
   stamp();
+  for (int e = tid; e < TQ * 112; e += NW * 64) {
+    const int m = e / 112, n = e - m * 112, t = n >> 4, o = m * 16 + (n & 15);
+    float v = t < 6 ? part[(2 * t) * 256 + o] + part[(2 * t + 1) * 256 + o]
+                    : (part[12 * 256 + o] + part[13 * 256 + o]) + (part[14 * 256 + o] + part[15 * 256 + o]);
+    bufM[m * HSTR + n] = n < D ? fmaxf(v + blob[L.b_1 + n], 0.0f) : 0.0f;
+  }
+  // ---- P7: y = fc2 h1 + b2 -> bufQ[:, 0:100] -----------------------------------------------------
+  __syncthreads();
+  stamp();
   {
-    g7.run(bufP + a_off * ASTR + a_k, lane, [&](int m, int n, float v) {
+    g7.run(bufM + a_off * HSTR + a_k, lane, [&](int m, int n, float v) {
       if (n < D) bufQ[m * ASTR + n] = v;
     });
   }
@@ -728,7 +776,7 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
   ORCA_REQUIRE(!in->nbr_flags || in->nbr_overlay, "orca_tgat_forward: nbr_flags without nbr_overlay");
   ORCA_REQUIRE(in->nbr_idx || Q * K < (1LL << 31), "orca_tgat_forward: dense mode limited to Q*K < 2^31");
   Blob L = blob_layout(d_e);
-  size_t lds_bytes = (size_t)(2 * TQ * ASTR + TQ * MSTR + TQ * 2 * (L.KP + 4)) * sizeof(float);
+  size_t lds_bytes = (size_t)(2 * TQ * ASTR + TQ * HSTR + TQ * (L.KBT * 16 + 4)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     const int lim = 160 * 1024 - 256;

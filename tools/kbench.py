@@ -78,11 +78,11 @@ def main():
   torch.cuda.synchronize()
   _lib.load().orca_debug_tgat_phase_clock(None)
   c = clk.view(nwg, 16).cpu().double()
-  d = (c[:, 1:11] - c[:, 0:10]) / 100.0
-  names = ["T0+P0 stage", "P1 q-proj", "P2 fold", "P3 per-query", "P4 Wv", "P5 out-proj", "P6 fc1", "P7 fc2", "P8 LN"]
+  d = (c[:, 1:9] - c[:, 0:8]) / 100.0
+  names = ["T0 stage", "P1 q-proj", "P2 key fold", "P3 per-query", "P4 folded tail", "P4 reduce", "P7 fc2", "P8 LN"]
   print("tgat phases (median us over workgroups):", {n: round(float(d[:, i].median()), 2) for i, n in enumerate(names)})
-  print("tgat workgroup span us: median", float(((c[:, 9] - c[:, 0]) / 100).median()), "chip span",
-        float((c[:, 9].max() - c[:, 0].min()) / 100), " start skew", float((c[:, 0].max() - c[:, 0].min()) / 100))
+  print("tgat workgroup span us: median", float(((c[:, 8] - c[:, 0]) / 100).median()), "chip span",
+        float((c[:, 8].max() - c[:, 0].min()) / 100), " start skew", float((c[:, 0].max() - c[:, 0].min()) / 100))
   stamp = torch.zeros(N + 1, dtype=torch.int64, device=dev)
   wl = torch.zeros(N + 1, dtype=torch.int32, device=dev)
   cnt = torch.zeros(1, dtype=torch.int32, device=dev)
