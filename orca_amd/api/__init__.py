@@ -13,3 +13,5 @@ from .message_aggregator import get_message_aggregator                      # mo
 from .embedding_module import get_embedding_module, GraphAttentionEmbedding  # modules/embedding_module.py
 from .cache import get_cache_plan                                           # utils/cache.py
 from .tgn_model import TGN                                                  # model/tgn_model.py (thin caller)
+from .data import Data, get_data, load_feat                                 # utils/data_processing.py
+from .evaluation import RandEdgeSampler, eval_edge_prediction               # utils/util.py:68-87, evaluation/evaluation.py

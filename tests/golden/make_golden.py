@@ -411,9 +411,77 @@ def gen_mrd():
   print("mrd.npz")
 
 
+def gen_harness():
+  """The callers either side of the path: utils/data_processing.py:31-120
+  (get_data on the ml_{name}.csv / .npy layout), utils/util.py:68-87 (RandEdgeSampler) and
+  evaluation/evaluation.py:6-47 (eval_edge_prediction, here with a deterministic stand-in model so that only the
+  loop and the metrics are pinned)."""
+  import contextlib
+  import io
+  import tempfile
+  import pandas as pd
+  from utils.data_processing import get_data, load_feat
+  from utils.util import RandEdgeSampler
+  from evaluation.evaluation import eval_edge_prediction
+  out = {}
+  # ---- get_data on a synthetic bipartite interaction file ------------------------------------------
+  rs = np.random.RandomState(41)
+  n_users, n_items, n_edges = 300, 120, 6000
+  u = rs.randint(1, n_users + 1, n_edges)
+  i = rs.randint(n_users + 1, n_users + n_items + 1, n_edges)
+  ts = np.sort(rs.uniform(0, 2.6e6, n_edges))
+  label = (rs.uniform(size=n_edges) < 0.02).astype(np.int64)
+  idx = np.arange(1, n_edges + 1)
+  feats = rs.randn(n_edges + 1, 8).astype(np.float64)
+  cwd = os.getcwd()
+  with tempfile.TemporaryDirectory() as tmp:
+    os.makedirs(os.path.join(tmp, "data", "toy"))
+    os.makedirs(os.path.join(tmp, "run"))
+    pd.DataFrame({"u": u, "i": i, "ts": ts, "label": label, "idx": idx}).to_csv(
+        os.path.join(tmp, "data", "toy", "ml_toy.csv"))
+    np.save(os.path.join(tmp, "data", "toy", "ml_toy.npy"), feats)
+    os.chdir(os.path.join(tmp, "run"))
+    try:
+      with contextlib.redirect_stdout(io.StringIO()):
+        full, train, val, test, nn_val, nn_test, n_nodes, n_e = get_data("toy")
+      node_f, edge_f = load_feat("toy")
+    finally:
+      os.chdir(cwd)
+  assert node_f is None and np.array_equal(edge_f, feats)
+  out.update(data_u=u, data_i=i, data_ts=ts, data_label=label, data_idx=idx, data_feats=feats,
+             data_counts=np.array([n_nodes, n_e]))
+  for name, d in dict(full=full, train=train, val=val, test=test, nn_val=nn_val, nn_test=nn_test).items():
+    out[f"data_{name}_edge_idxs"] = np.asarray(d.edge_idxs)
+    out[f"data_{name}_sources"] = np.asarray(d.sources)
+    out[f"data_{name}_n_unique_nodes"] = np.array([d.n_unique_nodes])
+  # ---- RandEdgeSampler -----------------------------------------------------------------------------
+  smp = RandEdgeSampler(full.sources, full.destinations, seed=3)
+  a1 = smp.sample(50)
+  a2 = smp.sample(7)
+  smp.reset_random_state()
+  a3 = smp.sample(50)
+  assert np.array_equal(a1[0], a3[0]) and np.array_equal(a1[1], a3[1])
+  out.update(neg_src_50=a1[0], neg_dst_50=a1[1], neg_src_7=a2[0], neg_dst_7=a2[1])
+  # ---- eval_edge_prediction with a deterministic stand-in model ------------------------------------
+  class Model:
+    def eval(self):
+      return self
+
+    def compute_edge_probabilities(self, s, d, n, t, e, n_neighbors, reuse, train, cache):
+      pos = 1.0 / (1.0 + np.exp(-np.sin(0.37 * s + 0.11 * d + 1e-6 * t)))
+      neg = 1.0 / (1.0 + np.exp(-np.sin(0.37 * s + 0.11 * n + 1e-6 * t) + 0.4))
+      return torch.from_numpy(pos.reshape(-1, 1)), torch.from_numpy(neg.reshape(-1, 1))
+
+  smp = RandEdgeSampler(full.sources, full.destinations, seed=0)
+  ap, auc, acc = eval_edge_prediction(Model(), smp, val, 10, 200)
+  out["eval_metrics"] = np.array([ap, auc, acc])
+  np.savez_compressed(os.path.join(OUT, "harness.npz"), **out)
+  print("harness.npz")
+
+
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["sampler", "time", "attention", "agg", "history", "tgn", "mrd"]
+  which = sys.argv[1:] or ["sampler", "time", "attention", "agg", "history", "tgn", "mrd", "harness"]
   fns = dict(sampler=gen_sampler, time=gen_time_encode, attention=gen_attention, agg=gen_aggregators,
-             history=gen_history, tgn=gen_tgn, mrd=gen_mrd)
+             history=gen_history, tgn=gen_tgn, mrd=gen_mrd, harness=gen_harness)
   for w in which:
     fns[w]()

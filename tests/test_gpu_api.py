@@ -239,3 +239,38 @@ def test_get_cache_plan(api, golden, tag, capsys):
       assert np.array_equal(np.sort(p), np.sort(g[f"{tag}_plan_flat"][off[i]:off[i + 1]]))
   with pytest.raises(SystemExit):
     api.get_cache_plan(args, data, nf, args.n_nodes, "LRU")
+
+
+def test_eval_edge_prediction_drives_the_hip_model(api, golden):
+  """evaluation/evaluation.py:6-47 over orca_amd.api.TGN (Path B): the loop's metrics equal those of the same
+  batches scored by hand on an identically initialised model (the loop itself is pinned to the reference in
+  tests/test_harness_cpu.py)."""
+  from sklearn.metrics import average_precision_score
+  g = golden("tgn.npz")
+  L, reuse, budget, bs, K, n_train, n_eval, n_nodes, n_edges = [int(x) for x in g["B2_meta"]]
+  src, dst, ts, eidx = (g[f"g172_{k}"] for k in ("src", "dst", "ts", "eidx"))
+  args = argparse.Namespace(n_nodes=n_nodes + 1, n_edges=n_edges + 1, reuse=True, budget=0, gradient=False, bs=bs, n_degree=K)
+  sd = {k[len("g172_sd."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("g172_sd.")}
+
+  def model():
+    nf = api.get_neighbor_finder(Data(src, dst, ts, eidx), max_node_idx=n_nodes, device=DEV)
+    tgn = api.TGN(neighbor_finder=nf, node_features=None, edge_features=g["g172_edge_feats"], device=DEV, n_layers=L,
+                  n_heads=2, dropout=0.1, use_memory=True, node_dimension=100, time_dimension=100, memory_dimension=100,
+                  embedding_module_type="graph_attention", message_function="identity", aggregator_type="last",
+                  memory_updater_type="gru", n_neighbors=K, args=args)
+    own = tgn.state_dict()
+    tgn.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+    return tgn.eval()
+
+  lo = n_train * bs
+  data = api.Data(src[lo:], dst[lo:], ts[lo:], eidx[lo:], np.zeros(len(src) - lo))
+  ap, auc, acc = api.eval_edge_prediction(model(), api.RandEdgeSampler(src, dst, seed=0), data, K, bs, True)
+  m2, smp, aps = model(), api.RandEdgeSampler(src, dst, seed=0), []
+  for b in range(int(np.ceil(data.n_interactions / bs))):
+    r = slice(b * bs, min(data.n_interactions, (b + 1) * bs))
+    _, neg = smp.sample(len(data.sources[r]))
+    p, n = m2.compute_edge_probabilities(data.sources[r], data.destinations[r], neg, data.timestamps[r], data.edge_idxs[r],
+                                         K, True, False, None)
+    p, n = p.cpu().numpy(), n.cpu().numpy()
+    aps.append(average_precision_score(np.concatenate([np.ones(len(p)), np.zeros(len(n))]), np.concatenate([p, n])))
+  assert ap == np.mean(aps) and 0.0 <= auc <= 1.0 and 0.0 <= acc <= 1.0
