@@ -266,6 +266,9 @@ typedef struct {
                                       updated memory row of each of its roots (rows lo..hi); the caller all-gathers
                                       the buffer before orca_engine_finish, which then commits the positives' rows
                                       from it instead of recomputing the GRU of every rank's positives */
+  int32_t* eager_ids;              /* [2, q_max] or NULL: the distinct ids whose raw message a train-ordered step
+                                      stored (two halves, written and consumed by alternate steps) */
+  int32_t* eager_count;            /* [2] their counts; zero-initialised by the caller */
 } orca_engine_desc;
 
 int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** out);
@@ -299,6 +302,18 @@ int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t hi, void*
  * batch was begun with.  tgn_model.py:127-145 */
 int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* eidx,
                        const double* ts, void* stream);
+
+/* Eager overlay.  While the state is "overlay complete" -- overlay[id] == GRU(messages[id], memory[id]) for every id
+ * with a pending message, save those the last step stored -- a train-ordered orca_engine_begin over the whole
+ * batch needs no per-batch work-list: it applies the GRU to the ids the previous step stored and nothing else.
+ * A freshly zeroed state is complete; so is any state right after update_memory_in_test (no pending ids).  The
+ * driver clears the flag itself when a step leaves pending ids it did not list; a caller that stores messages,
+ * restores a backup or otherwise changes memory / messages / pending behind the driver's back must clear it
+ * (complete = 0: also forgets the outstanding list).  orca_engine_drain applies the outstanding list now (before
+ * the handle is destroyed and rebuilt, for instance). */
+int orca_engine_set_overlay_complete(orca_engine_t* e, int complete);
+int orca_engine_get_overlay_complete(orca_engine_t* e);
+int orca_engine_drain(orca_engine_t* e, void* stream);
 
 /* ---- offline cache planner: utils/cache.py:19-89 (read_batches) + :92-166 (MRD_numba) ------- */
 

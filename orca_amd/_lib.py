@@ -37,7 +37,7 @@ class EngineDesc(ctypes.Structure):
                ("messages", vp), ("msg_ts", vp), ("pending", vp), ("overlay", vp),
                ("hist", vp * (ORCA_ENGINE_MAX_LAYERS - 1)), ("slot", vp), ("worklist", vp), ("count", vp),
                ("q_max", i64), ("nodes", vp), ("qts", vp), ("nodes32", vp), ("nbr", vp), ("eid", vp), ("et", vp),
-               ("dt", vp), ("emb", vp * 2), ("winners", vp), ("upd", vp)])
+               ("dt", vp), ("emb", vp * 2), ("winners", vp), ("upd", vp), ("eager_ids", vp), ("eager_count", vp)])
 
 
 # name -> (restype, argtypes); every symbol include/orca_hip.h declares
@@ -84,6 +84,9 @@ SIGNATURES = {
     "orca_engine_begin": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
     "orca_engine_layer": (i32, [vp, i32, i64, i64, vp]),
     "orca_engine_finish": (i32, [vp, vp, vp, vp, vp, vp]),
+    "orca_engine_set_overlay_complete": (i32, [vp, i32]),
+    "orca_engine_get_overlay_complete": (i32, [vp]),
+    "orca_engine_drain": (i32, [vp, vp]),
     "orca_mrd_plan_host": (i32, [i64, i64, i32, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]),
 }
 

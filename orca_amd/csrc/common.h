@@ -85,6 +85,7 @@ struct orca_tgat_side {
   float* store_messages;
   float* store_msg_ts;
   uint8_t* store_pending;
+  int32_t* zero_word;               // or null: a device counter this launch resets to 0
   float* src_rows_out;              // [Q, ORCA_D] or null: the (overlay-resolved) source row of every query, i.e. the
                                     // root's memory after its pending message is applied -- what a multi-rank step
                                     // all-gathers so that no rank has to redo the GRU of another rank's positives

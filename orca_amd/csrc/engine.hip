@@ -25,6 +25,12 @@ struct orca_engine {
   bool upd_rows;               // layer 1 wrote the updated memory rows of this rank's roots to d.upd (sliced train step)
   bool store_done;             // the raw-message store of the batch was fused into the last attention layer
   const int64_t* eidx;         // batch edge ids handed to begin() (may be null)
+  // Eager overlay (see orca_engine_begin).  overlay_complete: every pending id outside the outstanding list has
+  // overlay[id] == GRU(messages[id], memory[id]).  have_list: eager_ids[cur ^ 1 half] holds the distinct ids whose
+  // messages the last train-ordered step stored and whose overlay rows are not computed yet.
+  bool overlay_complete, have_list, list_written;
+  int cur;                     // half of eager_ids / eager_count this step's election writes
+  int64_t list_bound;          // entries the outstanding list can hold (2 * bs of the step that wrote it)
   int profile;         // > 0: every profile-th step has HIP events attached to its sampler / GRU / attention launches
   int64_t step;        // steps begun since profiling was switched on
   bool timed_step;     // this step is one of those
@@ -52,7 +58,8 @@ __device__ __forceinline__ int elect_part(int64_t id, int parts) { return (int)(
 // full, so every occurrence of that id takes the same route and the result stays exact.
 template <typename GetId>
 __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64_t n, int64_t n_nodes, GetId get,
-                                             uint8_t* __restrict__ winner, int part, int parts) {
+                                             uint8_t* __restrict__ winner, int part, int parts,
+                                             int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
   for (int i = threadIdx.x; i < ELECT_SLOTS; i += ELECT_THREADS) { keys[i] = -1; vals[i] = -1; }
   __syncthreads();
   for (int64_t p = threadIdx.x; p < n; p += ELECT_THREADS) {
@@ -85,6 +92,16 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
       }
     }
     winner[p] = w;
+    if (list) {   // the distinct ids of the list, in no particular order: one atomicAdd per wavefront
+      const unsigned long long m = __ballot(w != 0);
+      if (m) {
+        const int ln = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (ln == leader) base = atomicAdd(list_count, __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (w) list[base + __popcll(m & ((1ull << ln) - 1ull))] = (int32_t)id;
+      }
+    }
   }
 }
 
@@ -98,14 +115,14 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
     int32_t* __restrict__ nodes32, int nb, int parts, int64_t n_nodes, uint8_t* __restrict__ win_push,
-    uint8_t* __restrict__ win_msg,
+    uint8_t* __restrict__ win_msg, int32_t* __restrict__ msg_list, int32_t* __restrict__ msg_count,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ c_nbr, const int32_t* __restrict__ c_eid,
     const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int K, int32_t* __restrict__ o_nbr,
     int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt, orca_claim claim) {
   __shared__ int32_t keys[ELECT_SLOTS], vals[ELECT_SLOTS];
   auto root = [&](int64_t i) { return i < bs ? src[i] : (i < 2 * bs ? dst[i - bs] : neg[i - 2 * bs]); };
-  if ((int)blockIdx.x >= nb + parts) { elect_in_lds(keys, vals, 2 * bs, n_nodes, root, win_msg, (int)blockIdx.x - nb - parts, parts); return; }
-  if ((int)blockIdx.x >= nb) { elect_in_lds(keys, vals, 3 * bs, n_nodes, root, win_push, (int)blockIdx.x - nb, parts); return; }
+  if ((int)blockIdx.x >= nb + parts) { elect_in_lds(keys, vals, 2 * bs, n_nodes, root, win_msg, (int)blockIdx.x - nb - parts, parts, msg_list, msg_count); return; }
+  if ((int)blockIdx.x >= nb) { elect_in_lds(keys, vals, 3 * bs, n_nodes, root, win_push, (int)blockIdx.x - nb, parts, nullptr, nullptr); return; }
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
   if (i >= 3 * bs) return;
@@ -170,6 +187,11 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   e->store_done = false;
   e->upd_rows = false;
   e->eidx = nullptr;
+  e->overlay_complete = false;
+  e->have_list = false;
+  e->list_written = false;
+  e->cur = 0;
+  e->list_bound = 0;
   e->profile = 0;
   e->step = 0;
   e->timed_step = false;
@@ -247,28 +269,59 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   ORCA_REQUIRE(src && dst && neg && ts, "orca_engine_begin: null batch array");
   const int64_t n = hi - lo;
   const int K = d.K;
-  const int64_t cand = n * (K + 1);
-  const int64_t claim_epoch = (train && n > 0) ? take_epochs(e, cand) : 0;
   int rc;
+  // ---- eager overlay ----------------------------------------------------------------------------------------
+  // get_updated_memory (memory_updater.py:56-78) is GRU(message, memory) of the pending ids a batch reads.  Its
+  // value for an id is fixed from the moment the message is stored until the id is a positive again (nothing
+  // else writes its message or its memory), so it can be computed ONCE, right after the store: the election of
+  // the raw-message list also emits the list of distinct ids, and the next begin() runs the GRU over exactly that
+  // list.  While `overlay_complete` holds no batch needs a work-list of the ids it reads (no claim pass, no
+  // append kernel, no GRU over a 45,045-candidate bound).  Steps that leave pending ids without an overlay row
+  // (a sliced multi-rank step, callers that store messages outside the driver) clear the flag and the driver
+  // falls back to the per-batch work-list until the caller declares the state clean again.
+  e->cur ^= 1;
+  const bool lists = d.eager_ids && d.eager_count && e->winners_valid;
+  int32_t* my_list = lists ? d.eager_ids + (int64_t)e->cur * d.q_max : nullptr;
+  int32_t* my_count = lists ? d.eager_count + e->cur : nullptr;
+  e->list_written = lists;
+  if (e->have_list) {
+    e->have_list = false;
+    if (e->overlay_complete) {
+      Timed t(e, ORCA_PROF_GRU, stream);
+      rc = orca_gru_update(d.gru_blob, 3 * ORCA_D + d.d_e, d.eager_ids + (int64_t)(e->cur ^ 1) * d.q_max, e->list_bound,
+                           d.eager_count + (e->cur ^ 1), d.messages, d.memory, d.overlay, nullptr, nullptr, stream_);
+      if (rc != ORCA_OK) return rc;
+    }
+  }
+  const bool eager = train && lo == 0 && hi == Q && e->overlay_complete;
+  const bool lazy = train && !eager;
+  const int64_t cand = n * (K + 1);
+  const int64_t claim_epoch = (lazy && n > 0) ? take_epochs(e, cand) : 0;
   {
     int64_t n_rows = 0;
     const int64_t* indptr; const int32_t *c_nbr, *c_eid; const double* c_ts;
     if ((rc = orca_csr_arrays(d.csr, &n_rows, nullptr, &indptr, &c_nbr, &c_eid, &c_ts)) != ORCA_OK) return rc;
-    const orca_claim claim = (train && n > 0) ? orca_claim{d.pending, d.slot, claim_epoch, d.n_nodes, d.count} : orca_claim{};
+    const orca_claim claim = (lazy && n > 0) ? orca_claim{d.pending, d.slot, claim_epoch, d.n_nodes, d.count} : orca_claim{};
     const int nb = (int)ceil_div64(Q, ELECT_THREADS / 64);
     Timed t(e, ORCA_PROF_SAMPLE, stream);
     ORCA_LAUNCH_TIMED(k_begin_queries, (unsigned)(nb + (e->winners_valid ? 2 * parts : 0)), ELECT_THREADS, 0, stream, src, dst, neg, ts,
                       bs, d.nodes, d.qts, d.nodes32, nb, parts, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr,
+                      my_list, my_count,
                       indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, K, d.nbr, d.eid, d.et, d.dt, claim);
     ORCA_LAUNCH_CHECK();
   }
-  if (n == 0) return ORCA_OK;
+  // the other half of the list buffers (consumed above) is the next step's: its counter restarts at zero
+  int32_t* next_count = (d.eager_ids && d.eager_count) ? d.eager_count + (e->cur ^ 1) : nullptr;
+  if (n == 0) {
+    if (next_count) ORCA_HIP_TRY(hipMemsetAsync(next_count, 0, sizeof(int32_t), stream));
+    return ORCA_OK;
+  }
   orca_tgat_inputs in{};
   in.src_table = d.memory; in.src_idx = d.nodes32 + lo;
   in.nbr_table = d.memory; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
   in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b;
-  if (train) {   // :159-161 get_updated_memory(unique(neighbors ∪ sources)) -> overlay rows
+  if (lazy) {    // :159-161 get_updated_memory(unique(neighbors ∪ sources)) -> overlay rows
     rc = orca_worklist_append(d.nbr, n * K, d.nodes + lo, n, d.pending, d.slot, claim_epoch, d.n_nodes, d.worklist,
                               d.count, stream_);
     if (rc != ORCA_OK) return rc;
@@ -278,12 +331,15 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
                            d.messages, d.memory, d.overlay, nullptr, nullptr, stream_);
     }
     if (rc != ORCA_OK) return rc;
+  }
+  if (train) {
     in.src_overlay = d.overlay; in.src_flags = d.pending;
     in.nbr_overlay = d.overlay; in.nbr_flags = d.pending;
   }
   // a rank that embeds the whole batch lets the attention kernel do the row writes that would otherwise be
   // kernels of their own: the memory persist of the positives (train order) and the history push of its output
   orca_tgat_side side{};
+  side.zero_word = next_count;
   if (e->overlay_covers_batch) {
     side.persist_memory = d.memory; side.persist_last_update = d.last_update; side.persist_msg_ts = d.msg_ts;
     side.persist_n = 2 * bs;
@@ -383,8 +439,36 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
   int rc;
   if (e->train) {                 // tgn_model.py:127-141
     if ((rc = persist()) != ORCA_OK) return rc;
-    return store();
+    if ((rc = store()) != ORCA_OK) return rc;
+    // the ids that now hold a fresh message: begin() elected them into this step's list (all ranks elect the
+    // global list, but a sliced step would make every rank redo every rank's rows: it stays on work-lists)
+    if (e->list_written && !e->upd_rows && e->overlay_covers_batch) {
+      e->have_list = true;
+      e->list_bound = 2 * bs < d.q_max ? 2 * bs : d.q_max;
+    } else {
+      e->overlay_complete = false;
+    }
+    return ORCA_OK;
   }
   if ((rc = store()) != ORCA_OK) return rc;   // :131-145
-  return persist();
+  return persist();                           // the positives end without a pending message: nothing to list
+}
+
+ORCA_API int orca_engine_set_overlay_complete(orca_engine_t* e, int complete) {
+  ORCA_REQUIRE(e, "orca_engine_set_overlay_complete: null handle");
+  e->overlay_complete = complete != 0;
+  e->have_list = false;
+  return ORCA_OK;
+}
+
+ORCA_API int orca_engine_get_overlay_complete(orca_engine_t* e) { return (e && e->overlay_complete) ? 1 : 0; }
+
+ORCA_API int orca_engine_drain(orca_engine_t* e, void* stream_) {
+  ORCA_REQUIRE(e, "orca_engine_drain: null handle");
+  const orca_engine_desc& d = e->d;
+  if (!e->have_list) return ORCA_OK;
+  e->have_list = false;
+  if (!e->overlay_complete) return ORCA_OK;
+  return orca_gru_update(d.gru_blob, 3 * ORCA_D + d.d_e, d.eager_ids + (int64_t)e->cur * d.q_max, e->list_bound,
+                         d.eager_count + e->cur, d.messages, d.memory, d.overlay, nullptr, nullptr, stream_);
 }

@@ -436,6 +436,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     ++phase_no;
   };
   stamp();
+  if (side.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *side.zero_word = 0;
   const int K = KT ? KT : K_rt;
   const int d_e = DE ? DE : d_e_rt;
   constexpr Blob LC = blob_layout(DE ? DE : 1);   // compile-time layout when DE is fixed

@@ -75,6 +75,9 @@ class OrcaEngine:
     self._native = None      # orca_engine_t: the C++ step driver (created on first use, regrown with the batch)
     self._q_max = 0
     self._prof_native = 0
+    # "overlay complete" (include/orca_hip.h, eager overlay): true for the zeroed state this object starts with;
+    # mirrored into the native driver, which keeps it up to date while it owns the steps
+    self._overlay_complete = True
     self.prof = None     # set to {} to bracket the kernels with HIP events (bench.py roofline)
 
   def _timed(self, name, fn, *a, **k):
@@ -122,6 +125,12 @@ class OrcaEngine:
     for t in self.hist + self.cache_flag:
       t.zero_()
     self.test_mode = False
+    self._set_overlay_complete(True)       # no pending ids
+
+  def _set_overlay_complete(self, flag):
+    self._overlay_complete = bool(flag)
+    if self._native is not None:
+      check(_lib.load().orca_engine_set_overlay_complete(self._native, int(flag)), "orca_engine_set_overlay_complete")
 
   # modules/memory.py:39-43, embedding_module.py:83-91
   def backup(self):
@@ -135,6 +144,7 @@ class OrcaEngine:
       t.copy_(s)
     for t, s in zip(self.cache_flag, b[2]):
       t.copy_(s)
+    self._set_overlay_complete(False)      # the overlay rows of the restored pending ids are not part of a backup
 
   # -------------------------------------------------------------------------------------------
   def _slot_epoch(self, n):
@@ -155,6 +165,8 @@ class OrcaEngine:
     L = _lib.load()
     if self._native is not None:
       self.slot_epoch = int(L.orca_engine_take_epochs(self._native, 0))
+      check(L.orca_engine_drain(self._native, stream()), "orca_engine_drain")   # the ids the last step stored
+      self._overlay_complete = bool(L.orca_engine_get_overlay_complete(self._native))
       L.orca_engine_destroy(self._native)
       self._native = None
     dev, K = self.device, self.K
@@ -168,7 +180,9 @@ class OrcaEngine:
                    dt=torch.zeros(q_max * K, dtype=torch.float32, device=dev),
                    emb=[torch.zeros(q_max, D, dtype=torch.float32, device=dev) for _ in range(2)],
                    winners=torch.zeros(2 * q_max, dtype=torch.uint8, device=dev),
-                   upd=torch.zeros(q_max, D, dtype=torch.float32, device=dev) if self.world > 1 else None)
+                   upd=torch.zeros(q_max, D, dtype=torch.float32, device=dev) if self.world > 1 else None,
+                   eager_ids=torch.zeros(2 * q_max, dtype=torch.int32, device=dev),
+                   eager_count=torch.zeros(2, dtype=torch.int32, device=dev))
     d = _lib.EngineDesc()
     d.n_nodes, d.n_layers, d.K, d.d_e = self.N, self.L, K, self.d_e
     d.csr = self.csr._h if self.csr is not None else None
@@ -188,9 +202,11 @@ class OrcaEngine:
     d.emb[0], d.emb[1] = ptr(w["emb"][0]), ptr(w["emb"][1])
     d.winners = ptr(w["winners"])
     d.upd = ptr(w["upd"]) if w["upd"] is not None else None
+    d.eager_ids, d.eager_count = ptr(w["eager_ids"]), ptr(w["eager_count"])
     h = _lib.vp()
     check(L.orca_engine_create(ctypes.byref(d), ctypes.byref(h)), "orca_engine_create")
     L.orca_engine_take_epochs(h, self.slot_epoch)       # continue after the epochs already used on `slot`
+    L.orca_engine_set_overlay_complete(h, int(self._overlay_complete))
     self._native, self._q_max = h, q_max
     if self._prof_native:
       L.orca_engine_profile(h, self._prof_native)
@@ -285,6 +301,7 @@ class OrcaEngine:
     ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory,
                    self.memory, self.last_update, self.msg_ts)
     ops.fill_u8(self.pending, 0)
+    self._set_overlay_complete(True)       # no pending ids left
 
   def _sample(self, nodes, ts):
     nbr, eid, _, dt = self._timed("sample_recent", ops.sample_recent, self.csr, nodes, ts, self.K)
@@ -404,6 +421,7 @@ class OrcaEngine:
     if self.reuse and self.budget == 0 and self.prof is None:
       # Path B end to end in the native driver (embedding, memory persist, message store)
       return self._step_reuse_native(src, dst, neg, ts, eidx, train)
+    self._set_overlay_complete(False)      # the Python-dispatched paths store messages without overlay rows
     nodes = torch.cat([src, dst, neg])
     t3 = torch.cat([ts, ts, ts])
     positives = nodes[:2 * src.numel()]
