@@ -159,3 +159,59 @@ def test_election_table_overflow_vs_oracle(golden):
     assert np.array_equal(eng.pending.cpu().numpy().astype(bool), ref.pending)
   assert_close_fp32(eng.messages.cpu().numpy(), ref.messages.numpy(), 1e-5, "messages")
   assert np.array_equal(eng.msg_ts.cpu().numpy(), ref.msg_ts.numpy())
+
+
+def test_eager_overlay_survives_mode_changes(golden):
+  """The native driver applies GRU(message, memory) once per stored message (the ids of the previous step's
+  store) instead of building a work-list of the ids each batch reads.  That rests on a state flag which train /
+  eval switches, a backup restore, a batch-size change that rebuilds the driver and a Python-dispatched step
+  all have to keep honest: after each of them the results must still equal the oracle's."""
+  import copy
+  from orca_amd import ops
+  from orca_amd.engine import OrcaEngine
+  g = golden("tgn.npz")
+  sd = {k[len("g172_sd."):]: g[k] for k in g.files if k.startswith("g172_sd.")}
+  N, E, K = 5000, 80000, 10
+  src, dst, ts, eidx, ef = _synthetic(21, N, E, 172)
+  eng = OrcaEngine(sd, ef, N + 1, 2, K, True, 0, device=DEV)
+  eng.set_neighbor_finder(ops.CSR.from_edges_device(*(torch.from_numpy(x).to(DEV) for x in (src, dst, eidx, ts)), N + 1))
+  ref = O.OracleTGN(sd, ef, N + 1, 2, K, True, 0)
+  ref.neighbor_finder = O.OracleNeighborFinder(src, dst, eidx, ts, max_node_idx=N)
+  rs = np.random.RandomState(22)
+  pos = [60000]
+
+  def step(bs, train, what):
+    s, e = pos[0], pos[0] + bs
+    pos[0] = e
+    neg = rs.randint(1, N + 1, bs).astype(np.int64)
+    emb = eng.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], train).cpu().numpy()
+    exp = ref.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], train).numpy()
+    assert_close_fp32(emb, exp, 1e-5, what + " emb")
+    assert_close_fp32(eng.memory.cpu().numpy(), ref.memory.numpy(), 1e-5, what + " memory")
+    assert_close_fp32(eng.messages.cpu().numpy(), ref.messages.numpy(), 1e-5, what + " messages")
+    assert np.array_equal(eng.pending.cpu().numpy().astype(bool), ref.pending), what
+    assert np.array_equal(eng.last_update.cpu().numpy(), ref.last_update.numpy()), what
+
+  for b in range(3):
+    step(300, True, f"train {b}")
+  step(700, True, "train, larger batch (driver rebuilt)")        # drains the outstanding list, carries the flag
+  step(700, True, "train after the rebuild")
+  bk, ref_bk = eng.backup(), copy.deepcopy(ref)
+  bk_pos = pos[0]
+  step(250, False, "eval 0 (flushes every pending message)")
+  step(250, False, "eval 1")
+  step(300, True, "train after eval")
+  step(300, True, "train after eval, 2")
+  eng.restore(bk)                                                  # pending ids come back without overlay rows
+  ref, pos[0] = ref_bk, bk_pos
+  step(300, True, "train after restore (work-list route)")
+  step(300, True, "train after restore, 2")
+  eng.prof = {}                                                    # one Python-dispatched Path B step
+  step(300, True, "python-dispatched step")
+  eng.prof = None
+  step(300, True, "native step after a python-dispatched one")
+  eng.reset_state()
+  ref.init_memory()
+  ref.reset_history()
+  step(300, True, "train after reset")
+  step(300, True, "train after reset, 2")
