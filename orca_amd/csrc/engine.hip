@@ -56,50 +56,72 @@ __device__ __forceinline__ int elect_part(int64_t id, int parts) { return (int)(
 // An id that finds its table full (only possible when far more distinct ids hash to one part than the sizing
 // assumes) is elected by scanning the rest of the list for a later occurrence: slow, but a full table stays
 // full, so every occurrence of that id takes the same route and the result stays exact.
+constexpr int ELECT_UNROLL = 6;            // ids a thread has in flight (one pass covers a full table's worth)
+
 template <typename GetId>
 __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64_t n, int64_t n_nodes, GetId get,
                                              uint8_t* __restrict__ winner, int part, int parts,
                                              int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
+  constexpr int64_t CHUNK = (int64_t)ELECT_UNROLL * ELECT_THREADS;
+  // the first chunk's ids are requested before the table is cleared: their round trip hides behind the clear
+  int64_t id[ELECT_UNROLL];
+  auto fetch = [&](int64_t p0) {
+#pragma unroll
+    for (int u = 0; u < ELECT_UNROLL; ++u) {
+      const int64_t p = p0 + (int64_t)u * ELECT_THREADS + threadIdx.x;
+      id[u] = get(p < n ? p : n - 1);                  // clamped, not skipped: the loads stay independent
+      if (p >= n) id[u] = -1;
+    }
+  };
+  fetch(0);
   for (int i = threadIdx.x; i < ELECT_SLOTS; i += ELECT_THREADS) { keys[i] = -1; vals[i] = -1; }
   __syncthreads();
-  for (int64_t p = threadIdx.x; p < n; p += ELECT_THREADS) {
-    const int64_t id = get(p);
-    if (id < 0 || id >= n_nodes || elect_part(id, parts) != part) continue;
-    uint32_t h = ((uint32_t)id * 2654435761u) >> 19;
-    int probes = 0;
-    for (; probes < ELECT_SLOTS; ++probes) {
-      const int32_t old = atomicCAS(&keys[h], -1, (int32_t)id);
-      if (old == -1 || old == (int32_t)id) break;
-      h = (h + 1) & (ELECT_SLOTS - 1);
+  for (int64_t p0 = 0; p0 < n; p0 += CHUNK) {
+    if (p0) fetch(p0);
+#pragma unroll
+    for (int u = 0; u < ELECT_UNROLL; ++u) {
+      const int64_t p = p0 + (int64_t)u * ELECT_THREADS + threadIdx.x, v = id[u];
+      if (v < 0 || v >= n_nodes || elect_part(v, parts) != part) continue;
+      uint32_t h = ((uint32_t)v * 2654435761u) >> 19;
+      int probes = 0;
+      for (; probes < ELECT_SLOTS; ++probes) {
+        const int32_t old = atomicCAS(&keys[h], -1, (int32_t)v);
+        if (old == -1 || old == (int32_t)v) break;
+        h = (h + 1) & (ELECT_SLOTS - 1);
+      }
+      if (probes < ELECT_SLOTS) atomicMax(&vals[h], (int32_t)p);
     }
-    if (probes < ELECT_SLOTS) atomicMax(&vals[h], (int32_t)p);
   }
   __syncthreads();
-  for (int64_t p = threadIdx.x; p < n; p += ELECT_THREADS) {
-    const int64_t id = get(p);
-    const bool valid = id >= 0 && id < n_nodes;
-    if (valid ? elect_part(id, parts) != part : part != 0) continue;   // another part's id (invalid ids: part 0)
-    uint8_t w = 0;
-    if (valid) {
-      uint32_t h = ((uint32_t)id * 2654435761u) >> 19;
-      int probes = 0;
-      while (probes < ELECT_SLOTS && keys[h] != (int32_t)id) { h = (h + 1) & (ELECT_SLOTS - 1); ++probes; }
-      if (probes < ELECT_SLOTS) {
-        w = vals[h] == (int32_t)p;
-      } else {
-        w = 1;
-        for (int64_t p2 = p + 1; p2 < n; ++p2) if (get(p2) == id) { w = 0; break; }
+  for (int64_t p0 = 0; p0 < n; p0 += CHUNK) {
+    if (n > CHUNK) fetch(p0);                          // a single chunk still holds its ids
+#pragma unroll
+    for (int u = 0; u < ELECT_UNROLL; ++u) {
+      const int64_t p = p0 + (int64_t)u * ELECT_THREADS + threadIdx.x, v = id[u];
+      const bool valid = v >= 0 && v < n_nodes;
+      bool mine = p < n && (valid ? elect_part(v, parts) == part : part == 0);   // invalid ids: cleared by part 0
+      uint8_t w = 0;
+      if (mine && valid) {
+        uint32_t h = ((uint32_t)v * 2654435761u) >> 19;
+        int probes = 0;
+        while (probes < ELECT_SLOTS && keys[h] != (int32_t)v) { h = (h + 1) & (ELECT_SLOTS - 1); ++probes; }
+        if (probes < ELECT_SLOTS) {
+          w = vals[h] == (int32_t)p;
+        } else {
+          w = 1;
+          for (int64_t p2 = p + 1; p2 < n; ++p2) if (get(p2) == v) { w = 0; break; }
+        }
       }
-    }
-    winner[p] = w;
-    if (list) {   // the distinct ids of the list, in no particular order: one atomicAdd per wavefront
-      const unsigned long long m = __ballot(w != 0);
-      if (m) {
-        const int ln = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-        int base = 0;
-        if (ln == leader) base = atomicAdd(list_count, __popcll(m));
-        base = __shfl(base, leader, 64);
-        if (w) list[base + __popcll(m & ((1ull << ln) - 1ull))] = (int32_t)id;
+      if (mine) winner[p] = w;
+      if (list) {   // the distinct ids of the list, in no particular order: one atomicAdd per wavefront
+        const unsigned long long m = __ballot(mine && w != 0);
+        if (m) {
+          const int ln = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+          int base = 0;
+          if (ln == leader) base = atomicAdd(list_count, __popcll(m));
+          base = __shfl(base, leader, 64);
+          if (mine && w) list[base + __popcll(m & ((1ull << ln) - 1ull))] = (int32_t)v;
+        }
       }
     }
   }
@@ -120,7 +142,10 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int K, int32_t* __restrict__ o_nbr,
     int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt, orca_claim claim) {
   __shared__ int32_t keys[ELECT_SLOTS], vals[ELECT_SLOTS];
-  auto root = [&](int64_t i) { return i < bs ? src[i] : (i < 2 * bs ? dst[i - bs] : neg[i - 2 * bs]); };
+  auto root = [&](int64_t i) {   // one load through a selected pointer: no branch around it
+    const int64_t* a = i < bs ? src : (i < 2 * bs ? dst - bs : neg - 2 * bs);
+    return a[i];
+  };
   if ((int)blockIdx.x >= nb + parts) { elect_in_lds(keys, vals, 2 * bs, n_nodes, root, win_msg, (int)blockIdx.x - nb - parts, parts, msg_list, msg_count); return; }
   if ((int)blockIdx.x >= nb) { elect_in_lds(keys, vals, 3 * bs, n_nodes, root, win_push, (int)blockIdx.x - nb, parts, nullptr, nullptr); return; }
   const int lane = threadIdx.x & 63;
@@ -258,7 +283,9 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   e->bs = bs; e->Q = Q; e->train = train;
   e->timed_step = e->profile > 0 && (e->step++ % e->profile) == 0;
   e->overlay_covers_batch = train && lo == 0 && hi == Q;
-  const int parts = (int)ceil_div64(Q > 0 ? Q : 1, ELECT_MAX);
+  // the ids of a list are spread over `parts` tables; past a third of a table's capacity two tables already pay
+  // (the workgroups run side by side and each sees half the LDS atomics)
+  const int parts = Q <= ELECT_MAX / 3 ? 1 : (Q <= ELECT_MAX ? 2 : (int)ceil_div64(Q, ELECT_MAX));
   e->winners_valid = d.winners && parts <= ELECT_PARTS_MAX;
   e->persist_done = false;
   e->pushed_layer = 0;
