@@ -18,7 +18,8 @@ struct orca_engine {
   int64_t epoch;       // next unused value of the `slot` scratch table
   int64_t bs, Q;       // current batch
   int train;
-  bool overlay_covers_batch;   // begin() ran in train order over the whole batch: overlay holds every pending root
+  bool overlay_covers_batch;   // train order and the overlay holds every pending positive of the batch (the whole
+                               // batch on this rank, or an overlay-complete state)
   bool winners_valid;          // begin() elected the last occurrences of the push / message-store id lists
   bool persist_done;           // the memory persist of the batch was fused into attention layer 1
   int pushed_layer;            // output of this layer is already in its history table (fused push), 0 = none
@@ -320,8 +321,10 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
       if (rc != ORCA_OK) return rc;
     }
   }
-  const bool eager = train && lo == 0 && hi == Q && e->overlay_complete;
+  const bool full = lo == 0 && hi == Q;
+  const bool eager = train && e->overlay_complete;       // a slice too: every rank lists and applies the global ids
   const bool lazy = train && !eager;
+  e->overlay_covers_batch = train && (full || eager);
   const int64_t cand = n * (K + 1);
   const int64_t claim_epoch = (lazy && n > 0) ? take_epochs(e, cand) : 0;
   {
@@ -367,7 +370,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   // kernels of their own: the memory persist of the positives (train order) and the history push of its output
   orca_tgat_side side{};
   side.zero_word = next_count;
-  if (e->overlay_covers_batch) {
+  if (e->overlay_covers_batch && full) {
     side.persist_memory = d.memory; side.persist_last_update = d.last_update; side.persist_msg_ts = d.msg_ts;
     side.persist_n = 2 * bs;
     e->persist_done = true;
@@ -467,8 +470,9 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
   if (e->train) {                 // tgn_model.py:127-141
     if ((rc = persist()) != ORCA_OK) return rc;
     if ((rc = store()) != ORCA_OK) return rc;
-    // the ids that now hold a fresh message: begin() elected them into this step's list (all ranks elect the
-    // global list, but a sliced step would make every rank redo every rank's rows: it stays on work-lists)
+    // the ids that now hold a fresh message: begin() elected them into this step's list.  Every rank of a sliced
+    // step elects the same global list and applies it redundantly -- for up to 8 ranks that is cheaper than the
+    // per-slice work-list plus an exchange of the positives' rows, and the ranks stay bit-identical
     if (e->list_written && !e->upd_rows && e->overlay_covers_batch) {
       e->have_list = true;
       e->list_bound = 2 * bs < d.q_max ? 2 * bs : d.q_max;

@@ -245,10 +245,12 @@ class OrcaEngine:
     self._ensure_native(Q)
     lo, hi, per = self._slice(Q)
     st = stream()
+    # a sliced train step on a state that is not overlay-complete exchanges the roots' updated memory rows
+    exchange_upd = self.world > 1 and train and not L.orca_engine_get_overlay_complete(self._native)
     check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, lo, hi, int(train), st),
           "orca_engine_begin")
     emb = self._w["emb"]
-    if self.world > 1 and train:      # the roots' updated memory rows: finish() commits the positives from them
+    if exchange_upd:                  # finish() commits the positives from the gathered rows
       self._gather_in_place(self._w["upd"], per)
     for layer in range(2, self.L + 1):
       self._gather_in_place(emb[layer & 1], per)

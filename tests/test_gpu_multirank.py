@@ -42,10 +42,13 @@ def _worker(rank, world, port, q):
       single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=reuse, device=dev, group=None)
       multi.set_neighbor_finder(csr)
       single.set_neighbor_finder(csr)
-      for b in range(4):
+      for b in range(7):
         s, e = 50000 + b * bs, 50000 + (b + 1) * bs
         neg = torch.randint(1, N + 1, (bs,), generator=g, device=dev)
-        train = b < 3
+        train = b != 3
+        if b == 5:      # a restored backup drops the overlay-complete state: the sliced step then builds per-batch
+          multi.restore(multi.backup())      # work-lists and exchanges the roots' updated rows
+          single.restore(single.backup())
         a = multi.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], train)
         c = single.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], train)
         ok = ok and torch.equal(a, c) and torch.equal(multi.memory, single.memory)
