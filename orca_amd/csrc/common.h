@@ -118,60 +118,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr int pw_tiles(int n) { return (n + 15) / 16; }
 __host__ __device__ constexpr int64_t pw_floats(int N, int Kd) { return (int64_t)pw_tiles(N) * pw_tiles(Kd) * 256; }
 
-// One wave accumulates up to NT 16x16 output tiles of C = A(16 x 16*KB) * PW.
-// a_row: LDS pointer to this lane's A row (row l&15) already offset by 4*(l>>4) floats.
-// pw: packed matrix base; tile[t] the n-tile ids; nt <= NT of them are live (wave-uniform).
-// The B operands stream from L2 (every tile is used by exactly one wave of the workgroup, so there is
-// nothing to share through LDS); they are fetched G k-blocks ahead, double buffered in registers, so a
-// chain of KB dependent steps pays the L2 latency once per group instead of once per k-block.
-template <int NT, int G = (NT == 1 ? 6 : (NT == 2 ? 3 : 2))>
-__device__ __forceinline__ void wave_gemm16(const float* a_row, const f32x4* __restrict__ pw, int KB,
-                                            const int (&tile)[NT], int nt, f32x4 (&acc)[NT], int lane) {
-  const f32x4* bp[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) bp[t] = pw + (int64_t)(t < nt ? tile[t] : tile[0]) * KB * 64 + lane;
-  f32x4 cur[G][NT], nxt[G][NT];
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-      if (g < KB && t < nt) cur[g][t] = bp[t][g * 64];
-  for (int kb0 = 0; kb0 < KB; kb0 += G) {
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (kb0 + G + g < KB && t < nt) nxt[g][t] = bp[t][(kb0 + G + g) * 64];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      if (kb0 + g < KB) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(a_row + (kb0 + g) * 16);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], cur[g][t][s], acc[t], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) cur[g][t] = nxt[g][t];
-  }
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
 // cos(x) for the time encoder (model/time_encoding.py:27).  Arguments reach 2.6e6 (Δt in seconds times
 // ω_0 = 1), where the libm cosf takes its slow Payne-Hanek path; here the range reduction x = n·π + r is done
 // in fp64 (two-constant π, error < 1e-9 for |x| < 2^31·π) and cos(r), |r| <= π/2, is ONE even polynomial of
