@@ -116,13 +116,21 @@ def main():
   local = int(os.environ.get("LOCAL_RANK", "0"))
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+  if os.environ.get("ORCA_BENCH_BACKEND", "nccl") != "nccl":
+    local %= torch.cuda.device_count()        # rehearsal: several ranks share the GPUs there are
   torch.cuda.set_device(local)
   dev = torch.device("cuda", local)
   group = None
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=dev)
+    # "nccl" (= RCCL) on a multi-GPU node; ORCA_BENCH_BACKEND=gloo rehearses the N-rank path with several ranks
+    # on ONE GPU (RCCL refuses two ranks per device), rows staged through the host
+    backend = os.environ.get("ORCA_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+      dist.init_process_group("nccl", device_id=dev)
+    else:
+      dist.init_process_group(backend)
     group = dist.group.WORLD
 
   from orca_amd import ops, synth
@@ -174,7 +182,7 @@ def main():
     dt = time.perf_counter() - t0
   if world > 1:
     import torch.distributed as dist
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
   prof = eng.profile_read() or eng.prof_summary()   # HIP events recorded around the kernels inside the timed region
