@@ -237,7 +237,7 @@ class OrcaEngine:
     except Exception:
       pass
 
-  def _step_reuse_native(self, src, dst, neg, ts, eidx, train):
+  def _step_reuse_native(self, src, dst, neg, ts, eidx, train, gather_output=True):
     """Path B + memory/messages through the C++ driver: begin -> (all-gather) -> layer ... -> finish"""
     L = _lib.load()
     bs = src.numel()
@@ -256,9 +256,10 @@ class OrcaEngine:
       self._gather_in_place(emb[layer & 1], per)
       check(L.orca_engine_layer(self._native, layer, lo, hi, st), "orca_engine_layer")
     out = emb[(self.L + 1) & 1]
-    self._gather_in_place(out, per)
+    if gather_output:
+      self._gather_in_place(out, per)
     check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
-    return out[:Q]
+    return out[:Q] if gather_output else out[lo:hi]
 
   def _gather_in_place(self, buf, per):
     """every rank's rows [rank*per, rank*per+per) of buf -> all ranks (RCCL all-gather, in place)"""
@@ -406,9 +407,12 @@ class OrcaEngine:
     return self._attend(n_layers, n, nbr, eid, dt, train, comb, None, h, nbr, False)
 
   # -------------------------------------------------------------------------------------------
-  def compute_temporal_embeddings(self, src, dst, neg, ts, eidx, train=True, cache_plan=None):
+  def compute_temporal_embeddings(self, src, dst, neg, ts, eidx, train=True, cache_plan=None, gather_output=True):
     """model/tgn_model.py:95-147.  src/dst/neg/eidx int64 [bs], ts float64 [bs], device tensors
-    (NumPy arrays are uploaded).  Returns the [3*bs, 100] embeddings of [src; dst; neg]."""
+    (NumPy arrays are uploaded).  Returns the [3*bs, 100] embeddings of [src; dst; neg].
+    gather_output=False (several ranks, Path B): the final embeddings stay sharded by query -- each rank returns
+    the rows of its own slice (`query_slice`) and the closing all-gather is skipped; the state tables are
+    replicated and identical on every rank either way."""
     dev = self.device
     src, dst, neg, eidx = (self._dev(x, torch.int64) for x in (src, dst, neg, eidx))
     ts = self._dev(ts, torch.float64)
@@ -422,7 +426,7 @@ class OrcaEngine:
       self.test_mode = True
     if self.reuse and self.budget == 0 and self.prof is None:
       # Path B end to end in the native driver (embedding, memory persist, message store)
-      return self._step_reuse_native(src, dst, neg, ts, eidx, train)
+      return self._step_reuse_native(src, dst, neg, ts, eidx, train, gather_output)
     self._set_overlay_complete(False)      # the Python-dispatched paths store messages without overlay rows
     nodes = torch.cat([src, dst, neg])
     t3 = torch.cat([ts, ts, ts])

@@ -49,8 +49,14 @@ def _worker(rank, world, port, q):
         if b == 5:      # a restored backup drops the overlay-complete state: the sliced step then builds per-batch
           multi.restore(multi.backup())      # work-lists and exchanges the roots' updated rows
           single.restore(single.backup())
-        a = multi.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], train)
+        sharded = reuse and b in (2, 6)     # outputs left on the rank that computed them (bench.py, N > 1)
+        a = multi.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], train,
+                                              gather_output=not sharded)
         c = single.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], train)
+        if sharded:
+          from orca_amd.dist import query_slice
+          lo, hi, _ = query_slice(3 * bs, rank, world)
+          c = c[lo:hi]
         ok = ok and torch.equal(a, c) and torch.equal(multi.memory, single.memory)
         ok = ok and torch.equal(multi.messages, single.messages) and torch.equal(multi.pending, single.pending)
         ok = ok and torch.equal(multi.last_update, single.last_update) and torch.equal(multi.msg_ts, single.msg_ts)
