@@ -252,19 +252,34 @@ class OrcaEngine:
     emb = self._w["emb"]
     if exchange_upd:                  # finish() commits the positives from the gathered rows
       self._gather_in_place(self._w["upd"], per)
+    def finish():
+      check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
+    # Several ranks: the memory persist and the message store read nothing the later layers write and write
+    # nothing they read (layer >= 2 works on history rows and layer outputs only), so they are enqueued while the
+    # first exchange is in flight instead of after the last layer.  One rank keeps the reference's order: there
+    # the last attention kernel stores the messages itself.
+    early_finish = self.world > 1 and self.L >= 2
     for layer in range(2, self.L + 1):
-      self._gather_in_place(emb[layer & 1], per)
+      if layer == 2 and early_finish:
+        work = self._gather_in_place(emb[layer & 1], per, async_op=True)
+        finish()
+        if work is not None:
+          work.wait()
+      else:
+        self._gather_in_place(emb[layer & 1], per)
       check(L.orca_engine_layer(self._native, layer, lo, hi, st), "orca_engine_layer")
     out = emb[(self.L + 1) & 1]
     if gather_output:
       self._gather_in_place(out, per)
-    check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
+    if not early_finish:
+      finish()
     return out[:Q] if gather_output else out[lo:hi]
 
-  def _gather_in_place(self, buf, per):
-    """every rank's rows [rank*per, rank*per+per) of buf -> all ranks (RCCL all-gather, in place)"""
+  def _gather_in_place(self, buf, per, async_op=False):
+    """every rank's rows [rank*per, rank*per+per) of buf -> all ranks (RCCL all-gather, in place).  async_op:
+    returns the work handle (None when the exchange already completed) -- wait() before reading the rows."""
     if self.world == 1:
-      return
+      return None
     import torch.distributed as dist
     full = buf[:self.world * per]
     mine = full[self.rank * per:(self.rank + 1) * per]
@@ -272,8 +287,9 @@ class OrcaEngine:
       hf = torch.empty(full.shape, dtype=full.dtype)
       dist.all_gather_into_tensor(hf, mine.cpu(), group=self.group)
       full.copy_(hf)
-    else:
-      dist.all_gather_into_tensor(full, mine, group=self.group)
+      return None
+    work = dist.all_gather_into_tensor(full, mine, group=self.group, async_op=async_op)
+    return work if async_op else None
 
   def _build_worklist(self, ids32, ids64, bound):
     """distinct ids of (ids32 ∪ ids64) that hold a pending message -> self.worklist[:count]."""
