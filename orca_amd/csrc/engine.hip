@@ -96,11 +96,13 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
   __syncthreads();
   for (int64_t p0 = 0; p0 < n; p0 += CHUNK) {
     if (n > CHUNK) fetch(p0);                          // a single chunk still holds its ids
+    unsigned long long wmask[ELECT_UNROLL];            // per slot u: the lanes of this wave that hold a winner
+    int total = 0;
 #pragma unroll
     for (int u = 0; u < ELECT_UNROLL; ++u) {
       const int64_t p = p0 + (int64_t)u * ELECT_THREADS + threadIdx.x, v = id[u];
       const bool valid = v >= 0 && v < n_nodes;
-      bool mine = p < n && (valid ? elect_part(v, parts) == part : part == 0);   // invalid ids: cleared by part 0
+      const bool mine = p < n && (valid ? elect_part(v, parts) == part : part == 0);   // invalid ids: cleared by part 0
       uint8_t w = 0;
       if (mine && valid) {
         uint32_t h = ((uint32_t)v * 2654435761u) >> 19;
@@ -114,15 +116,18 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
         }
       }
       if (mine) winner[p] = w;
-      if (list) {   // the distinct ids of the list, in no particular order: one atomicAdd per wavefront
-        const unsigned long long m = __ballot(mine && w != 0);
-        if (m) {
-          const int ln = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-          int base = 0;
-          if (ln == leader) base = atomicAdd(list_count, __popcll(m));
-          base = __shfl(base, leader, 64);
-          if (mine && w) list[base + __popcll(m & ((1ull << ln) - 1ull))] = (int32_t)v;
-        }
+      wmask[u] = __ballot(mine && w != 0);
+      total += __popcll(wmask[u]);
+    }
+    if (list && total) {   // the distinct ids of the list, in no particular order: ONE atomicAdd per wavefront and chunk
+      const int ln = threadIdx.x & 63;                 // (a returning atomic is a full L2 round trip: not one per slot)
+      int base = 0;
+      if (ln == 0) base = atomicAdd(list_count, total);
+      base = __shfl(base, 0, 64);
+#pragma unroll
+      for (int u = 0; u < ELECT_UNROLL; ++u) {
+        if ((wmask[u] >> ln) & 1ull) list[base + __popcll(wmask[u] & ((1ull << ln) - 1ull))] = (int32_t)id[u];
+        base += __popcll(wmask[u]);
       }
     }
   }

@@ -10,10 +10,11 @@
 //   2. lanes 0..K-1 gather the K entries ending at the bound (contiguous in HBM) and write the
 //      right-aligned, zero-padded outputs plus the fused Δt.
 // Algorithmic bytes per query: 16 (indptr pair) + 8*ceil(log2(deg+1)) (probes) + 16K read + 16K written.
-__device__ __forceinline__ int64_t wave_lower_bound(const double* __restrict__ ts, int64_t lo, int64_t hi, double t,
-                                                    int lane) {
-  // invariant: answer in [lo, hi]; elements < lo are < t, element hi (if any) is >= t
-  while (hi - lo > 64) {
+// Narrows [lo, hi] with 64-ary rounds until at most `window` candidates remain.
+// invariant: answer in [lo, hi]; elements < lo are < t, element hi (if any) is >= t
+__device__ __forceinline__ void wave_narrow(const double* __restrict__ ts, int64_t& lo, int64_t& hi, double t, int lane,
+                                            int window) {
+  while (hi - lo > window) {
     int64_t n = hi - lo;
     int64_t step = (n + 63) >> 6;
     int64_t p = lo + (int64_t)(lane + 1) * step - 1;
@@ -27,6 +28,11 @@ __device__ __forceinline__ int64_t wave_lower_bound(const double* __restrict__ t
     lo = nlo < hi ? nlo : hi;
     hi = nhi;
   }
+}
+
+__device__ __forceinline__ int64_t wave_lower_bound(const double* __restrict__ ts, int64_t lo, int64_t hi, double t,
+                                                    int lane) {
+  wave_narrow(ts, lo, hi, t, lane, 64);
   int64_t p = lo + lane;
   bool less = (p < hi) ? (ts[p] < t) : false;
   return lo + __popcll(__ballot(less));
@@ -44,6 +50,42 @@ __device__ __forceinline__ void sample_recent_wave(const int64_t* __restrict__ i
   if (claim.slot) {
     if (q == 0 && lane == 0) *claim.count = 0;
     if (lane == 0 && v >= 0 && v < claim.n_nodes && (!claim.flags || claim.flags[v])) claim.slot[v] = claim.epoch + Q * K + q;
+  }
+  if (K <= 32) {
+    // Last round and gather in ONE memory round trip: the search stops at a window of <= 64 - K candidates, and
+    // the 64 lanes load timestamps, neighbours and edge ids of the entries [lo - K, lo - K + 64), which contain
+    // both the candidates and the K entries before any bound among them.  The bound is a ballot away and slot j
+    // of the answer is a shuffle from lane (bound - lo) + j.  Entries before the row start load as zeros: they
+    // are exactly the padding of a short history.
+    int64_t row_lo = 0, lo = 0, hi = 0;
+    const bool ok = v >= 0 && v < n_rows;
+    if (ok) {
+      row_lo = lo = indptr[v];
+      hi = indptr[v + 1];
+      wave_narrow(ts, lo, hi, t, lane, 64 - K);
+    } else if (err_flag && lane == 0) {
+      *err_flag = 1;
+    }
+    const int64_t p = lo - K + lane;
+    const bool have = ok && p >= row_lo && p < hi;
+    const double tv = have ? ts[p] : 0.0;
+    int32_t n = have ? nbr[p] : 0;
+    int32_t e = have ? eid[p] : 0;
+    const int c = __popcll(__ballot(have && p >= lo && tv < t));   // bound = lo + c
+    float et = (float)tv;
+    const int from = (c + lane) & 63;                              // lane j < K reads entry (lo + c) - K + j
+    n = __shfl(n, from, 64);
+    e = __shfl(e, from, 64);
+    et = __shfl(et, from, 64);
+    if (lane < K) {
+      const int64_t o = q * K + lane;
+      o_nbr[o] = n;
+      o_eid[o] = e;
+      o_et[o] = et;
+      if (o_dt) o_dt[o] = (float)(t - (double)et);   // embedding_module.py:130-131
+      if (claim.slot && n >= 0 && n < claim.n_nodes && (!claim.flags || claim.flags[n])) claim.slot[n] = claim.epoch + o;
+    }
+    return;
   }
   int64_t lo = 0, i = 0;
   if (v >= 0 && v < n_rows) {
