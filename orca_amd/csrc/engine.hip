@@ -1,13 +1,16 @@
 // Native driver of one TGN batch step in the embedding-reuse (Orca-P) formulation: the launch sequence of
 // model/tgn_model.py:95-147 + modules/embedding_module.py:154-182 issued from C++ on one stream, so a
-// step costs three library calls instead of ~25 Python-dispatched launches (the step is a few hundred
-// microseconds of GPU time: host dispatch, not the kernels, was the limit).  All tables and work buffers
-// are caller-owned (orca_engine_desc); the handle only remembers pointers and the scratch-epoch counter.
+// step costs three library calls instead of ~25 Python-dispatched launches (a step is ~100 microseconds of GPU
+// time: host dispatch, not the kernels, was the limit).  All tables and work buffers are caller-owned
+// (orca_engine_desc); the handle remembers pointers, the scratch-epoch counter and the eager-overlay state.
 //
 // The step is cut where ranks of a multi-GPU run have to exchange rows:
-//   orca_engine_begin  : build [src;dst;neg] queries, sample, GRU overlay, attention layer 1   -> emb[0][lo:hi)
+//   orca_engine_begin  : GRU of the ids the previous step stored (eager overlay; or of the ids this batch reads),
+//                        build [src;dst;neg] queries + sample + elect, attention layer 1     -> emb[0][lo:hi)
 //   orca_engine_layer  : history push of ALL Q rows of the previous layer (global order), attention layer l
 //   orca_engine_finish : persist memory update + raw-message build/store (train or eval order)
+// On one rank in train order the row writes of layer / finish ride inside the attention kernels (orca_tgat_side):
+// 4 launches per step.  DESIGN.md section 3 has the table.
 #include <new>
 #include <vector>
 #include "common.h"
