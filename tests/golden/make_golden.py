@@ -371,6 +371,8 @@ def gen_tgn():
     else:
       run_tgn("B2z", out, graph, edge_feats, sd, n_layers=2, reuse=True, budget=0, bs=50, K=10, n_train=8, n_eval=2, neg_seed=5)
       run_tgn("A1z", out, graph, edge_feats, sd, n_layers=1, reuse=False, budget=0, bs=50, K=5, n_train=4, n_eval=1, neg_seed=6)
+      # BASELINE config 3's shape: zero features, two layers, budgeted reuse with an MRD plan
+      run_tgn("C2z", out, graph, edge_feats, sd, n_layers=2, reuse=True, budget=15, bs=50, K=10, n_train=8, n_eval=0, neg_seed=7)
   np.savez_compressed(os.path.join(OUT, "tgn.npz"), **out)
   sz = os.path.getsize(os.path.join(OUT, "tgn.npz"))
   print("tgn.npz", len(out), "arrays", sz // 1024, "KiB")

@@ -167,7 +167,7 @@ def test_memory_and_updater(api):
 
 
 @pytest.mark.parametrize("tag,graph", [("A1", "g172"), ("A2", "g172"), ("B2", "g172"), ("C2", "g172"),
-                                       ("B2z", "g1"), ("A1z", "g1")])
+                                       ("B2z", "g1"), ("A1z", "g1"), ("C2z", "g1")])
 def test_tgn_flow_like_the_reference(api, golden, tag, graph):
   """The flow of tests/golden/make_golden.py:run_tgn, with orca_amd.api in place of the reference."""
   g = golden("tgn.npz")

@@ -30,7 +30,7 @@ def _engine_and_graph(g, tag, graph):
 
 
 @pytest.mark.parametrize("tag,graph", [("A1", "g172"), ("A2", "g172"), ("B2", "g172"), ("C2", "g172"),
-                                       ("B2z", "g1"), ("A1z", "g1")])
+                                       ("B2z", "g1"), ("A1z", "g1"), ("C2z", "g1")])
 def test_tgn_paths_vs_reference_golden(golden, tag, graph):
   g = golden("tgn.npz")
   eng, train_csr, full_csr, meta, edges = _engine_and_graph(g, tag, graph)

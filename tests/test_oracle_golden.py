@@ -118,7 +118,7 @@ def _run_tgn(g, tag, graph):
 
 
 @pytest.mark.parametrize("tag,graph", [("A1", "g172"), ("A2", "g172"), ("B2", "g172"), ("C2", "g172"),
-                                       ("B2z", "g1"), ("A1z", "g1")])
+                                       ("B2z", "g1"), ("A1z", "g1"), ("C2z", "g1")])
 def test_tgn_paths(golden, tag, graph):
   _run_tgn(golden("tgn.npz"), tag, graph)
 
