@@ -396,14 +396,29 @@ class OrcaEngine:
     u = u[self.cache_flag[0][u] == 0]
     return u[1:]
 
-  # Path C: embedding_module.py:215-285 (single rank: its control flow depends on global sets)
+  def _attend_partitioned(self, layer, n, nbr, eid, dt, train, src_table, src_idx, nbr_table, from_memory):
+    """_attend over this rank's contiguous share of the n queries, rows all-gathered back to [n, D]"""
+    if self.world == 1:
+      return self._attend(layer, n, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr, from_memory)
+    lo, hi, per = self._slice(n)
+    if src_idx is None:                               # dense source rows: row q belongs to query q
+      src_table = src_table[lo:hi]
+    else:
+      src_idx = src_idx[lo:hi]
+    part = self._attend(layer, hi - lo, nbr[lo:hi], eid[lo:hi], dt[lo:hi], train, src_table, src_idx, nbr_table,
+                        nbr[lo:hi], from_memory)
+    return self._all_gather_rows(part, n, per)
+
+  # Path C: embedding_module.py:215-285.  Its control flow depends on global sets (which neighbours are cached), so
+  # every rank samples all the queries and derives the same sets; the attention evaluations -- the cost -- are cut
+  # into per-rank query slices and their rows all-gathered.
   def _embed_budget(self, nodes, ts, n_layers, cache_plan, train):
     n = nodes.numel()
     nbr, eid, dt = self._sample(nodes, ts)
     if n_layers == 1:                                 # :224-246
       if train:
         self._overlay_updated_memory(nbr, nodes)
-      return self._attend(1, n, nbr, eid, dt, train, self.memory, nodes.to(torch.int32), self.memory, nbr, True)
+      return self._attend_partitioned(1, n, nbr, eid, dt, train, self.memory, nodes.to(torch.int32), self.memory, True)
     unc = self._find_uncached(nodes, nbr)             # :251
     if unc.numel():                                   # :253-260
       c_nodes = torch.cat([nodes, unc])
@@ -420,7 +435,7 @@ class OrcaEngine:
         ops.set_flags(flag, ids64=cache_plan, v=1)
     else:                                             # history.py:30
       ops.set_flags(flag, ids64=c_nodes, v=1)
-    return self._attend(n_layers, n, nbr, eid, dt, train, comb, None, h, nbr, False)
+    return self._attend_partitioned(n_layers, n, nbr, eid, dt, train, comb, None, h, False)
 
   # -------------------------------------------------------------------------------------------
   def compute_temporal_embeddings(self, src, dst, neg, ts, eidx, train=True, cache_plan=None, gather_output=True):
@@ -448,8 +463,6 @@ class OrcaEngine:
     t3 = torch.cat([ts, ts, ts])
     positives = nodes[:2 * src.numel()]
     if self.reuse and self.budget != 0:                # :114-120
-      if self.world != 1:
-        raise OrcaError("budgeted reuse (Path C) runs on one rank")
       plan = self._dev(cache_plan, torch.int64) if cache_plan is not None else None
       emb = self._embed_budget(nodes, t3, self.L, plan, train)
     elif self.reuse:

@@ -62,6 +62,19 @@ def _worker(rank, world, port, q):
         ok = ok and torch.equal(multi.last_update, single.last_update) and torch.equal(multi.msg_ts, single.msg_ts)
         if reuse:
           ok = ok and torch.equal(multi.hist[0], single.hist[0])
+    # Path C (budgeted reuse with a cache plan per batch): global set algebra on every rank, attention partitioned
+    multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=dist.group.WORLD)
+    single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None)
+    multi.set_neighbor_finder(csr)
+    single.set_neighbor_finder(csr)
+    for b in range(3):
+      s, e = 50000 + b * bs, 50000 + (b + 1) * bs
+      neg = torch.randint(1, N + 1, (bs,), generator=g, device=dev)
+      plan = torch.randint(1, N + 1, (40,), generator=g, device=dev)
+      a = multi.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True, plan)
+      c = single.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True, plan)
+      ok = ok and torch.equal(a, c) and torch.equal(multi.memory, single.memory)
+      ok = ok and torch.equal(multi.hist[0], single.hist[0]) and torch.equal(multi.cache_flag[0], single.cache_flag[0])
     q.put((rank, bool(ok), ""))
     dist.barrier()
     dist.destroy_process_group()
