@@ -228,6 +228,13 @@ def main():
                          "bytes_per_query": synth.tgat_bytes_per_query(args.d_e, args.k),
                          "hbm_gbs_algorithmic": synth.tgat_bytes_per_query(args.d_e, args.k) * q_mean / (ms * 1e-3) / 1e9}
       out["kernels_ms"] = {k: {"launches": v[0], "avg_ms": v[1]} for k, v in prof.items()}
+      w = getattr(eng, "_w", None)
+      if w is not None and "gru_update" in prof:      # rows of the last eager list = distinct ids a batch stores
+        rows = int(w["eager_count"].max().item())
+        if rows:
+          gms = prof["gru_update"][1]
+          out["gru"] = {"rows_per_launch": rows, "flops_per_row": 2 * (3 * 100 + args.d_e + 100) * 300,
+                        "achieved_tflops": rows * 2 * (3 * 100 + args.d_e + 100) * 300 / (gms * 1e-3) / 1e12}
     if world == 1 and args.cpu_batches > 0:
       threads = min(16, os.cpu_count() or 1)
       out["cpu_baseline"] = cpu_baseline(args, csr, ef, sd, batches[args.warmup:], threads)
