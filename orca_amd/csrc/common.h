@@ -105,6 +105,16 @@ extern thread_local orca_launch_events orca_armed_events;
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), (uint32_t)(lds), stream, _ev.start, _ev.stop, 0, __VA_ARGS__); \
   } while (0)
 
+// true the first time it is called for the current device (function attributes are per device: a process that
+// drives several GPUs has to set them on each)
+static inline bool orca_first_use_on_device(bool (&seen)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (seen[dev]) return false;
+  seen[dev] = true;
+  return true;
+}
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

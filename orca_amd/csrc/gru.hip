@@ -407,10 +407,9 @@ static int gru_launch_rows(const float* blob, int msg_dim, const int32_t* ids, i
                            hipStream_t stream) {
   GBlob L = gru_layout(msg_dim);
   size_t lds_bytes = (size_t)16 * L.AS * sizeof(float) + (size_t)NWG * 4 * 64 * sizeof(f32x4);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (orca_first_use_on_device(attr_set)) {
     ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_gru_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    attr_set = true;
   }
   ORCA_LAUNCH_TIMED((k_gru_rows<1>), (unsigned)ceil_div64(n, 16), KS2 * NWG * 64, lds_bytes, stream, blob, msg_dim, ids, n,
                     n_dev, x, h, out, last_update, msg_ts);

@@ -778,13 +778,12 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
   ORCA_REQUIRE(in->nbr_idx || Q * K < (1LL << 31), "orca_tgat_forward: dense mode limited to Q*K < 2^31");
   Blob L = blob_layout(d_e);
   size_t lds_bytes = (size_t)(2 * TQ * ASTR + TQ * HSTR + TQ * (L.KBT * 16 + 4)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (orca_first_use_on_device(attr_set)) {
     const int lim = 160 * 1024 - 256;
     ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<10, 172>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<10, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    attr_set = true;
   }
   ORCA_REQUIRE(lds_bytes <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds_bytes);
   const unsigned grid = (unsigned)ceil_div64(Q, TQ);
