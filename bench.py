@@ -228,6 +228,13 @@ def main():
                          "bytes_per_query": synth.tgat_bytes_per_query(args.d_e, args.k),
                          "hbm_gbs_algorithmic": synth.tgat_bytes_per_query(args.d_e, args.k) * q_mean / (ms * 1e-3) / 1e9}
       out["kernels_ms"] = {k: {"launches": v[0], "avg_ms": v[1]} for k, v in prof.items()}
+      if "sample_recent" in prof and not args.no_reuse:   # first kernel of the step: build + sample + elections
+        deg = 2.0 * args.edges / max(args.nodes, 1)
+        bpq = 32 * args.k + 16 + 8 * int(np.ceil(np.log2(deg + 1)))
+        sms = prof["sample_recent"][1]
+        out["sampler"] = {"bytes_per_query": bpq, "queries_per_launch": Q, "avg_launch_ms": sms,
+                          "achieved_gbs": bpq * Q / (sms * 1e-3) / 1e9, "peak_gbs": PEAK_HBM_GBS,
+                          "note": "latency-bound: ~5 dependent memory round trips per query, 1.6 MB per launch"}
       w = getattr(eng, "_w", None)
       if w is not None and "gru_update" in prof:      # rows of the last eager list = distinct ids a batch stores
         rows = int(w["eager_count"].max().item())
