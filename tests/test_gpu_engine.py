@@ -215,3 +215,40 @@ def test_eager_overlay_survives_mode_changes(golden):
   ref.reset_history()
   step(300, True, "train after reset")
   step(300, True, "train after reset, 2")
+
+
+def test_native_driver_rejects_bad_calls(golden):
+  """Argument checks of the orca_engine_* entry points: a batch beyond the work buffers, a layer outside the
+  model, a slice outside the batch -- each refused with ORCA_EINVAL (ValueError in the mirror) and a message,
+  leaving the driver usable."""
+  import ctypes
+  from orca_amd import _lib, ops
+  from orca_amd.engine import OrcaEngine
+  g = golden("tgn.npz")
+  sd = {k[len("g172_sd."):]: g[k] for k in g.files if k.startswith("g172_sd.")}
+  N, E, K = 3000, 40000, 10
+  src, dst, ts, eidx, ef = _synthetic(31, N, E, 172)
+  eng = OrcaEngine(sd, ef, N + 1, 2, K, True, 0, device=DEV)
+  eng.set_neighbor_finder(ops.CSR.from_edges_device(*(torch.from_numpy(x).to(DEV) for x in (src, dst, eidx, ts)), N + 1))
+  rs = np.random.RandomState(32)
+  s, e = 30000, 30100
+  neg = rs.randint(1, N + 1, 100).astype(np.int64)
+  ok = eng.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True).clone()
+  L, h = _lib.load(), eng._native
+  t = [torch.from_numpy(x).to(DEV) for x in (src[s:e], dst[s:e], neg, eidx[s:e])] + [torch.from_numpy(ts[s:e]).to(DEV)]
+  p = [x.data_ptr() for x in t]
+  st = torch.cuda.current_stream().cuda_stream
+  big = eng._q_max // 3 + 1
+  with pytest.raises(ValueError, match="does not fit"):
+    _lib.check(L.orca_engine_begin(h, p[0], p[1], p[2], p[3], p[4], big, 0, 3 * big, 1, st), "orca_engine_begin")
+  with pytest.raises(ValueError, match="slice"):
+    _lib.check(L.orca_engine_begin(h, p[0], p[1], p[2], p[3], p[4], 100, 10, 400, 1, st), "orca_engine_begin")
+  with pytest.raises(ValueError, match="layer"):
+    _lib.check(L.orca_engine_layer(h, 3, 0, 300, st), "orca_engine_layer")
+  with pytest.raises(ValueError, match="null"):
+    _lib.check(L.orca_engine_begin(h, None, p[1], p[2], p[3], p[4], 100, 0, 300, 1, st), "orca_engine_begin")
+  # an empty batch is a no-op, and the driver still works afterwards
+  assert eng.compute_temporal_embeddings(src[:0], dst[:0], neg[:0], ts[:0], eidx[:0], True).shape == (0, 100)
+  eng.reset_state()
+  again = eng.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True)
+  assert torch.equal(ok, again)
