@@ -101,6 +101,13 @@ int orca_tgat_pack(int d_e, const float* q_proj_w, const float* k_proj_w, const 
                    const float* in_proj_b, const float* out_proj_w, const float* out_proj_b,
                    const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                    const float* ln_w, const float* ln_b, float* blob, void* stream);
+/* Optional second step after orca_tgat_pack for blobs used in gather mode: the source's own time encoding
+ * there is the constant cos(time_b) (modules/embedding_module.py:126, a zero time delta), so the q projection
+ * (model/temporal_attention.py:48, in_proj of nn.MultiheadAttention) multiplies into the key map and the
+ * kernel skips one GEMM stage.  The blob is then tied to this time_b: gather-mode calls must pass the same
+ * values in orca_tgat_inputs.time_b; dense-mode calls are unaffected.  Re-run after either changes. */
+int orca_tgat_pack_gather(int d_e, const float* q_proj_w, const float* k_proj_w, const float* in_proj_b,
+                          const float* time_b, float* blob, void* stream);
 
 /* Where the rows of one attention call come from.  Two modes:
  *  gather: rows are fetched by index from feature tables (the fused path used by
@@ -133,6 +140,9 @@ typedef struct {
   const float* time_b;
   const float* src_time;
   const float* nbr_time;
+  /* nonzero (gather mode only): the caller states that `blob` was completed by orca_tgat_pack_gather with these
+   * time_b values; the kernel then takes q~ straight from the source rows.  0 = the general path. */
+  int32_t q_folded;
 } orca_tgat_inputs;
 
 /* out [Q, ORCA_D]; out_weights [Q, K] (head-averaged attention, may be NULL).  1 <= K <= ORCA_MAX_K. */
@@ -269,6 +279,7 @@ typedef struct {
   int32_t* eager_ids;              /* [2, q_max] or NULL: the distinct ids whose raw message a train-ordered step
                                       stored (two halves, written and consumed by alternate steps) */
   int32_t* eager_count;            /* [2] their counts; zero-initialised by the caller */
+  int32_t att_q_folded;            /* nonzero: every att_blob was completed by orca_tgat_pack_gather with time_b */
 } orca_engine_desc;
 
 int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** out);

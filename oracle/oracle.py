@@ -190,9 +190,14 @@ def time_encode_weights(dim=100):
   return torch.from_numpy(1 / 10 ** np.linspace(0, 9, dim, dtype=np.float32))
 
 
-def time_encode(t, w):
-  """time_encoding.py:26-27: cos(Linear(1,dim)(t.unsqueeze(2))) with zero bias."""
-  return torch.cos(t.unsqueeze(-1) * w)
+def time_encode(t, w, b=None):
+  """time_encoding.py:26-27: cos(Linear(1,dim)(t.unsqueeze(2))).  With a bias the argument is the rounded
+  product plus the bias (two roundings).  torch's CPU linear is NOT used for this: it rounds once or twice
+  depending on the host's MKL code path, which moves single values by O(0.1) at t ~ 1e6.  The reference's
+  fixtures all have b = 0, where the order cannot matter: the b != 0 case is parity-unpinned."""
+  if b is None:
+    return torch.cos(t.unsqueeze(-1) * w)
+  return torch.cos(t.unsqueeze(-1) * w + b)
 
 
 # ------------------------------------------------------------------------------------------
@@ -257,6 +262,8 @@ class OracleTGN:
     self.L, self.K, self.reuse, self.budget, self.D = n_layers, K, reuse, budget, D
     self.msg_dim = 2 * D + self.d_e + D   # tgn_model.py:49-50
     self.w_time = self.sd["time_encoder.w.weight"].reshape(-1)
+    b = self.sd.get("time_encoder.w.bias")
+    self.b_time = b.reshape(-1) if b is not None and bool((b != 0).any()) else None
     self.att = [{k[len(f"embedding_module.attention_models.{i}."):]: v for k, v in self.sd.items()
                  if k.startswith(f"embedding_module.attention_models.{i}.")} for i in range(n_layers)]
     self.gru = {k[len("memory_updater.memory_updater."):]: v for k, v in self.sd.items()
@@ -313,8 +320,8 @@ class OracleTGN:
   def _aggregate(self, layer, src_feat, nbr_feat, dt, eid_t, mask):
     """embedding_module.py:318-329 with the time encodings of :126,132 and the gather of :133."""
     B = src_feat.shape[0]
-    src_t = time_encode(torch.zeros(B, 1), self.w_time)
-    nbr_t = time_encode(dt, self.w_time)
+    src_t = time_encode(torch.zeros(B, 1), self.w_time, self.b_time)
+    nbr_t = time_encode(dt, self.w_time, self.b_time)
     edge = self.edge_feats[eid_t]
     out, _ = attention_forward(self.att[layer - 1], src_feat, src_t, nbr_feat, nbr_t, edge, mask)
     return out
@@ -400,7 +407,7 @@ class OracleTGN:
     et = torch.from_numpy(t2[index]).float()
     ef = self.edge_feats[torch.from_numpy(e2[index])]
     delta = et - self.last_update[uniq]
-    enc = time_encode(delta.unsqueeze(1), self.w_time).view(len(uniq), -1)
+    enc = time_encode(delta.unsqueeze(1), self.w_time, self.b_time).view(len(uniq), -1)
     msg = torch.cat([self.memory[uniq], self.memory[up], ef, enc], dim=1)
     self.pending[uniq] = True
     self.messages[uniq] = msg

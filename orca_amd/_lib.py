@@ -23,7 +23,7 @@ class TgatInputs(ctypes.Structure):
       "src_table", "src_idx", "src_overlay", "src_flags",
       "nbr_table", "nbr_idx", "nbr_overlay", "nbr_flags",
       "nbr_ids", "mask", "edge_table", "edge_idx",
-      "dt", "time_w", "time_b", "src_time", "nbr_time")]
+      "dt", "time_w", "time_b", "src_time", "nbr_time")] + [("q_folded", ctypes.c_int32)]
 
 
 ORCA_ENGINE_MAX_LAYERS = 4
@@ -37,7 +37,8 @@ class EngineDesc(ctypes.Structure):
                ("messages", vp), ("msg_ts", vp), ("pending", vp), ("overlay", vp),
                ("hist", vp * (ORCA_ENGINE_MAX_LAYERS - 1)), ("slot", vp), ("worklist", vp), ("count", vp),
                ("q_max", i64), ("nodes", vp), ("qts", vp), ("nodes32", vp), ("nbr", vp), ("eid", vp), ("et", vp),
-               ("dt", vp), ("emb", vp * 2), ("winners", vp), ("upd", vp), ("eager_ids", vp), ("eager_count", vp)])
+               ("dt", vp), ("emb", vp * 2), ("winners", vp), ("upd", vp), ("eager_ids", vp), ("eager_count", vp),
+               ("att_q_folded", ctypes.c_int32)])
 
 
 # name -> (restype, argtypes); every symbol include/orca_hip.h declares
@@ -57,6 +58,7 @@ SIGNATURES = {
     "orca_time_encode": (i32, [vp, i64, vp, vp, vp, vp]),
     "orca_tgat_blob_floats": (i64, [i32]),
     "orca_tgat_pack": (i32, [i32] + [vp] * 14),
+    "orca_tgat_pack_gather": (i32, [i32] + [vp] * 6),
     "orca_tgat_forward": (i32, [vp, i32, ctypes.POINTER(TgatInputs), i64, i32, vp, vp, vp]),
     "orca_debug_tgat_phase_clock": (i32, [vp]),
     "orca_debug_gru_phase_clock": (i32, [vp]),

@@ -155,8 +155,17 @@ __device__ __forceinline__ float orca_cosf(float x) {
   p = __builtin_fmaf(u, p, 1.0f);
   return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p) ^ sign);
 }
-// t·ω + φ exactly as nn.Linear(1, D) rounds it: one rounded product, then the bias add (no fma contraction)
-__device__ __forceinline__ float orca_time_arg(float t, float w, float b) { return __fadd_rn(__fmul_rn(t, w), b); }
+// t·ω + φ of nn.Linear(1, D) (time_encoding.py:26) with TWO roundings: the product, then the bias add.  With
+// φ = 0 (the reference's initial value and every fixture it holds) the rounding order cannot matter; with a
+// trained φ != 0 torch's own CPU linear rounds once or twice depending on the MKL code path of the host (measured:
+// twice on the GPU box's host, once in the build container), which moves single cos values by O(0.1) at
+// t ~ 1e6.  Two roundings is also what a GEMM with a bias epilogue does; contraction is switched off so that the
+// choice does not hang on the compiler's default.
+__device__ __forceinline__ float orca_time_arg(float t, float w, float b) {
+#pragma clang fp contract(off)
+  const float p = t * w;
+  return p + b;
+}
 
 // Raw message of one interaction side, built and stored by one wavefront (model/tgn_model.py:172-191 +
 // modules/memory.py:25-28): messages[id] = [memory[id] | memory[partner] | edge_feats[eidx] | cos(w (t - last_update[id]) + b)],

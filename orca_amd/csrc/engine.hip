@@ -358,7 +358,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   in.src_table = d.memory; in.src_idx = d.nodes32 + lo;
   in.nbr_table = d.memory; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
-  in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b;
+  in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b; in.q_folded = d.att_q_folded;
   if (lazy) {    // :159-161 get_updated_memory(unique(neighbors ∪ sources)) -> overlay rows
     rc = orca_worklist_append(d.nbr, n * K, d.nodes + lo, n, d.pending, d.slot, claim_epoch, d.n_nodes, d.worklist,
                               d.count, stream_);
@@ -414,7 +414,7 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
   in.src_table = prev + lo * ORCA_D;               // dense rows of this rank's slice
   in.nbr_table = h; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;   // pull (history.py:32-36) fused into the gather
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
-  in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b;
+  in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b; in.q_folded = d.att_q_folded;
   orca_tgat_side side{};
   if (lo == 0 && hi == e->Q && e->winners_valid && layer < d.n_layers) {   // this layer's output feeds the next history
     side.push_table = d.hist[layer - 1]; side.push_ids = d.nodes; side.push_winner = d.winners;

@@ -36,7 +36,7 @@ constexpr int MAXE = (ORCA_MAX_DE + 63) / 64;   // edge-feature registers per la
 
 struct Blob {   // float offsets inside the packed parameter blob
   int kdim, KP, NTk, KBk, KBT;
-  int64_t pw_q, b_q, pw_kt, pw_t, b_1, pw_2, b_2, ln_w, ln_b, total;
+  int64_t pw_q, b_q, pw_kt, pw_t, b_1, pw_2, b_2, ln_w, ln_b, pw_qk, b_qk, qk_flag, total;
 };
 
 __host__ __device__ constexpr Blob blob_layout(int d_e) {
@@ -58,6 +58,11 @@ __host__ __device__ constexpr Blob blob_layout(int d_e) {
   L.b_2 = o;   o += 112;
   L.ln_w = o;  o += 112;
   L.ln_b = o;  o += 112;
+  // gather mode only (orca_tgat_pack_gather): the q projection folded into the key map, per head
+  // [kdim+1 x 100] over src plus a constant column vector; qk_flag != 0 once they are filled in
+  L.pw_qk = o; o += 2 * pw_floats(L.kdim + 1, D);
+  L.b_qk = o;  o += 2 * L.KP;
+  L.qk_flag = o; o += 16;
   L.total = o;
   return L;
 }
@@ -98,6 +103,39 @@ __global__ void k_fold_f(const double* __restrict__ U, const float* __restrict__
   }
   F[i] = (float)acc;
 }
+
+// ---- folding the q projection into the key map (gather mode: the source's time encoding is the constant
+// cos(time_b), embedding_module.py:126) ---------------------------------------------------------------------
+// t[j] = bq[j] + sum_i Wq[j][100 + i] cos(time_b[i])          (q_w [200, 200] row-major, j < 200)
+__global__ void k_fold_qt(const float* __restrict__ q_w, const float* __restrict__ in_b,
+                          const float* __restrict__ time_b, double* __restrict__ t) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= QD) return;
+  double acc = (double)in_b[j];
+  for (int i = 0; i < D; ++i)
+    acc += (double)q_w[j * QD + D + i] * (double)orca_cosf(orca_time_arg(0.0f, 0.0f, time_b[i]));
+  t[j] = acc;
+}
+// A [2][kdim+1][100]: A[h][c][s] = 0.1 sum_d Wk'[h][d][c] Wq[h*100 + d][s], with Wk'[h][d][kdim] = bk[h*100 + d];
+// a [2][KP]: a[h][c] = 0.1 sum_d Wk'[h][d][c] t[h*100 + d]    (zero beyond kdim)
+__global__ void k_fold_qk(const float* __restrict__ q_w, const float* __restrict__ k_w, const float* __restrict__ in_b,
+                          const double* __restrict__ t, int kdim, int KP, float* __restrict__ A,
+                          float* __restrict__ a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = (kdim + 1) * (D + 1);
+  if (i >= 2 * per) return;
+  const int h = i / per, c = (i % per) / (D + 1), s = i % (D + 1);
+  const double scale = (double)0.1f;
+  double acc = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const int j = h * D + d;
+    const double wk = c < kdim ? (double)k_w[(int64_t)j * kdim + c] : (double)in_b[QD + j];
+    acc += wk * (s < D ? (double)q_w[j * QD + s] : t[j]);
+  }
+  if (s < D) A[((int64_t)h * (kdim + 1) + c) * D + s] = (float)(scale * acc);
+  else a[h * KP + c] = (float)(scale * acc);
+}
+__global__ void k_set_flag(float* p) { *p = 1.0f; }
 
 __global__ void k_pack(float* __restrict__ dst, int KB, int n0, int n_cnt, int Kd, const float* __restrict__ src,
                        int64_t sn, int64_t sk) {
@@ -192,6 +230,42 @@ ORCA_API int orca_tgat_pack(int d_e, const float* q_w, const float* k_w, const f
   rc |= copy_pad(blob + L.ln_b, ln_b, D, 112, s);
   if (rc != ORCA_OK) {
     orca_set_error("orca_tgat_pack: kernel launch failed");
+    return ORCA_EHIP;
+  }
+  return ORCA_OK;
+}
+
+ORCA_API int orca_tgat_pack_gather(int d_e, const float* q_w, const float* k_w, const float* in_b,
+                                   const float* time_b, float* blob, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  ORCA_REQUIRE(d_e >= 1 && d_e <= ORCA_MAX_DE, "orca_tgat_pack_gather: d_e=%d outside [1,%d]", d_e, ORCA_MAX_DE);
+  ORCA_REQUIRE(q_w && k_w && in_b && time_b && blob, "orca_tgat_pack_gather: null pointer");
+  Blob L = blob_layout(d_e);
+  const int kdim = L.kdim;
+  double* t = nullptr;
+  float* A = nullptr;
+  ORCA_HIP_TRY(hipMalloc(&t, sizeof(double) * QD));
+  if (hipMalloc(&A, sizeof(float) * 2 * (kdim + 1) * D) != hipSuccess) {
+    (void)hipFree(t);
+    orca_set_error("orca_tgat_pack_gather: out of device memory for the fold scratch");
+    return ORCA_ENOMEM;
+  }
+  int rc = ORCA_OK;
+  hipError_t e0 = hipMemsetAsync(blob + L.b_qk, 0, sizeof(float) * 2 * L.KP, s);
+  k_fold_qt<<<1, 256, 0, s>>>(q_w, in_b, time_b, t);
+  k_fold_qk<<<(2 * (kdim + 1) * (D + 1) + 255) / 256, 256, 0, s>>>(q_w, k_w, in_b, t, kdim, L.KP, A, blob + L.b_qk);
+  for (int h = 0; h < 2; ++h)
+    rc |= orca_pack_matrix(blob + L.pw_qk + (int64_t)h * pw_floats(kdim + 1, D), L.NTk, pw_tiles(D), 0, kdim + 1, D,
+                           A + (int64_t)h * (kdim + 1) * D, D, 1, s);
+  k_set_flag<<<1, 1, 0, s>>>(blob + L.qk_flag);
+  if (hipGetLastError() != hipSuccess) rc = ORCA_EHIP;
+  const hipError_t e1 = hipStreamSynchronize(s);
+  (void)hipFree(t);
+  (void)hipFree(A);
+  ORCA_HIP_TRY(e0);
+  ORCA_HIP_TRY(e1);
+  if (rc != ORCA_OK) {
+    orca_set_error("orca_tgat_pack_gather: kernel launch failed");
     return ORCA_EHIP;
   }
   return ORCA_OK;
@@ -422,7 +496,7 @@ __device__ __forceinline__ float half_sum(float v) {
 // the second-chunk code fold away) or 0 = run-time K <= ORCA_MAX_K.
 // DE = compile-time edge width (172, the Wikipedia / Reddit / benchmark width: every k-block count of the
 // projection chains becomes a constant) or 0 = run-time d_e <= ORCA_MAX_DE.
-template <int KT, int DE>
+template <int KT, int DE, bool QK>
 __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restrict__ blob, int d_e_rt,
                                                           orca_tgat_inputs in, int64_t Q, int K_rt,
                                                           float* __restrict__ out, float* __restrict__ out_w,
@@ -463,8 +537,16 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   // LayerNorm affine parameters (P8) and the q-projection weights depend on nothing: fetch them right away
   const float ln_ga = blob[L.ln_w + lane], ln_ba = blob[L.ln_b + lane];
   const float ln_gb = blob[c1 < D ? L.ln_w + c1 : L.ln_w], ln_bb = blob[c1 < D ? L.ln_b + c1 : L.ln_b];
+  // QK: gather mode with a blob completed by orca_tgat_pack_gather: q~ comes straight from src (no P1)
+  constexpr bool qk = QK;
+  const int h2 = wave & 1;                        // P2: wave (h2, slot = wave >> 1)
   WaveGemm<1, 7, 13, true> g1;
-  g1.prefetch(blob4 + L.pw_q / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_q);
+  WaveGemm<3, 3, 7, FOLD_ALL> g2;
+  if constexpr (qk)
+    g2.prefetch(blob4 + (L.pw_qk + (int64_t)h2 * pw_floats(kdim + 1, D)) / 4, NT100, wave >> 1, NW / 2, L.NTk, lane,
+                blob + L.b_qk + h2 * KPS);
+  else
+    g1.prefetch(blob4 + L.pw_q / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_q);
 
   // ---- T0: this wave's query: neighbour slots, source row, L2 touches, time encodings ------------
   const int64_t q = q0 + wave;
@@ -552,21 +634,21 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   stamp();
 
   // ---- P1: q = Wq [src|time] + bq, scaled by sqrt(1/head_dim) -> bufP ---------------------------
-  {
+  if constexpr (!qk) {
     g1.run(bufQ + a_off * ASTR + a_k, lane, [&](int m, int n, float v) {
       if (n < ASTR) bufP[m * ASTR + n] = (n < QD) ? v * 0.1f : 0.0f;
     });
+    g2.prefetch(blob4 + (L.pw_kt + (int64_t)h2 * pw_floats(kdim + 1, D)) / 4, NT100, wave >> 1, NW / 2, L.NTk, lane);
+    __syncthreads();
   }
-  // ---- P2: q~_h = Wk_h^T (0.1 q_h)  (column kdim carries (0.1 q_h).bk_h): wave (h = w&1, slot = w>>1)
-  //      owns tiles slot, slot+8, slot+16 of head h -> bufT
-  const int h2 = wave & 1;
-  WaveGemm<3, 3, 7, FOLD_ALL> g2;
-  g2.prefetch(blob4 + (L.pw_kt + (int64_t)h2 * pw_floats(kdim + 1, D)) / 4, NT100, wave >> 1, NW / 2, L.NTk, lane);
-  __syncthreads();
   stamp();
+  // ---- P2: q~_h = Wk_h^T (0.1 q_h)  (column kdim carries (0.1 q_h).bk_h): wave (h = w&1, slot = w>>1)
+  //      owns tiles slot, slot+8, slot+16 of head h -> bufT.  With the folded map the operand is src itself
+  //      (the columns 100..111 of bufQ hold finite time values that meet zero weights).
   {
     float* dstT = bufT + h2 * KPS;
-    g2.run(bufP + h2 * D + a_off * ASTR + a_k, lane, [&](int m, int n, float v) { dstT[m * RS + n] = v; });
+    g2.run((qk ? bufQ : bufP + h2 * D) + a_off * ASTR + a_k, lane,
+           [&](int m, int n, float v) { dstT[m * RS + n] = v; });
   }
   __syncthreads();
   stamp();
@@ -781,19 +863,31 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
   static bool attr_set[64] = {};
   if (orca_first_use_on_device(attr_set)) {
     const int lim = 160 * 1024 - 256;
-    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<10, 172>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<10, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_tgat_forward<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    const void* fns[] = {(const void*)k_tgat_forward<10, 172, false>, (const void*)k_tgat_forward<10, 172, true>,
+                         (const void*)k_tgat_forward<10, 0, false>,   (const void*)k_tgat_forward<10, 0, true>,
+                         (const void*)k_tgat_forward<0, 0, false>,    (const void*)k_tgat_forward<0, 0, true>};
+    for (const void* f : fns) ORCA_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
   ORCA_REQUIRE(lds_bytes <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds_bytes);
+  ORCA_REQUIRE(!in->q_folded || in->dt, "orca_tgat_forward: q_folded needs gather-mode time inputs (dt)");
   const unsigned grid = (unsigned)ceil_div64(Q, TQ);
   hipStream_t st = (hipStream_t)stream;
+#define ORCA_TGAT_LAUNCH(KT_, DE_)                                                                              \
+  do {                                                                                                          \
+    if (in->q_folded)                                                                                           \
+      ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, \
+                        out_weights, side, g_phase_clock);                                                      \
+    else                                                                                                        \
+      ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, false>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, \
+                        out_weights, side, g_phase_clock);                                                      \
+  } while (0)
   if (K == 10 && d_e == 172)
-    ORCA_LAUNCH_TIMED((k_tgat_forward<10, 172>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, side, g_phase_clock);
+    ORCA_TGAT_LAUNCH(10, 172);
   else if (K == 10)
-    ORCA_LAUNCH_TIMED((k_tgat_forward<10, 0>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, side, g_phase_clock);
+    ORCA_TGAT_LAUNCH(10, 0);
   else
-    ORCA_LAUNCH_TIMED((k_tgat_forward<0, 0>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights, side, g_phase_clock);
+    ORCA_TGAT_LAUNCH(0, 0);
+#undef ORCA_TGAT_LAUNCH
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

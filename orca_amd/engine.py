@@ -106,7 +106,8 @@ class OrcaEngine:
     self.att_blobs = []
     for i in range(self.L):
       p = f"embedding_module.attention_models.{i}."
-      self.att_blobs.append(ops.tgat_pack({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, self.d_e, dev))
+      self.att_blobs.append(ops.tgat_pack({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, self.d_e, dev,
+                                          time_b=self.time_b))
     p = "memory_updater.memory_updater."
     self.gru_blob = ops.gru_pack(sd[p + "weight_ih"], sd[p + "weight_hh"], sd[p + "bias_ih"], sd[p + "bias_hh"], dev)
     self.aff = {k[len("affinity_score."):]: v.to(device=dev, dtype=torch.float32)
@@ -203,6 +204,7 @@ class OrcaEngine:
     d.winners = ptr(w["winners"])
     d.upd = ptr(w["upd"]) if w["upd"] is not None else None
     d.eager_ids, d.eager_count = ptr(w["eager_ids"]), ptr(w["eager_count"])
+    d.att_q_folded = 1     # load_state_dict completes every blob with orca_tgat_pack_gather
     h = _lib.vp()
     check(L.orca_engine_create(ctypes.byref(d), ctypes.byref(h)), "orca_engine_create")
     L.orca_engine_take_epochs(h, self.slot_epoch)       # continue after the epochs already used on `slot`
@@ -330,7 +332,8 @@ class OrcaEngine:
     """embedding_module.py:318-329 (aggregate) fused with the gathers of :123,133,172-174 and the
     time encodings of :126,132."""
     kw = dict(src_table=src_table, src_idx=src_idx, nbr_table=nbr_table, nbr_idx=nbr_idx, nbr_ids=nbr,
-              edge_table=self.edge_feats, edge_idx=eid, dt=dt, time_w=self.time_w, time_b=self.time_b)
+              edge_table=self.edge_feats, edge_idx=eid, dt=dt, time_w=self.time_w, time_b=self.time_b,
+              q_folded=True)
     if from_memory and train:
       kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
     out, _ = self._timed("tgat_forward", ops.tgat_forward, self.att_blobs[layer - 1], self.d_e, Q, self.K, **kw)

@@ -154,8 +154,9 @@ TGAT_KEYS = ("multi_head_target.q_proj_weight", "multi_head_target.k_proj_weight
              "norm.weight", "norm.bias")
 
 
-def tgat_pack(sd, d_e, device, blob=None):
-  """Packs one TemporalAttentionLayer state_dict (keys TGAT_KEYS) into the kernel's blob."""
+def tgat_pack(sd, d_e, device, blob=None, time_b=None):
+  """Packs one TemporalAttentionLayer state_dict (keys TGAT_KEYS) into the kernel's blob.  With time_b (the
+  time encoder's bias) the blob is also completed for gather mode (orca_tgat_pack_gather)."""
   n = _lib.load().orca_tgat_blob_floats(int(d_e))
   if n < 0:
     raise ValueError(f"tgat_pack: unsupported edge width {d_e}")
@@ -166,14 +167,23 @@ def tgat_pack(sd, d_e, device, blob=None):
   if k_w.shape != (2 * D, 2 * D + d_e):
     raise ValueError(f"tgat_pack: k_proj_weight has shape {tuple(k_w.shape)}, expected {(2 * D, 2 * D + d_e)}")
   check(_lib.load().orca_tgat_pack(int(d_e), *(ptr(t) for t in ts), ptr(blob), stream()), "orca_tgat_pack")
+  if time_b is not None:
+    tb = time_b.detach().to(device=device, dtype=torch.float32).contiguous()
+    if tb.numel() != D:
+      raise ValueError(f"tgat_pack: time_b has {tb.numel()} values, expected {D}")
+    check(_lib.load().orca_tgat_pack_gather(int(d_e), ptr(ts[0]), ptr(k_w), ptr(ts[3]), ptr(tb), ptr(blob), stream()),
+          "orca_tgat_pack_gather")
   return blob
 
 
 def tgat_forward(blob, d_e, Q, K, out=None, want_weights=False, **kw):
-  """orca_tgat_forward.  kw: the fields of orca_tgat_inputs (tensors or None)."""
+  """orca_tgat_forward.  kw: the fields of orca_tgat_inputs (tensors or None; q_folded: bool)."""
   inp = _lib.TgatInputs()
+  inp.q_folded = int(bool(kw.pop("q_folded", False)))
   keep = []
-  for name, _ in _lib.TgatInputs._fields_:
+  for name, ty in _lib.TgatInputs._fields_:
+    if ty is not _lib.vp:
+      continue
     t = kw.pop(name, None)
     if t is not None:
       if not t.is_cuda:

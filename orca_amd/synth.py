@@ -92,11 +92,12 @@ def tgat_flops_per_query(d_e, K):
 
 
 def tgat_flops_executed_per_query(d_e, K):
-  """Multiply-add flops the kernel executes since the linear tail (value map, out-proj, fc1) is multiplied out
-  into one [100 x (2*k_dim + 1 + 100)] map at pack time: fewer than the yardstick above, which stays the
-  figure roofline.achieved is priced with."""
+  """Multiply-add flops the kernel executes in gather mode since (a) the q projection is multiplied into the key
+  map ([2 x (k_dim+1) x 100] over the source row) and (b) the linear tail (value map, out-proj, fc1) into one
+  [100 x (2*k_dim + 1 + 100)] map, both at pack time: fewer than the yardstick above, which stays the figure
+  roofline.achieved is priced with."""
   kd = 2 * D + d_e
-  return 2 * (2 * D * 2 * D + 2 * D * kd + 2 * K * kd + 2 * K * kd + D * (2 * kd + 1 + D) + D * D)
+  return 2 * (2 * D * (kd + 1) + 2 * K * kd + 2 * K * kd + D * (2 * kd + 1 + D) + D * D)
 
 
 def tgat_bytes_per_query(d_e, K):

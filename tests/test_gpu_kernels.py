@@ -133,6 +133,18 @@ def test_time_encode(ops, golden):
   assert_close_fp32(out, g["out"], 1e-5, "time_encode")
 
 
+def test_time_encode_bias(ops):
+  """A trained time encoder has a non-zero bias; the reference's fixtures do not (parity unpinned by a reference
+  vector, and torch's CPU linear rounds t*w + b host-dependently): checked against the two-rounding definition of
+  oracle.time_encode."""
+  rs = np.random.RandomState(11)
+  t = torch.from_numpy(np.concatenate([rs.uniform(0, 2.6e6, 400), rs.uniform(0, 50, 100)]).astype(np.float32)).view(50, 10)
+  w = O.time_encode_weights(100)
+  b = torch.from_numpy(rs.uniform(-3, 3, 100).astype(np.float32))
+  out = ops.time_encode(t.to(DEV), w.to(DEV), b.to(DEV)).cpu().numpy()
+  assert_close_fp32(out, O.time_encode(t, w, b).numpy(), 1e-5, "time_encode with bias")
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["de172_K10_", "de1_K10_", "de4_K20_", "de172_K1_"])
 def test_attention_dense_boundary(ops, golden, tag):
@@ -153,9 +165,12 @@ def test_attention_dense_boundary(ops, golden, tag):
     assert_close_fp32(w.cpu().numpy(), g[tag + "weights"], 1e-5, tag + "weights")
 
 
+@pytest.mark.parametrize("folded", [False, True])
 @pytest.mark.parametrize("d_e,K,Q", [(172, 10, 1000), (1, 10, 333), (172, 20, 130), (64, 7, 17)])
-def test_attention_gather_mode_vs_oracle(ops, golden, d_e, K, Q):
-  """The fused path: rows gathered by index, time encodings computed in-kernel, overlay rows."""
+def test_attention_gather_mode_vs_oracle(ops, golden, d_e, K, Q, folded):
+  """The fused path: rows gathered by index, time encodings computed in-kernel, overlay rows.  folded: the blob
+  completed by orca_tgat_pack_gather (q projection multiplied into the key map), with a non-zero time bias so
+  that the constant part of the fold is exercised."""
   g = golden("attention.npz")
   tag = "de172_K10_"
   sd = {k[len(tag + "sd."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "sd.")}
@@ -180,9 +195,9 @@ def test_attention_gather_mode_vs_oracle(ops, golden, d_e, K, Q):
     eid[q, :npad[q]] = 0
   dt = rs.uniform(0, 2.6e6, (Q, K)).astype(np.float32)
   w_time = O.time_encode_weights(100)
-  b_time = torch.zeros(100)
-  blob = ops.tgat_pack(sd, d_e, DEV)
-  out, w = ops.tgat_forward(blob, d_e, Q, K, want_weights=True,
+  b_time = torch.from_numpy(rs.uniform(-3, 3, 100).astype(np.float32)) if folded else torch.zeros(100)
+  blob = ops.tgat_pack(sd, d_e, DEV, time_b=b_time if folded else None)
+  out, w = ops.tgat_forward(blob, d_e, Q, K, want_weights=True, q_folded=folded,
                             src_table=_t(table), src_idx=_t(nodes), src_overlay=_t(overlay), src_flags=_t(flags),
                             nbr_table=_t(table), nbr_idx=_t(nbr), nbr_overlay=_t(overlay), nbr_flags=_t(flags),
                             nbr_ids=_t(nbr), edge_table=_t(edge_feats), edge_idx=_t(eid), dt=_t(dt),
@@ -191,8 +206,9 @@ def test_attention_gather_mode_vs_oracle(ops, golden, d_e, K, Q):
   nbr_t = torch.from_numpy(nbr.astype(np.int64))
   mask = nbr_t == 0
   ref, ref_w = O.attention_forward(sd, eff[torch.from_numpy(nodes.astype(np.int64))],
-                                   O.time_encode(torch.zeros(Q, 1), w_time), eff[nbr_t.flatten()].view(Q, K, 100),
-                                   O.time_encode(torch.from_numpy(dt), w_time),
+                                   O.time_encode(torch.zeros(Q, 1), w_time, b_time),
+                                   eff[nbr_t.flatten()].view(Q, K, 100),
+                                   O.time_encode(torch.from_numpy(dt), w_time, b_time),
                                    torch.from_numpy(edge_feats)[torch.from_numpy(eid.astype(np.int64))], mask)
   assert_close_fp32(out.cpu().numpy(), ref.numpy(), 1e-5, "gather attention out")
   assert_close_fp32(w.cpu().numpy(), ref_w.numpy(), 1e-5, "gather attention weights")

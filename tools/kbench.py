@@ -38,12 +38,12 @@ def main():
   csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
   ef = synth.edge_features(E, d_e, dev)
   sd = synth.tgn_state_dict(d_e, 2)
+  tb = torch.zeros(100, device=dev)
   p = "embedding_module.attention_models.0."
-  blob = ops.tgat_pack({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, d_e, dev)
+  blob = ops.tgat_pack({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, d_e, dev, time_b=tb)
   g = "memory_updater.memory_updater."
   gblob = ops.gru_pack(sd[g + "weight_ih"], sd[g + "weight_hh"], sd[g + "bias_ih"], sd[g + "bias_hh"], dev)
   tw = sd["time_encoder.w.weight"].reshape(-1).to(dev).contiguous()
-  tb = torch.zeros(100, device=dev)
   s0 = int(0.7 * E)
   nodes = torch.cat([src[s0:s0 + Q // 3], dst[s0:s0 + Q // 3], torch.randint(1, N + 1, (Q - 2 * (Q // 3),), device=dev)])
   t3 = ts[s0:s0 + Q // 3].repeat(3)[:Q].contiguous()
@@ -62,11 +62,11 @@ def main():
   res["tgat_layer1_gather_overlay"] = timeit(lambda: ops.tgat_forward(
       blob, d_e, Q, K, out=out, src_table=memory, src_idx=n32, src_overlay=overlay, src_flags=pending, nbr_table=memory,
       nbr_idx=nbr, nbr_overlay=overlay, nbr_flags=pending, nbr_ids=nbr, edge_table=ef, edge_idx=eid, dt=dt, time_w=tw,
-      time_b=tb))
+      time_b=tb, q_folded=True))
   emb = torch.randn(Q, 100, device=dev)
   res["tgat_layer2_history"] = timeit(lambda: ops.tgat_forward(
       blob, d_e, Q, K, out=out, src_table=emb, nbr_table=memory, nbr_idx=nbr, nbr_ids=nbr, edge_table=ef, edge_idx=eid,
-      dt=dt, time_w=tw, time_b=tb))
+      dt=dt, time_w=tw, time_b=tb, q_folded=True))
   # phase breakdown of the attention kernel (100 MHz counter -> us), median over workgroups
   from orca_amd import _lib
   nwg = (Q + 15) // 16
@@ -74,7 +74,7 @@ def main():
   _lib.load().orca_debug_tgat_phase_clock(clk.data_ptr())
   ops.tgat_forward(blob, d_e, Q, K, out=out, src_table=memory, src_idx=n32, src_overlay=overlay, src_flags=pending,
                    nbr_table=memory, nbr_idx=nbr, nbr_overlay=overlay, nbr_flags=pending, nbr_ids=nbr, edge_table=ef,
-                   edge_idx=eid, dt=dt, time_w=tw, time_b=tb)
+                   edge_idx=eid, dt=dt, time_w=tw, time_b=tb, q_folded=True)
   torch.cuda.synchronize()
   _lib.load().orca_debug_tgat_phase_clock(None)
   c = clk.view(nwg, 16).cpu().double()
