@@ -136,16 +136,17 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
   }
 }
 
-// First kernel of a step.  Block b < nb, wave w: root query i = 16 b + w of [src;dst;neg] x [t;t;t]
+// First kernel of a step.  Query block b (block index ne + b), wave w: root query i = 16 b + w of [src;dst;neg] x [t;t;t]
 // (tgn_model.py:99-102) is written to nodes / qts / nodes32 and, when i lies in this rank's slice [lo, hi), its K
 // most recent neighbours are sampled into row i - lo of the sampler outputs (embedding_module.py:157), with the
 // claim pass of the overlay work-list in train order.
-// blocks nb .. nb+parts-1        (elect only): winners of the history push over all 3*bs roots (embedding_module.py:103-113, H7)
-// blocks nb+parts .. nb+2parts-1 (elect only): winners of the raw-message store over [src;dst]  (tgn_model.py:174-176)
+// blocks 0 .. parts-1        (elect only): winners of the raw-message store over [src;dst]  (tgn_model.py:174-176)
+// blocks parts .. 2*parts-1  (elect only): winners of the history push over all 3*bs roots (embedding_module.py:103-113, H7)
+// blocks ne .. ne+nb-1: the root queries (ne = 2*parts, or 0 when the caller elects elsewhere)
 __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
-    int32_t* __restrict__ nodes32, int nb, int parts, int64_t n_nodes, uint8_t* __restrict__ win_push,
+    int32_t* __restrict__ nodes32, int ne, int parts, int64_t n_nodes, uint8_t* __restrict__ win_push,
     uint8_t* __restrict__ win_msg, int32_t* __restrict__ msg_list, int32_t* __restrict__ msg_count,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ c_nbr, const int32_t* __restrict__ c_eid,
     const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int K, int32_t* __restrict__ o_nbr,
@@ -155,10 +156,15 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const int64_t* a = i < bs ? src : (i < 2 * bs ? dst - bs : neg - 2 * bs);
     return a[i];
   };
-  if ((int)blockIdx.x >= nb + parts) { elect_in_lds(keys, vals, 2 * bs, n_nodes, root, win_msg, (int)blockIdx.x - nb - parts, parts, msg_list, msg_count); return; }
-  if ((int)blockIdx.x >= nb) { elect_in_lds(keys, vals, 3 * bs, n_nodes, root, win_push, (int)blockIdx.x - nb, parts, nullptr, nullptr); return; }
+  // the election workgroups (the longest dependent chains of this launch) take the first block indices so that
+  // they are dispatched first; ne = 2*parts of them, or 0
+  if ((int)blockIdx.x < ne) {
+    if ((int)blockIdx.x < parts) elect_in_lds(keys, vals, 2 * bs, n_nodes, root, win_msg, (int)blockIdx.x, parts, msg_list, msg_count);
+    else elect_in_lds(keys, vals, 3 * bs, n_nodes, root, win_push, (int)blockIdx.x - parts, parts, nullptr, nullptr);
+    return;
+  }
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
+  const int64_t i = (int64_t)((int)blockIdx.x - ne) * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
   if (i >= 3 * bs) return;
   const int64_t e = i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs);
   const int64_t v = root(i);                                            // tgn_model.py:99
@@ -343,7 +349,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     const int nb = (int)ceil_div64(Q, ELECT_THREADS / 64);
     Timed t(e, ORCA_PROF_SAMPLE, stream);
     ORCA_LAUNCH_TIMED(k_begin_queries, (unsigned)(nb + (e->winners_valid ? 2 * parts : 0)), ELECT_THREADS, 0, stream, src, dst, neg, ts,
-                      bs, d.nodes, d.qts, d.nodes32, nb, parts, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr,
+                      bs, d.nodes, d.qts, d.nodes32, e->winners_valid ? 2 * parts : 0, parts, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr,
                       my_list, my_count,
                       indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, K, d.nbr, d.eid, d.et, d.dt, claim);
     ORCA_LAUNCH_CHECK();

@@ -576,7 +576,9 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       side.src_rows_out[q * D + lane] = sa;
       if (c1 < D) side.src_rows_out[q * D + c1] = sb;
     }
-    if (in.dt) {    // embedding_module.py:126: the source's own time encoding is cos(0*w + b)
+    if constexpr (qk) {
+      // the source's time encoding is a constant already inside the folded map: nothing to compute
+    } else if (in.dt) {    // embedding_module.py:126: the source's own time encoding is cos(0*w + b)
       sta = orca_cosf(orca_time_arg(0.0f, in.time_w[lane], in.time_b[lane]));
       stb = c1 < D ? orca_cosf(orca_time_arg(0.0f, in.time_w[c1], in.time_b[c1])) : 0.f;
     } else {
