@@ -149,6 +149,38 @@ typedef struct {
 int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
                       float* out, float* out_weights, void* stream);
 
+/* ---- backward of the attention layer: torch autograd of model/temporal_attention.py:24-56 as the training
+ * loop runs it (train.py:236-237 loss.backward()) -------------------------------------------------------- */
+/* The layer's raw row-major state_dict tensors, or gradient buffers of the same shapes. */
+typedef struct {
+  float* q_w;    /* multi_head_target.q_proj_weight [200,200] */
+  float* k_w;    /* multi_head_target.k_proj_weight [200,200+d_e] */
+  float* v_w;    /* multi_head_target.v_proj_weight [200,200+d_e] */
+  float* in_b;   /* multi_head_target.in_proj_bias [600] */
+  float* o_w;    /* multi_head_target.out_proj.weight [200,200] */
+  float* o_b;    /* multi_head_target.out_proj.bias [200] */
+  float* fc1_w;  /* merger.fc1.weight [100,300] */
+  float* fc1_b;  /* merger.fc1.bias [100] */
+  float* fc2_w;  /* merger.fc2.weight [100,100] */
+  float* fc2_b;  /* merger.fc2.bias [100] */
+  float* ln_w;   /* norm.weight [100] */
+  float* ln_b;   /* norm.bias [100] */
+} orca_tgat_params;
+/* Floats of scratch orca_tgat_backward needs for Q queries of K slots (-1: unsupported sizes). */
+int64_t orca_tgat_backward_workspace_floats(int d_e, int64_t Q, int K);
+/* Given grad_out = dL/d out [Q, ORCA_D] of orca_tgat_forward on the same `in` (dropout off), ADDS the parameter
+ * gradients into `grads` (caller zeroes them, as optimizer.zero_grad does) and writes the input gradients:
+ * d_src [Q,ORCA_D] (per query; may be NULL), d_nbr [Q*K,ORCA_D] (per slot, zero for padded slots; the caller
+ * scatter-adds rows that came from a table), and for the time features either d_src_time [Q,ORCA_D] /
+ * d_nbr_time [Q*K,ORCA_D] (dense mode, may be NULL) or, in gather mode, ADDS into d_time_w / d_time_b [ORCA_D]
+ * (time_encoding.py:14; both or neither).  Edge features are data upstream and get no gradient.  `in->mask`
+ * must be the mask as it was BEFORE the forward call (the forward un-masks slot 0 of all-padded queries in
+ * place, :46-47).  `params` are read, not modified.  workspace: orca_tgat_backward_workspace_floats floats. */
+int orca_tgat_backward(const orca_tgat_params* params, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
+                       const float* grad_out, const orca_tgat_params* grads, float* d_src, float* d_nbr,
+                       float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b, float* workspace,
+                       void* stream);
+
 /* Profiling aid (no counterpart in the reference): when buf != NULL (device int64 [ceil(Q/16) * 16]) later
  * orca_tgat_forward launches write the 100 MHz real-time counter at each internal phase boundary. */
 int orca_debug_tgat_phase_clock(void* buf);

@@ -26,6 +26,12 @@ class TgatInputs(ctypes.Structure):
       "dt", "time_w", "time_b", "src_time", "nbr_time")] + [("q_folded", ctypes.c_int32)]
 
 
+class TgatParams(ctypes.Structure):
+  """orca_tgat_params (include/orca_hip.h): raw state_dict tensors, in ops.TGAT_KEYS order."""
+  _fields_ = [(n, vp) for n in ("q_w", "k_w", "v_w", "in_b", "o_w", "o_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                                "ln_w", "ln_b")]
+
+
 ORCA_ENGINE_MAX_LAYERS = 4
 
 
@@ -59,6 +65,8 @@ SIGNATURES = {
     "orca_tgat_blob_floats": (i64, [i32]),
     "orca_tgat_pack": (i32, [i32] + [vp] * 14),
     "orca_tgat_pack_gather": (i32, [i32] + [vp] * 6),
+    "orca_tgat_backward_workspace_floats": (i64, [i32, i64, i32]),
+    "orca_tgat_backward": (i32, [vp, i32, vp, i64, i32] + [vp] * 10),
     "orca_tgat_forward": (i32, [vp, i32, ctypes.POINTER(TgatInputs), i64, i32, vp, vp, vp]),
     "orca_debug_tgat_phase_clock": (i32, [vp]),
     "orca_debug_gru_phase_clock": (i32, [vp]),

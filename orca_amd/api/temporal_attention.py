@@ -20,9 +20,34 @@ class MergeLayer(nn.Module):
     return self.fc2(self.act(self.fc1(torch.cat([x1, x2], dim=1))))
 
 
+class _AttentionFn(torch.autograd.Function):
+  """forward = the fused HIP kernel, backward = orca_tgat_backward (both through the C ABI)."""
+
+  @staticmethod
+  def forward(ctx, layer, B, K, src, st, nbr, nt, edge, mask, *params):
+    before = mask.clone()                       # the forward un-masks slot 0 of all-padded rows in place (:46-47)
+    out, wts = ops.tgat_forward(layer.packed(), layer.n_edge_features, B, K, want_weights=True, src_table=src,
+                                nbr_table=nbr, edge_table=edge, mask=mask.view(torch.uint8), src_time=st, nbr_time=nt)
+    ctx.layer, ctx.B, ctx.K = layer, B, K
+    ctx.save_for_backward(src, st, nbr, nt, edge, before, *params)
+    ctx.mark_non_differentiable(wts)
+    return out, wts
+
+  @staticmethod
+  def backward(ctx, g_out, _g_wts):
+    src, st, nbr, nt, edge, before, *params = ctx.saved_tensors
+    sd = dict(zip(ops.TGAT_KEYS, params))
+    grads, d_src, d_nbr, d_st, d_nt, _, _ = ops.tgat_backward(
+        sd, ctx.layer.n_edge_features, ctx.B, ctx.K, g_out, src_table=src, nbr_table=nbr, edge_table=edge,
+        mask=before.view(torch.uint8), src_time=st, nbr_time=nt)
+    return (None, None, None, d_src, d_st, d_nbr, d_nt, None, None) + tuple(grads[k] for k in ops.TGAT_KEYS)
+
+
 class TemporalAttentionLayer(nn.Module):
-  """Same constructor, parameters (state_dict keys) and forward contract as the reference; forward
-  runs the fused HIP kernel.  Dropout is not applied (inference / module.eval() semantics)."""
+  """Same constructor, parameters (state_dict keys) and forward contract as the reference; forward runs the
+  fused HIP kernel and, under autograd, backward runs orca_tgat_backward (gradients of all twelve parameters
+  and of the node / time feature inputs; edge features are data upstream and get none).  Dropout is not applied
+  (module.eval() semantics)."""
 
   def __init__(self, n_node_features, n_neighbors_features, n_edge_features, time_dim, output_dimension, n_head=2,
                dropout=0.1):
@@ -53,7 +78,6 @@ class TemporalAttentionLayer(nn.Module):
       self._blob_key = key
     return self._blob
 
-  @torch.no_grad()
   def forward(self, src_node_features, src_time_features, neighbors_features, neighbors_time_features, edge_features,
               neighbors_padding_mask):
     """[B,100], [B,1,100], [B,K,100], [B,K,100], [B,K,d_e], bool [B,K] (mutated in place as
@@ -63,10 +87,13 @@ class TemporalAttentionLayer(nn.Module):
     if mask.dtype != torch.bool or not mask.is_contiguous():
       raise TypeError("neighbors_padding_mask must be a contiguous torch.bool tensor")
     f = lambda x, w: x.float().contiguous().view(-1, w)
-    out, wts = ops.tgat_forward(self.packed(), self.n_edge_features, B, K, want_weights=True,
-                                src_table=f(src_node_features, self.feat_dim),
-                                nbr_table=f(neighbors_features, self.feat_dim),
-                                edge_table=f(edge_features, self.n_edge_features), mask=mask.view(torch.uint8),
-                                src_time=f(src_time_features, self.time_dim),
-                                nbr_time=f(neighbors_time_features, self.time_dim))
-    return out, wts
+    src, st = f(src_node_features, self.feat_dim), f(src_time_features, self.time_dim)
+    nbr, nt = f(neighbors_features, self.feat_dim), f(neighbors_time_features, self.time_dim)
+    edge = f(edge_features, self.n_edge_features)
+    named = dict(self.named_parameters())
+    params = [named[k] for k in ops.TGAT_KEYS]
+    if torch.is_grad_enabled() and any(t.requires_grad for t in params + [src, st, nbr, nt]):
+      return _AttentionFn.apply(self, B, K, src, st, nbr, nt, edge, mask, *params)
+    with torch.no_grad():
+      return ops.tgat_forward(self.packed(), self.n_edge_features, B, K, want_weights=True, src_table=src,
+                              nbr_table=nbr, edge_table=edge, mask=mask.view(torch.uint8), src_time=st, nbr_time=nt)

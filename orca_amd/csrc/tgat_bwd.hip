@@ -1,0 +1,536 @@
+// Backward pass of the TGAT attention layer (autograd of model/temporal_attention.py:24-56 as train.py:236-237
+// runs it): gradients of the raw state_dict tensors and of the layer's inputs.
+//
+// First cut, built for correctness before speed: the forward intermediates are recomputed from the raw
+// (unpacked, unfolded) parameters, every dense contraction -- recompute, data gradients and the weight
+// gradients, which reduce over the queries -- goes through ONE generic strided fp32 MFMA GEMM
+// (v_mfma_f32_16x16x4_f32, 64x64 tiles staged in LDS, deterministic split-K), and the per-query parts (key
+// gathers, scores, softmax and their derivatives, LayerNorm) are wave-per-query kernels.  The algebra of the
+// forward kernel is kept where it removes work: scores and the weighted key sum act on the raw key rows
+// (q~_h = Wk_h^T 0.1 q_h, x-bar_h = sum_j a_hj x_j), so the K x k_dim key matrix is never projected.
+// Intermediates live in a caller-provided workspace (orca_tgat_backward_workspace_floats).
+#include "common.h"
+
+namespace {
+
+constexpr int D = ORCA_D;
+constexpr int QD = 2 * D;
+constexpr int MAXC = (QD + ORCA_MAX_DE + 63) / 64;   // key columns per lane
+
+// ---- generic strided GEMM ---------------------------------------------------------------------------------
+// C(m,n) = alpha * (sum_k A(m,k) B(k,n) + bias[n]) [+ C(m,n)] [relu];  X(i,j) = X[i*s0 + j*s1].
+// With part != NULL block z writes its raw partial sums of k in [z*kchunk, (z+1)*kchunk) to part[z][m][n].
+struct GemmArgs {
+  int M, N, K;
+  const float* A; int64_t sam, sak;
+  const float* B; int64_t sbk, sbn;
+  float* C; int64_t scm, scn;
+  const float* bias;
+  float alpha;
+  int accumulate, relu, kchunk;
+  float* part;
+};
+
+__global__ __launch_bounds__(256) void k_sgemm(GemmArgs g) {
+  __shared__ float As[16][68], Bs[16][68];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kbeg = blockIdx.z * g.kchunk;
+  const int kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = t + 256 * e;
+      int m, k;
+      if (a_kfast) { m = idx >> 4; k = idx & 15; } else { m = idx & 63; k = idx >> 6; }
+      As[k][m] = (m0 + m < g.M && k0 + k < kend) ? g.A[(int64_t)(m0 + m) * g.sam + (int64_t)(k0 + k) * g.sak] : 0.f;
+      int n, kk;
+      if (b_nfast) { n = idx & 63; kk = idx >> 6; } else { kk = idx & 15; n = idx >> 4; }
+      Bs[kk][n] = (n0 + n < g.N && k0 + kk < kend) ? g.B[(int64_t)(k0 + kk) * g.sbk + (int64_t)(n0 + n) * g.sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int kr = kk * 4 + (lane >> 4);
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[kr][wm + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wn + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + 4 * (lane >> 4) + r, n = n0 + wn + j * 16 + (lane & 15);
+        if (m >= g.M || n >= g.N) continue;
+        if (g.part) {
+          g.part[((int64_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+        } else {
+          float v = g.alpha * (acc[i][j][r] + (g.bias ? g.bias[n] : 0.f));
+          float* c = g.C + (int64_t)m * g.scm + (int64_t)n * g.scn;
+          if (g.accumulate) v += *c;
+          *c = g.relu ? fmaxf(v, 0.f) : v;
+        }
+      }
+}
+
+__global__ void k_splitk_reduce(const float* __restrict__ part, int S, int M, int N, float* C, int64_t scm, int64_t scn,
+                                float alpha, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * N) return;
+  float v = 0.f;
+  for (int z = 0; z < S; ++z) v += part[(int64_t)z * M * N + i];   // fixed order: deterministic
+  float* c = C + (i / N) * scm + (i % N) * scn;
+  v *= alpha;
+  *c = accumulate ? *c + v : v;
+}
+
+// out[n] (+)= alpha * sum_q X[q*ld + n], n < ncols: one 256-thread block per 64 columns, fixed summation order
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t Q, int64_t ld, int ncols,
+                                                float* out, float alpha, int accumulate) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  float v = 0.f;
+  if (c < ncols)
+    for (int64_t q = r; q < Q; q += 4) v += X[q * ld + c];
+  red[r][threadIdx.x & 63] = v;
+  __syncthreads();
+  if (r == 0 && c < ncols) {
+    v = alpha * (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    out[c] = accumulate ? out[c] + v : v;
+  }
+}
+
+int sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
+          int64_t sbn, float* C, int64_t scm, int64_t scn, const float* bias, float alpha, bool accumulate, bool relu,
+          float* part = nullptr, int splits = 1) {
+  if (M <= 0 || N <= 0) return ORCA_OK;
+  GemmArgs g{M, N, K, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, alpha, accumulate ? 1 : 0, relu ? 1 : 0, K, nullptr};
+  unsigned gz = 1;
+  if (part && splits > 1 && K > 64) {
+    int kc = (K + splits - 1) / splits;
+    kc = (kc + 15) / 16 * 16;
+    g.kchunk = kc;
+    gz = (unsigned)((K + kc - 1) / kc);
+    g.part = part;
+  }
+  if (g.kchunk < 16) g.kchunk = 16;
+  k_sgemm<<<dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), gz), 256, 0, s>>>(g);
+  if (g.part)
+    k_splitk_reduce<<<(unsigned)ceil_div64((int64_t)M * N, 256), 256, 0, s>>>(part, (int)gz, M, N, C, scm, scn, alpha,
+                                                                            accumulate ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
+}
+
+int colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate) {
+  k_colsum<<<(unsigned)((ncols + 63) / 64), 256, 0, s>>>(X, Q, ld, ncols, out, alpha, accumulate ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
+}
+
+// ---- per-query pieces -------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// the slots of one query as the forward kernel reads them (lane j = slot j)
+struct Slots {
+  int nrow, erow, ovl;
+  float dt;
+  bool masked;
+};
+__device__ __forceinline__ Slots load_slots(const orca_tgat_inputs& in, int64_t q, int K, int lane) {
+  Slots S{0, 0, 0, 0.f, true};
+  if (lane < K) {
+    const int64_t p = q * K + lane;
+    S.nrow = in.nbr_idx ? in.nbr_idx[p] : (int)p;
+    S.erow = in.edge_idx ? in.edge_idx[p] : (int)p;
+    S.masked = in.nbr_ids ? (in.nbr_ids[p] == 0) : (in.mask[p] != 0);
+    if (in.dt) S.dt = in.dt[p];
+    if (in.nbr_flags) S.ovl = in.nbr_flags[S.nrow] ? 1 : 0;
+  }
+  return S;
+}
+// this lane's columns c = lane + 64 i of key row j: [nbr (100) | edge (d_e) | time (100)]
+__device__ __forceinline__ void key_row(float (&x)[MAXC], const orca_tgat_inputs& in, const Slots& S, int64_t q, int j,
+                                        int K, int d_e, int lane) {
+  const int nr = __shfl(S.nrow, j, 64), er = __shfl(S.erow, j, 64), ov = __shfl(S.ovl, j, 64);
+  const float dt = __shfl(S.dt, j, 64);
+  const float* np = (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D;
+  const float* ep = in.edge_table + (int64_t)er * d_e;
+  const int kdim = QD + d_e;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    float v = 0.f;
+    if (c < D) v = np[c];
+    else if (c < D + d_e) v = ep[c - D];
+    else if (c < kdim) {
+      const int ct = c - D - d_e;
+      v = in.dt ? orca_cosf(orca_time_arg(dt, in.time_w[ct], in.time_b[ct])) : in.nbr_time[(q * K + j) * D + ct];
+    }
+    x[i] = v;
+  }
+}
+
+// xq[q] = [src | src_time] (the q projection's input), x1[q][200:300] = src (the merger's second input)
+__global__ __launch_bounds__(256) void k_bwd_prep(orca_tgat_inputs in, int64_t Q, float* __restrict__ xq,
+                                                  float* __restrict__ x1) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  const int64_t row = in.src_idx ? (int64_t)in.src_idx[q] : q;
+  const float* tab = (in.src_flags && in.src_flags[row]) ? in.src_overlay : in.src_table;
+  for (int c = lane; c < D; c += 64) {
+    const float s = tab[row * D + c];
+    xq[q * QD + c] = s;
+    x1[q * 3 * D + QD + c] = s;
+    xq[q * QD + D + c] = in.dt ? orca_cosf(orca_time_arg(0.0f, in.time_w[c], in.time_b[c])) : in.src_time[q * D + c];
+  }
+}
+
+// recompute of the attention core: a[q][h][j] = softmax_j(q~_h . x_j) over the unmasked slots,
+// xbar[q][h] = sum_j a_hj x_j;  invalid[q] = 1 for an all-padded query (temporal_attention.py:46-47,52)
+__global__ __launch_bounds__(256) void k_bwd_attn_fwd(orca_tgat_inputs in, int64_t Q, int K, int d_e,
+                                                      const float* __restrict__ qt, float* __restrict__ a_out,
+                                                      float* __restrict__ xbar, float* __restrict__ invalid) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  const int kdim = QD + d_e;
+  const Slots S = load_slots(in, q, K, lane);
+  unsigned long long live = __ballot(lane < K && !S.masked);
+  const bool inv = live == 0ull;
+  if (inv) live = 1ull;
+  float q0[MAXC], q1[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    q0[i] = c < kdim ? qt[q * 2 * kdim + c] : 0.f;
+    q1[i] = c < kdim ? qt[q * 2 * kdim + kdim + c] : 0.f;
+  }
+  float s0 = -INFINITY, s1 = -INFINITY;
+  for (int j = 0; j < K; ++j) {
+    float x[MAXC];
+    key_row(x, in, S, q, j, K, d_e, lane);
+    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) { p0 += x[i] * q0[i]; p1 += x[i] * q1[i]; }
+    p0 = wave_sum(p0);
+    p1 = wave_sum(p1);
+    if (lane == j && ((live >> j) & 1ull)) { s0 = p0; s1 = p1; }
+  }
+  const float m0 = wave_max_f(s0), m1 = wave_max_f(s1);
+  float e0 = (lane < K && ((live >> lane) & 1ull)) ? expf(s0 - m0) : 0.f;
+  float e1 = (lane < K && ((live >> lane) & 1ull)) ? expf(s1 - m1) : 0.f;
+  const float a0 = e0 / wave_sum(e0), a1 = e1 / wave_sum(e1);
+  if (lane < K) {
+    a_out[(q * 2 + 0) * K + lane] = a0;
+    a_out[(q * 2 + 1) * K + lane] = a1;
+  }
+  float b0[MAXC], b1[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) b0[i] = b1[i] = 0.f;
+  for (int j = 0; j < K; ++j) {
+    if (!((live >> j) & 1ull)) continue;   // wave-uniform
+    float x[MAXC];
+    key_row(x, in, S, q, j, K, d_e, lane);
+    const float w0 = __shfl(a0, j, 64), w1 = __shfl(a1, j, 64);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) { b0[i] += w0 * x[i]; b1[i] += w1 * x[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < kdim) {
+      xbar[q * 2 * kdim + c] = b0[i];
+      xbar[q * 2 * kdim + kdim + c] = b1[i];
+    }
+  }
+  if (lane == 0) invalid[q] = inv ? 1.f : 0.f;
+}
+
+// rows of an invalid query are zeroed in X[q*ld .. +n)
+__global__ void k_zero_invalid(float* __restrict__ X, int64_t Q, int64_t ld, int n, const float* __restrict__ invalid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q * n) return;
+  const int64_t q = i / n;
+  if (invalid[q] != 0.f) X[q * ld + i % n] = 0.f;
+}
+// d[i] = h[i] > 0 ? d[i] : 0   (ReLU backward through the kept activation)
+__global__ void k_relu_bwd(float* __restrict__ d, const float* __restrict__ h, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !(h[i] > 0.f)) d[i] = 0.f;
+}
+
+// LayerNorm backward (eps 1e-5, biased variance): dy from g = dL/dout, gx = g * xhat for the affine gradients
+__global__ __launch_bounds__(256) void k_bwd_ln(const float* __restrict__ y, const float* __restrict__ g,
+                                                const float* __restrict__ gamma, int64_t Q, float* __restrict__ dy,
+                                                float* __restrict__ gx) {
+  const int lane = threadIdx.x & 63, c1 = lane + 64;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  const float ya = y[q * D + lane], yb = c1 < D ? y[q * D + c1] : 0.f;
+  const float mean = wave_sum(ya + yb) * (1.0f / D);
+  const float da = ya - mean, db = c1 < D ? yb - mean : 0.f;
+  const float var = wave_sum(da * da + db * db) * (1.0f / D);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  const float xa = da * rstd, xb = db * rstd;
+  const float ga = g[q * D + lane], gb = c1 < D ? g[q * D + c1] : 0.f;
+  const float ha = ga * gamma[lane], hb = c1 < D ? gb * gamma[c1] : 0.f;
+  const float m1 = wave_sum(ha + hb) * (1.0f / D);
+  const float m2 = wave_sum(ha * xa + hb * xb) * (1.0f / D);
+  dy[q * D + lane] = (ha - m1 - xa * m2) * rstd;
+  gx[q * D + lane] = ga * xa;
+  if (c1 < D) {
+    dy[q * D + c1] = (hb - m1 - xb * m2) * rstd;
+    gx[q * D + c1] = gb * xb;
+  }
+}
+
+// backward of the attention core.  In: dxbar[q][h] (gradient of the weighted key sums), a, q~.  Out:
+// dqt[q][h] = sum_j ds_hj x_j with ds = softmax backward of da_hj = dxbar_h . x_j;  the key-row gradient
+// dx_j = sum_h (a_hj dxbar_h + ds_hj q~_h) goes to d_nbr (columns 0..99), is dropped for the edge columns (the edge
+// features are data, not parameters) and for the time columns goes to d_nbr_time (dense mode) or, through
+// d cos(dt w + b), into this query's row of tgrad = [d time_w | d time_b] (gather mode).
+__global__ __launch_bounds__(256) void k_bwd_attn_bwd(orca_tgat_inputs in, int64_t Q, int K, int d_e,
+                                                      const float* __restrict__ qt, const float* __restrict__ a_in,
+                                                      const float* __restrict__ dxbar, float* __restrict__ dqt,
+                                                      float* __restrict__ d_nbr, float* __restrict__ d_nbr_time,
+                                                      float* __restrict__ tgrad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  const int kdim = QD + d_e, t0 = D + d_e;
+  const Slots S = load_slots(in, q, K, lane);
+  float q0[MAXC], q1[MAXC], g0[MAXC], g1[MAXC], r0[MAXC], r1[MAXC], tw[MAXC], tb[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    const bool ok = c < kdim;
+    q0[i] = ok ? qt[q * 2 * kdim + c] : 0.f;
+    q1[i] = ok ? qt[q * 2 * kdim + kdim + c] : 0.f;
+    g0[i] = ok ? dxbar[q * 2 * kdim + c] : 0.f;
+    g1[i] = ok ? dxbar[q * 2 * kdim + kdim + c] : 0.f;
+    r0[i] = r1[i] = tw[i] = tb[i] = 0.f;
+  }
+  const float a0 = lane < K ? a_in[(q * 2 + 0) * K + lane] : 0.f;
+  const float a1 = lane < K ? a_in[(q * 2 + 1) * K + lane] : 0.f;
+  float da0 = 0.f, da1 = 0.f;
+  for (int j = 0; j < K; ++j) {
+    float x[MAXC];
+    key_row(x, in, S, q, j, K, d_e, lane);
+    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) { p0 += x[i] * g0[i]; p1 += x[i] * g1[i]; }
+    p0 = wave_sum(p0);
+    p1 = wave_sum(p1);
+    if (lane == j) { da0 = p0; da1 = p1; }
+  }
+  const float ds0 = a0 * (da0 - wave_sum(a0 * da0)), ds1 = a1 * (da1 - wave_sum(a1 * da1));
+  for (int j = 0; j < K; ++j) {
+    float x[MAXC];
+    key_row(x, in, S, q, j, K, d_e, lane);
+    const float w0 = __shfl(a0, j, 64), w1 = __shfl(a1, j, 64), e0 = __shfl(ds0, j, 64), e1 = __shfl(ds1, j, 64);
+    const float dt = __shfl(S.dt, j, 64);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      r0[i] += e0 * x[i];
+      r1[i] += e1 * x[i];
+      const float dx = w0 * g0[i] + w1 * g1[i] + e0 * q0[i] + e1 * q1[i];
+      if (c < D) {
+        d_nbr[(q * K + j) * D + c] = dx;
+      } else if (c >= t0 && c < kdim) {
+        const int ct = c - t0;
+        if (in.dt) {
+          if (tgrad) {
+            const float arg = orca_time_arg(dt, in.time_w[ct], in.time_b[ct]);
+            const float dth = -(float)sin((double)arg) * dx;
+            tw[i] += dt * dth;
+            tb[i] += dth;
+          }
+        } else if (d_nbr_time) {
+          d_nbr_time[(q * K + j) * D + ct] = dx;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < kdim) {
+      dqt[q * 2 * kdim + c] = r0[i];
+      dqt[q * 2 * kdim + kdim + c] = r1[i];
+    }
+    if (tgrad && c >= t0 && c < kdim) {
+      tgrad[q * QD + (c - t0)] = tw[i];
+      tgrad[q * QD + D + (c - t0)] = tb[i];
+    }
+  }
+}
+
+// d_src[q] = dx1[q][200:300] + dxq[q][0:100];  the source's time columns dxq[q][100:200] go to d_src_time (dense
+// mode) or, through d cos(0*w + b) = -sin(b), are added to the time_b half of tgrad (gather mode)
+__global__ void k_bwd_finish(orca_tgat_inputs in, int64_t Q, const float* __restrict__ dx1,
+                             const float* __restrict__ dxq, float* __restrict__ d_src, float* __restrict__ d_src_time,
+                             float* __restrict__ tgrad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q * D) return;
+  const int64_t q = i / D;
+  const int c = (int)(i % D);
+  if (d_src) d_src[i] = dx1[q * 3 * D + QD + c] + dxq[q * QD + c];
+  const float dst = dxq[q * QD + D + c];
+  if (in.dt) {
+    if (tgrad) tgrad[q * QD + D + c] += -(float)sin((double)orca_time_arg(0.0f, in.time_w[c], in.time_b[c])) * dst;
+  } else if (d_src_time) {
+    d_src_time[i] = dst;
+  }
+}
+
+struct Ws {   // float offsets of the per-query rows inside the workspace
+  int64_t xq, qs, qt, a, xbar, ocat, x1, h1, y, dy, gx, dh1, dx1, docat, dxbar, dqt, dq, dxq, tgrad, invalid, part, total;
+};
+constexpr int SPLITS = 32;
+Ws ws_layout(int d_e, int64_t Q, int K) {
+  const int64_t kdim = QD + d_e;
+  Ws w{};
+  int64_t o = 0;
+  auto take = [&](int64_t per) { int64_t r = o; o += (Q * per + 63) / 64 * 64; return r; };
+  w.xq = take(QD); w.qs = take(QD); w.qt = take(2 * kdim); w.a = take(2 * K); w.xbar = take(2 * kdim);
+  w.ocat = take(QD); w.x1 = take(3 * D); w.h1 = take(D); w.y = take(D); w.dy = take(D); w.gx = take(D);
+  w.dh1 = take(D); w.dx1 = take(3 * D); w.docat = take(QD); w.dxbar = take(2 * kdim); w.dqt = take(2 * kdim);
+  w.dq = take(QD); w.dxq = take(QD); w.tgrad = take(QD); w.invalid = take(1);
+  w.part = o;
+  o += (int64_t)SPLITS * QD * (kdim > 3 * D ? kdim : 3 * D);
+  w.total = o;
+  return w;
+}
+
+}  // namespace
+
+ORCA_API int64_t orca_tgat_backward_workspace_floats(int d_e, int64_t Q, int K) {
+  if (d_e < 1 || d_e > ORCA_MAX_DE || Q < 0 || K < 1 || K > ORCA_MAX_K) return -1;
+  return ws_layout(d_e, Q, K).total;
+}
+
+ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
+                                const float* grad_out, const orca_tgat_params* G, float* d_src, float* d_nbr,
+                                float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b,
+                                float* workspace, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  ORCA_REQUIRE(Q >= 0, "orca_tgat_backward: negative Q");
+  if (Q == 0) return ORCA_OK;
+  ORCA_REQUIRE(P && G && in && grad_out && workspace && d_nbr, "orca_tgat_backward: null pointer");
+  ORCA_REQUIRE(d_e >= 1 && d_e <= ORCA_MAX_DE, "orca_tgat_backward: d_e=%d outside [1,%d]", d_e, ORCA_MAX_DE);
+  ORCA_REQUIRE(K >= 1 && K <= ORCA_MAX_K, "orca_tgat_backward: K=%d outside [1,%d]", K, ORCA_MAX_K);
+  ORCA_REQUIRE(Q < (1LL << 31) / 1024, "orca_tgat_backward: Q too large for one call");
+  ORCA_REQUIRE(P->q_w && P->k_w && P->v_w && P->in_b && P->o_w && P->o_b && P->fc1_w && P->fc1_b && P->fc2_w &&
+               P->fc2_b && P->ln_w && P->ln_b, "orca_tgat_backward: null parameter");
+  ORCA_REQUIRE(G->q_w && G->k_w && G->v_w && G->in_b && G->o_w && G->o_b && G->fc1_w && G->fc1_b && G->fc2_w &&
+               G->fc2_b && G->ln_w && G->ln_b, "orca_tgat_backward: null gradient buffer");
+  ORCA_REQUIRE(in->src_table && in->nbr_table && in->edge_table, "orca_tgat_backward: null feature table");
+  ORCA_REQUIRE(in->nbr_ids || in->mask, "orca_tgat_backward: need nbr_ids or mask");
+  ORCA_REQUIRE(in->dt ? (in->time_w && in->time_b) : (in->src_time && in->nbr_time),
+               "orca_tgat_backward: need (dt, time_w, time_b) or (src_time, nbr_time)");
+  ORCA_REQUIRE(!in->src_flags || in->src_overlay, "orca_tgat_backward: src_flags without src_overlay");
+  ORCA_REQUIRE(!in->nbr_flags || in->nbr_overlay, "orca_tgat_backward: nbr_flags without nbr_overlay");
+  ORCA_REQUIRE(!in->dt || ((d_time_w != nullptr) == (d_time_b != nullptr)),
+               "orca_tgat_backward: d_time_w and d_time_b go together");
+  const int kdim = QD + d_e;
+  const int M = (int)Q;
+  const Ws w = ws_layout(d_e, Q, K);
+  float* W = workspace;
+  float *xq = W + w.xq, *qs = W + w.qs, *qt = W + w.qt, *a = W + w.a, *xbar = W + w.xbar, *ocat = W + w.ocat,
+        *x1 = W + w.x1, *h1 = W + w.h1, *y = W + w.y, *dy = W + w.dy, *gx = W + w.gx, *dh1 = W + w.dh1,
+        *dx1 = W + w.dx1, *docat = W + w.docat, *dxbar = W + w.dxbar, *dqt = W + w.dqt, *dq = W + w.dq,
+        *dxq = W + w.dxq, *tgrad = W + w.tgrad, *invalid = W + w.invalid, *part = W + w.part;
+  const unsigned qb = (unsigned)ceil_div64(Q, 4);
+  int rc = ORCA_OK;
+  auto ew = [&](int64_t n) { return (unsigned)ceil_div64(n, 256); };
+
+  // ---- forward recompute -------------------------------------------------------------------------------
+  k_bwd_prep<<<qb, 256, 0, s>>>(*in, Q, xq, x1);
+  // qs = 0.1 (xq Wq^T + bq)                                                    (scaling: head_dim^-0.5)
+  rc |= sgemm(s, M, QD, QD, xq, QD, 1, P->q_w, 1, QD, qs, QD, 1, P->in_b, 0.1f, false, false);
+  for (int h = 0; h < 2; ++h)   // q~_h = qs_h Wk_h   [Q,100] x [100,kdim]
+    rc |= sgemm(s, M, kdim, D, qs + h * D, QD, 1, P->k_w + (int64_t)h * D * kdim, kdim, 1, qt + h * kdim, 2 * kdim, 1,
+                nullptr, 1.f, false, false);
+  k_bwd_attn_fwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid);
+  for (int h = 0; h < 2; ++h)   // ocat_h = xbar_h Wv_h^T + bv_h
+    rc |= sgemm(s, M, D, kdim, xbar + h * kdim, 2 * kdim, 1, P->v_w + (int64_t)h * D * kdim, 1, kdim, ocat + h * D, QD, 1,
+                P->in_b + 2 * QD + h * D, 1.f, false, false);
+  // o = ocat Wo^T + bo -> x1[:, 0:200], zero for invalid queries                 (temporal_attention.py:52)
+  rc |= sgemm(s, M, QD, QD, ocat, QD, 1, P->o_w, 1, QD, x1, 3 * D, 1, P->o_b, 1.f, false, false);
+  k_zero_invalid<<<ew(Q * QD), 256, 0, s>>>(x1, Q, 3 * D, QD, invalid);
+  // h1 = relu(x1 W1^T + b1), y = h1 W2^T + b2                                     (utils/util.py:22-24)
+  rc |= sgemm(s, M, D, 3 * D, x1, 3 * D, 1, P->fc1_w, 1, 3 * D, h1, D, 1, P->fc1_b, 1.f, false, true);
+  rc |= sgemm(s, M, D, D, h1, D, 1, P->fc2_w, 1, D, y, D, 1, P->fc2_b, 1.f, false, false);
+
+  // ---- backward ----------------------------------------------------------------------------------------
+  k_bwd_ln<<<qb, 256, 0, s>>>(y, grad_out, P->ln_w, Q, dy, gx);
+  rc |= colsum(s, gx, Q, D, D, G->ln_w, 1.f, true);
+  rc |= colsum(s, grad_out, Q, D, D, G->ln_b, 1.f, true);
+  // fc2: dW2 += dy^T h1, db2 += sum dy, dh1 = dy W2
+  rc |= sgemm(s, D, D, M, dy, 1, D, h1, D, 1, G->fc2_w, D, 1, nullptr, 1.f, true, false, part, SPLITS);
+  rc |= colsum(s, dy, Q, D, D, G->fc2_b, 1.f, true);
+  rc |= sgemm(s, M, D, D, dy, D, 1, P->fc2_w, D, 1, dh1, D, 1, nullptr, 1.f, false, false);
+  k_relu_bwd<<<ew(Q * D), 256, 0, s>>>(dh1, h1, Q * D);
+  // fc1: dW1 += dz1^T x1, db1 += sum dz1, dx1 = dz1 W1
+  rc |= sgemm(s, D, 3 * D, M, dh1, 1, D, x1, 3 * D, 1, G->fc1_w, 3 * D, 1, nullptr, 1.f, true, false, part, SPLITS);
+  rc |= colsum(s, dh1, Q, D, D, G->fc1_b, 1.f, true);
+  rc |= sgemm(s, M, 3 * D, D, dh1, D, 1, P->fc1_w, 3 * D, 1, dx1, 3 * D, 1, nullptr, 1.f, false, false);
+  k_zero_invalid<<<ew(Q * QD), 256, 0, s>>>(dx1, Q, 3 * D, QD, invalid);     // do = 0 where the output was zeroed
+  // out-proj: dWo += do^T ocat, dbo += sum do, docat = do Wo
+  rc |= sgemm(s, QD, QD, M, dx1, 1, 3 * D, ocat, QD, 1, G->o_w, QD, 1, nullptr, 1.f, true, false, part, SPLITS);
+  rc |= colsum(s, dx1, Q, 3 * D, QD, G->o_b, 1.f, true);
+  rc |= sgemm(s, M, QD, QD, dx1, 3 * D, 1, P->o_w, QD, 1, docat, QD, 1, nullptr, 1.f, false, false);
+  // value map: dWv_h += docat_h^T xbar_h, dbv += sum docat, dxbar_h = docat_h Wv_h
+  rc |= colsum(s, docat, Q, QD, QD, G->in_b + 2 * QD, 1.f, true);
+  for (int h = 0; h < 2; ++h) {
+    rc |= sgemm(s, D, kdim, M, docat + h * D, 1, QD, xbar + h * kdim, 2 * kdim, 1, G->v_w + (int64_t)h * D * kdim, kdim, 1,
+                nullptr, 1.f, true, false, part, SPLITS);
+    rc |= sgemm(s, M, kdim, D, docat + h * D, QD, 1, P->v_w + (int64_t)h * D * kdim, kdim, 1, dxbar + h * kdim, 2 * kdim, 1,
+                nullptr, 1.f, false, false);
+  }
+  const bool want_t = in->dt && d_time_w;
+  k_bwd_attn_bwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr);
+  // key fold: dWk_h += qs_h^T dq~_h, dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs   (the bk gradient is zero: softmax is shift-invariant)
+  for (int h = 0; h < 2; ++h) {
+    rc |= sgemm(s, D, kdim, M, qs + h * D, 1, QD, dqt + h * kdim, 2 * kdim, 1, G->k_w + (int64_t)h * D * kdim, kdim, 1,
+                nullptr, 1.f, true, false, part, SPLITS);
+    rc |= sgemm(s, M, D, kdim, dqt + h * kdim, 2 * kdim, 1, P->k_w + (int64_t)h * D * kdim, 1, kdim, dq + h * D, QD, 1,
+                nullptr, 0.1f, false, false);
+  }
+  // q projection: dWq += dq^T xq, dbq += sum dq, dxq = dq Wq
+  rc |= sgemm(s, QD, QD, M, dq, 1, QD, xq, QD, 1, G->q_w, QD, 1, nullptr, 1.f, true, false, part, SPLITS);
+  rc |= colsum(s, dq, Q, QD, QD, G->in_b, 1.f, true);
+  rc |= sgemm(s, M, QD, QD, dq, QD, 1, P->q_w, QD, 1, dxq, QD, 1, nullptr, 1.f, false, false);
+  k_bwd_finish<<<ew(Q * D), 256, 0, s>>>(*in, Q, dx1, dxq, d_src, d_src_time, want_t ? tgrad : nullptr);
+  if (want_t) {
+    rc |= colsum(s, tgrad, Q, QD, D, d_time_w, 1.f, true);
+    rc |= colsum(s, tgrad + D, Q, QD, D, d_time_b, 1.f, true);
+  }
+  if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
+    orca_set_error("orca_tgat_backward: kernel launch failed");
+    return ORCA_EHIP;
+  }
+  return ORCA_OK;
+}

@@ -202,6 +202,60 @@ def tgat_forward(blob, d_e, Q, K, out=None, want_weights=False, **kw):
   return out, w
 
 
+def _tgat_inputs(kw, who):
+  inp = _lib.TgatInputs()
+  inp.q_folded = int(bool(kw.pop("q_folded", False)))
+  keep = []
+  for name, ty in _lib.TgatInputs._fields_:
+    if ty is not _lib.vp:
+      continue
+    t = kw.pop(name, None)
+    if t is not None:
+      if not t.is_cuda:
+        raise _lib.OrcaError(f"{who}: {name} is not on the HIP device")
+      t = t.contiguous()
+      keep.append(t)
+    setattr(inp, name, ptr(t))
+  if kw:
+    raise TypeError(f"{who}: unknown inputs {sorted(kw)}")
+  return inp, keep
+
+
+def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, **kw):
+  """orca_tgat_backward.  sd: the layer's raw parameters (keys TGAT_KEYS, fp32 on the device); kw: the fields of
+  orca_tgat_inputs of the forward call (mask = the mask BEFORE the forward).  Returns (grads: dict like sd,
+  d_src [Q,D], d_nbr [Q*K,D], d_src_time, d_nbr_time, d_time_w, d_time_b) -- the time entries that do not apply
+  to the mode are None."""
+  dev = grad_out.device
+  ps = [sd[k].detach().to(device=dev, dtype=torch.float32).contiguous() for k in TGAT_KEYS]
+  gs = [torch.zeros_like(p) for p in ps]
+  P, G = _lib.TgatParams(), _lib.TgatParams()
+  for (name, _), p, g in zip(_lib.TgatParams._fields_, ps, gs):
+    setattr(P, name, ptr(p))
+    setattr(G, name, ptr(g))
+  gather = kw.get("dt") is not None
+  inp, keep = _tgat_inputs(kw, "tgat_backward")
+  n = _lib.load().orca_tgat_backward_workspace_floats(int(d_e), int(Q), int(K))
+  if n < 0:
+    raise ValueError(f"tgat_backward: unsupported sizes d_e={d_e} K={K}")
+  wsp = torch.empty(n, dtype=torch.float32, device=dev)
+  go = grad_out.detach().to(torch.float32).contiguous()
+  d_src = torch.empty((Q, D), dtype=torch.float32, device=dev)
+  d_nbr = torch.empty((Q * K, D), dtype=torch.float32, device=dev)
+  d_st = d_nt = d_tw = d_tb = None
+  if gather:
+    if want_time_param_grads:
+      d_tw = torch.zeros(D, dtype=torch.float32, device=dev)
+      d_tb = torch.zeros(D, dtype=torch.float32, device=dev)
+  else:
+    d_st = torch.empty((Q, D), dtype=torch.float32, device=dev)
+    d_nt = torch.empty((Q * K, D), dtype=torch.float32, device=dev)
+  check(_lib.load().orca_tgat_backward(ctypes.byref(P), int(d_e), ctypes.byref(inp), int(Q), int(K), ptr(go),
+                                       ctypes.byref(G), ptr(d_src), ptr(d_nbr), ptr(d_st), ptr(d_nt), ptr(d_tw),
+                                       ptr(d_tb), ptr(wsp), stream()), "orca_tgat_backward")
+  return dict(zip(TGAT_KEYS, gs)), d_src, d_nbr, d_st, d_nt, d_tw, d_tb
+
+
 # ---------------------------------------------------------------------------------------------
 # GRU memory updater (modules/memory_updater.py)
 # ---------------------------------------------------------------------------------------------

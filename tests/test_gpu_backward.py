@@ -1,0 +1,138 @@
+"""Backward of the attention layer (orca_tgat_backward through the C ABI) against torch autograd of the oracle's
+forward.  The reference holds no gradient fixtures and can no longer be run:
+the oracle's forward is pinned to the reference's outputs, its autograd is the checker here -- gradient parity is
+"unpinned" by a reference vector.  Bar: 1e-5 relative (normwise and against the largest element), fp32.
+Needs a real MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close_fp32
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_num_threads(1)
+DEV = torch.device("cuda:0")
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+  from orca_amd import ops as _ops
+  return _ops
+
+
+def _sd(g, tag):
+  return {k[len(tag + "sd."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "sd.")}
+
+
+@pytest.mark.parametrize("tag", ["de172_K10_", "de1_K10_", "de4_K20_", "de172_K1_"])
+def test_attention_layer_backward_dense(golden, tag):
+  """loss.backward() through the drop-in TemporalAttentionLayer: gradients of the twelve parameters and of the
+  four differentiable inputs, on the reference's own forward fixtures (which include all-padded rows)."""
+  import orca_amd.api as api
+  g = golden("attention.npz")
+  sd = _sd(g, tag)
+  d_e = g[tag + "edge"].shape[2]
+  B, K = g[tag + "mask_in"].shape
+  R = torch.from_numpy(np.random.RandomState(B + K).randn(B, 100).astype(np.float32))
+  names = ["src", "src_t", "nbr", "nbr_t"]
+  # oracle: torch autograd on the CPU
+  P = {k: v.clone().requires_grad_() for k, v in sd.items()}
+  xin = {k: torch.from_numpy(g[tag + k]).clone().requires_grad_() for k in names}
+  out, _ = O.attention_forward(P, xin["src"], xin["src_t"], xin["nbr"], xin["nbr_t"], torch.from_numpy(g[tag + "edge"]),
+                               torch.from_numpy(g[tag + "mask_in"].copy()))
+  (out * R).sum().backward()
+  # product
+  layer = api.TemporalAttentionLayer(100, 100, d_e, 100, 100, n_head=2, dropout=0.1)
+  layer.load_state_dict(sd, strict=True)
+  layer = layer.to(DEV).eval()
+  yin = {k: torch.from_numpy(g[tag + k]).to(DEV).requires_grad_() for k in names}
+  mask = torch.from_numpy(g[tag + "mask_in"].copy()).to(DEV)
+  got, w = layer(yin["src"], yin["src_t"], yin["nbr"], yin["nbr_t"], torch.from_numpy(g[tag + "edge"]).to(DEV), mask)
+  assert_close_fp32(got.detach().cpu().numpy(), g[tag + "out"], 1e-5, tag + "out under autograd")
+  assert np.array_equal(mask.cpu().numpy(), g[tag + "mask_out"])
+  assert not w.requires_grad
+  (got * R.to(DEV)).sum().backward()
+  named = dict(layer.named_parameters())
+  for k in sd:
+    ref = P[k].grad.numpy()
+    if k == "multi_head_target.in_proj_bias":
+      # the key bias gets no gradient (softmax is shift-invariant): autograd leaves rounding noise there
+      assert float(np.abs(ref[200:400]).max()) <= 1e-5 * float(np.abs(ref).max())
+      ref = ref.copy()
+      ref[200:400] = 0.0
+    assert_close_fp32(named[k].grad.cpu().numpy(), ref, TOL, tag + "grad " + k)
+  for k in names:
+    assert_close_fp32(yin[k].grad.cpu().numpy(), xin[k].grad.numpy(), TOL, tag + "grad input " + k)
+
+
+@pytest.mark.parametrize("d_e,K,Q", [(172, 10, 700), (1, 10, 333), (64, 7, 130), (172, 20, 45)])
+def test_attention_backward_gather_mode(ops, golden, d_e, K, Q):
+  """The engine's mode: rows gathered by index with overlay flags, time encodings from dt with trainable
+  (w, b) -- per-slot row gradients and the time encoder's gradients."""
+  g = golden("attention.npz")
+  sd = _sd(g, "de172_K10_")
+  torch.manual_seed(d_e + K)
+  kd = 200 + d_e
+  sd["multi_head_target.k_proj_weight"] = torch.randn(200, kd) * (1.0 / kd ** 0.5)
+  sd["multi_head_target.v_proj_weight"] = torch.randn(200, kd) * (1.0 / kd ** 0.5)
+  rs = np.random.RandomState(Q)
+  N, E = 300, 2000
+  table = rs.randn(N, 100).astype(np.float32)
+  overlay = rs.randn(N, 100).astype(np.float32)
+  flags = (rs.rand(N) < 0.3).astype(np.uint8)
+  edge_feats = rs.randn(E, d_e).astype(np.float32)
+  nodes = rs.randint(0, N, Q).astype(np.int32)
+  nbr = rs.randint(1, N, (Q, K)).astype(np.int32)
+  eid = rs.randint(1, E, (Q, K)).astype(np.int32)
+  npad = rs.randint(0, K + 1, Q)
+  npad[:3] = K
+  for q in range(Q):
+    nbr[q, :npad[q]] = 0
+    eid[q, :npad[q]] = 0
+  dt = rs.uniform(0, 5e4, (Q, K)).astype(np.float32)
+  w_time = O.time_encode_weights(100)
+  b_time = torch.from_numpy(rs.uniform(-3, 3, 100).astype(np.float32))
+  R = torch.from_numpy(rs.randn(Q, 100).astype(np.float32))
+  # oracle
+  P = {k: v.clone().requires_grad_() for k, v in sd.items()}
+  eff = torch.from_numpy(np.where(flags[:, None] != 0, overlay, table))
+  nbr_t = torch.from_numpy(nbr.astype(np.int64))
+  src_rows = eff[torch.from_numpy(nodes.astype(np.int64))].clone().requires_grad_()
+  nbr_rows = eff[nbr_t.flatten()].view(Q, K, 100).clone().requires_grad_()
+  wt, bt = w_time.clone().requires_grad_(), b_time.clone().requires_grad_()
+  out, _ = O.attention_forward(P, src_rows, O.time_encode(torch.zeros(Q, 1), wt, bt), nbr_rows,
+                               O.time_encode(torch.from_numpy(dt), wt, bt),
+                               torch.from_numpy(edge_feats)[torch.from_numpy(eid.astype(np.int64))], nbr_t == 0)
+  (out * R).sum().backward()
+  # product
+  _t = lambda a: torch.from_numpy(a).to(DEV)
+  dsd = {k: v.to(DEV) for k, v in sd.items()}
+  grads, d_src, d_nbr, d_st, d_nt, d_tw, d_tb = ops.tgat_backward(
+      dsd, d_e, Q, K, R.to(DEV), want_time_param_grads=True, src_table=_t(table), src_idx=_t(nodes),
+      src_overlay=_t(overlay), src_flags=_t(flags), nbr_table=_t(table), nbr_idx=_t(nbr), nbr_overlay=_t(overlay),
+      nbr_flags=_t(flags), nbr_ids=_t(nbr), edge_table=_t(edge_feats), edge_idx=_t(eid), dt=_t(dt),
+      time_w=w_time.to(DEV), time_b=b_time.to(DEV))
+  assert d_st is None and d_nt is None
+  for k in sd:
+    ref = P[k].grad.numpy().copy()
+    if k == "multi_head_target.in_proj_bias":
+      ref[200:400] = 0.0
+    assert_close_fp32(grads[k].cpu().numpy(), ref, TOL, "gather grad " + k)
+  assert_close_fp32(d_src.cpu().numpy(), src_rows.grad.numpy(), TOL, "gather d_src")
+  assert_close_fp32(d_nbr.view(Q, K, 100).cpu().numpy(), nbr_rows.grad.numpy(), TOL, "gather d_nbr")
+  assert_close_fp32(d_tw.cpu().numpy(), wt.grad.numpy(), TOL, "gather d_time_w")
+  assert_close_fp32(d_tb.cpu().numpy(), bt.grad.numpy(), TOL, "gather d_time_b")
+  # padded slots get exactly zero
+  assert float(d_nbr.view(Q, K, 100)[torch.from_numpy(nbr == 0).to(DEV)].abs().max()) == 0.0
+
+
+def test_attention_backward_errors(ops, golden):
+  g = golden("attention.npz")
+  sd = {k: v.to(DEV) for k, v in _sd(g, "de1_K10_").items()}
+  x = torch.zeros(4, 100, device=DEV)
+  with pytest.raises(ValueError):        # K beyond ORCA_MAX_K
+    ops.tgat_backward(sd, 1, 1, 64, x[:1], src_table=x, nbr_table=x, edge_table=x, mask=x, src_time=x, nbr_time=x)
+  out = ops.tgat_backward(sd, 1, 0, 10, x[:0], src_table=x, nbr_table=x, edge_table=x, mask=x, src_time=x, nbr_time=x)
+  assert out[1].shape == (0, 100) and float(out[0]["norm.weight"].abs().max()) == 0.0
