@@ -202,6 +202,17 @@ int orca_gru_update(const float* blob, int msg_dim, const int32_t* ids, int64_t 
                     const float* x, const float* h, float* out, float* last_update, const float* msg_ts,
                     void* stream);
 
+/* Backward of GRUCell as get_updated_memory calls it (modules/memory_updater.py:56-78,86; train.py:236-237): for the
+ * n rows id = ids ? ids[r] : r with inputs x[id] [msg_dim], h[id] [ORCA_D] and d_out [n, ORCA_D] = dL/d(new h) in
+ * row order, ADDS the parameter gradients into g_* (shapes of the raw tensors) and writes d_x [n, msg_dim] and
+ * d_h [n, ORCA_D] when they are not NULL (upstream both are detached: the stored messages and the memory table
+ * carry no graph).  The parameters are the raw row-major tensors, not the packed blob. */
+int64_t orca_gru_backward_workspace_floats(int msg_dim, int64_t n);
+int orca_gru_backward(int msg_dim, const float* weight_ih, const float* weight_hh, const float* bias_ih,
+                      const float* bias_hh, const int32_t* ids, int64_t n, const float* x, const float* h,
+                      const float* d_out, float* g_weight_ih, float* g_weight_hh, float* g_bias_ih, float* g_bias_hh,
+                      float* d_x, float* d_h, float* workspace, void* stream);
+
 /* dst_table[id] = src_table[id] (rows of ORCA_D floats) and, if last_update != NULL, last_update[id] =
  * msg_ts[id], for the first min(n, *n_dev) ids of a work-list: commits GRU rows held in the overlay into
  * the persistent memory (modules/memory_updater.py:36-39). */

@@ -65,6 +65,8 @@ SIGNATURES = {
     "orca_tgat_blob_floats": (i64, [i32]),
     "orca_tgat_pack": (i32, [i32] + [vp] * 14),
     "orca_tgat_pack_gather": (i32, [i32] + [vp] * 6),
+    "orca_gru_backward_workspace_floats": (i64, [i32, i64]),
+    "orca_gru_backward": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 11),
     "orca_tgat_backward_workspace_floats": (i64, [i32, i64, i32]),
     "orca_tgat_backward": (i32, [vp, i32, vp, i64, i32] + [vp] * 10),
     "orca_tgat_forward": (i32, [vp, i32, ctypes.POINTER(TgatInputs), i64, i32, vp, vp, vp]),

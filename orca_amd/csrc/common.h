@@ -196,6 +196,16 @@ __device__ __forceinline__ void message_store_wave(int64_t id, int64_t partner, 
   }
 }
 
+// Generic strided fp32 MFMA GEMM and column sums of the backward passes (tgat_bwd.hip):
+// C(m,n) = alpha * (sum_k A(m,k) B(k,n) + bias[n]) [+ C(m,n)] [relu], X(i,j) = X[i*s0 + j*s1]; with part != NULL and
+// splits > 1 the k range is cut into pieces whose partial sums are added in a fixed order (deterministic).
+constexpr int ORCA_GEMM_SPLITS = 32;
+int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
+               int64_t sbn, float* C, int64_t scm, int64_t scn, const float* bias, float alpha, bool accumulate, bool relu,
+               float* part = nullptr, int splits = 1);
+// out[n] (+)= alpha * sum_q X[q*ld + n], n < ncols
+int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate);
+
 // generic strided pack kernel launcher (pack.hip)
 int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd, const float* src,
                      int64_t sn, int64_t sk, hipStream_t stream);

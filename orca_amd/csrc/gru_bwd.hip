@@ -1,0 +1,88 @@
+// Backward of the GRU memory updater: torch autograd of nn.GRUCell as modules/memory_updater.py:86 calls it
+// from get_updated_memory (:56-78), the only place the training loss reaches it (train.py:236-237).
+// First cut in the style of tgat_bwd.hip: rows gathered into the workspace, the gate pre-activations recomputed
+// and all contractions through the generic strided MFMA GEMM, one elementwise kernel for the gate derivatives.
+#include "common.h"
+
+namespace {
+constexpr int D = ORCA_D, G3 = 3 * ORCA_D;
+
+// dst[r][0..w) = table[ids ? ids[r] : r][0..w)
+__global__ void k_gather_wide(const float* __restrict__ table, const int32_t* __restrict__ ids, int64_t n, int w,
+                              float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * w) return;
+  const int64_t r = i / w;
+  dst[i] = table[(int64_t)(ids ? ids[r] : r) * w + i % w];
+}
+
+// In: gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh [n,300] (gate order r, z, n), h [n,100], d_out [n,100].
+// Out (in place): gi <- d gi, gh <- d gh;  dh_direct [n,100] = d_out * z (the blend's direct path), may be NULL.
+__global__ void k_gru_gates_bwd(float* __restrict__ gi, float* __restrict__ gh, const float* __restrict__ h,
+                                const float* __restrict__ d_out, int64_t n, float* __restrict__ dh_direct) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * D) return;
+  const int64_t r_ = i / D;
+  const int u = (int)(i % D);
+  float* a = gi + r_ * G3;
+  float* b = gh + r_ * G3;
+  const float r = 1.0f / (1.0f + expf(-(a[u] + b[u])));
+  const float z = 1.0f / (1.0f + expf(-(a[D + u] + b[D + u])));
+  const float ghn = b[2 * D + u];
+  const float nn = tanhf(a[2 * D + u] + r * ghn);
+  const float go = d_out[i];
+  const float dn = go * (1.0f - z), dz = go * (h[i] - nn);
+  const float dpn = dn * (1.0f - nn * nn);
+  const float dpr = dpn * ghn * r * (1.0f - r);
+  const float dpz = dz * z * (1.0f - z);
+  a[u] = dpr;          b[u] = dpr;
+  a[D + u] = dpz;      b[D + u] = dpz;
+  a[2 * D + u] = dpn;  b[2 * D + u] = dpn * r;
+  if (dh_direct) dh_direct[i] = go * z;
+}
+}  // namespace
+
+ORCA_API int64_t orca_gru_backward_workspace_floats(int msg_dim, int64_t n) {
+  if (msg_dim < 1 || msg_dim > 3 * ORCA_D + ORCA_MAX_DE || n < 0) return -1;
+  return n * (msg_dim + D + 2 * G3) + 256 + (int64_t)ORCA_GEMM_SPLITS * G3 * (msg_dim > D ? msg_dim : D);
+}
+
+ORCA_API int orca_gru_backward(int msg_dim, const float* weight_ih, const float* weight_hh, const float* bias_ih,
+                               const float* bias_hh, const int32_t* ids, int64_t n, const float* x, const float* h,
+                               const float* d_out, float* g_weight_ih, float* g_weight_hh, float* g_bias_ih,
+                               float* g_bias_hh, float* d_x, float* d_h, float* workspace, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  ORCA_REQUIRE(n >= 0, "orca_gru_backward: negative row count");
+  if (n == 0) return ORCA_OK;
+  ORCA_REQUIRE(msg_dim >= 1 && msg_dim <= 3 * ORCA_D + ORCA_MAX_DE, "orca_gru_backward: msg_dim=%d out of range", msg_dim);
+  ORCA_REQUIRE(n < (1LL << 31) / 1024, "orca_gru_backward: too many rows for one call");
+  ORCA_REQUIRE(weight_ih && weight_hh && bias_ih && bias_hh && x && h && d_out && workspace, "orca_gru_backward: null pointer");
+  ORCA_REQUIRE(g_weight_ih && g_weight_hh && g_bias_ih && g_bias_hh, "orca_gru_backward: null gradient buffer");
+  const int M = (int)n;
+  float* xg = workspace;
+  float* hg = xg + n * msg_dim;
+  float* gi = hg + n * D;
+  float* gh = gi + n * G3;
+  float* part = gh + n * G3;
+  part += (64 - ((part - workspace) & 63)) & 63;
+  auto ew = [&](int64_t k) { return (unsigned)ceil_div64(k, 256); };
+  k_gather_wide<<<ew(n * msg_dim), 256, 0, s>>>(x, ids, n, msg_dim, xg);
+  k_gather_wide<<<ew(n * D), 256, 0, s>>>(h, ids, n, D, hg);
+  int rc = ORCA_OK;
+  rc |= orca_sgemm(s, M, G3, msg_dim, xg, msg_dim, 1, weight_ih, 1, msg_dim, gi, G3, 1, bias_ih, 1.f, false, false);
+  rc |= orca_sgemm(s, M, G3, D, hg, D, 1, weight_hh, 1, D, gh, G3, 1, bias_hh, 1.f, false, false);
+  k_gru_gates_bwd<<<ew(n * D), 256, 0, s>>>(gi, gh, hg, d_out, n, d_h);
+  // weight_ih [300,msg] += dgi^T x;  weight_hh [300,100] += dgh^T h;  the biases: column sums
+  rc |= orca_sgemm(s, G3, msg_dim, M, gi, 1, G3, xg, msg_dim, 1, g_weight_ih, msg_dim, 1, nullptr, 1.f, true, false, part,
+                   ORCA_GEMM_SPLITS);
+  rc |= orca_sgemm(s, G3, D, M, gh, 1, G3, hg, D, 1, g_weight_hh, D, 1, nullptr, 1.f, true, false, part, ORCA_GEMM_SPLITS);
+  rc |= orca_colsum(s, gi, n, G3, G3, g_bias_ih, 1.f, true);
+  rc |= orca_colsum(s, gh, n, G3, G3, g_bias_hh, 1.f, true);
+  if (d_x) rc |= orca_sgemm(s, M, msg_dim, G3, gi, G3, 1, weight_ih, msg_dim, 1, d_x, msg_dim, 1, nullptr, 1.f, false, false);
+  if (d_h) rc |= orca_sgemm(s, M, D, G3, gh, G3, 1, weight_hh, D, 1, d_h, D, 1, nullptr, 1.f, true, false);
+  if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
+    orca_set_error("orca_gru_backward: kernel launch failed");
+    return ORCA_EHIP;
+  }
+  return ORCA_OK;
+}

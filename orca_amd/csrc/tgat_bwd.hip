@@ -117,9 +117,11 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int
   }
 }
 
-int sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
-          int64_t sbn, float* C, int64_t scm, int64_t scn, const float* bias, float alpha, bool accumulate, bool relu,
-          float* part = nullptr, int splits = 1) {
+}  // namespace
+
+int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
+               int64_t sbn, float* C, int64_t scm, int64_t scn, const float* bias, float alpha, bool accumulate, bool relu,
+               float* part, int splits) {
   if (M <= 0 || N <= 0) return ORCA_OK;
   GemmArgs g{M, N, K, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, alpha, accumulate ? 1 : 0, relu ? 1 : 0, K, nullptr};
   unsigned gz = 1;
@@ -138,10 +140,15 @@ int sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, int64
   return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
 }
 
-int colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate) {
+int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate) {
+  if (ncols <= 0) return ORCA_OK;
   k_colsum<<<(unsigned)((ncols + 63) / 64), 256, 0, s>>>(X, Q, ld, ncols, out, alpha, accumulate ? 1 : 0);
   return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
 }
+
+namespace {
+#define sgemm orca_sgemm
+#define colsum orca_colsum
 
 // ---- per-query pieces -------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_max_f(float v) {
@@ -408,7 +415,7 @@ __global__ void k_bwd_finish(orca_tgat_inputs in, int64_t Q, const float* __rest
 struct Ws {   // float offsets of the per-query rows inside the workspace
   int64_t xq, qs, qt, a, xbar, ocat, x1, h1, y, dy, gx, dh1, dx1, docat, dxbar, dqt, dq, dxq, tgrad, invalid, part, total;
 };
-constexpr int SPLITS = 32;
+constexpr int SPLITS = ORCA_GEMM_SPLITS;
 Ws ws_layout(int d_e, int64_t Q, int K) {
   const int64_t kdim = QD + d_e;
   Ws w{};

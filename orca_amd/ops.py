@@ -271,6 +271,27 @@ def gru_pack(weight_ih, weight_hh, bias_ih, bias_hh, device, blob=None):
   return blob
 
 
+def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_inputs=False):
+  """orca_gru_backward.  ids int32 [n] or None (dense rows).  Returns (g_weight_ih, g_weight_hh, g_bias_ih,
+  g_bias_hh, d_x, d_h) -- the last two None unless want_inputs."""
+  dev = d_out.device
+  ps = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
+  gs = [torch.zeros_like(p) for p in ps]
+  msg_dim = ps[0].shape[1]
+  n = d_out.shape[0]
+  nw = _lib.load().orca_gru_backward_workspace_floats(int(msg_dim), int(n))
+  if nw < 0:
+    raise ValueError(f"gru_backward: unsupported message width {msg_dim}")
+  wsp = torch.empty(nw, dtype=torch.float32, device=dev)
+  go = d_out.detach().to(torch.float32).contiguous()
+  d_x = torch.empty((n, msg_dim), dtype=torch.float32, device=dev) if want_inputs else None
+  d_h = torch.empty((n, D), dtype=torch.float32, device=dev) if want_inputs else None
+  x, h = x.contiguous(), h.contiguous()
+  check(_lib.load().orca_gru_backward(int(msg_dim), *(ptr(p) for p in ps), ptr(ids), int(n), ptr(x), ptr(h), ptr(go),
+                                      *(ptr(g) for g in gs), ptr(d_x), ptr(d_h), ptr(wsp), stream()), "orca_gru_backward")
+  return (*gs, d_x, d_h)
+
+
 def gru_update(blob, msg_dim, ids, n, n_dev, x, h, out, last_update=None, msg_ts=None):
   check(_lib.load().orca_gru_update(ptr(blob), int(msg_dim), ptr(ids), int(n), ptr(n_dev), ptr(x), ptr(h), ptr(out),
                                     ptr(last_update), ptr(msg_ts), stream()), "orca_gru_update")

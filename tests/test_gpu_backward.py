@@ -136,3 +136,27 @@ def test_attention_backward_errors(ops, golden):
     ops.tgat_backward(sd, 1, 1, 64, x[:1], src_table=x, nbr_table=x, edge_table=x, mask=x, src_time=x, nbr_time=x)
   out = ops.tgat_backward(sd, 1, 0, 10, x[:0], src_table=x, nbr_table=x, edge_table=x, mask=x, src_time=x, nbr_time=x)
   assert out[1].shape == (0, 100) and float(out[0]["norm.weight"].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("msg_dim,n,gather", [(472, 700, True), (301, 33, False), (472, 1, True), (472, 5000, True)])
+def test_gru_backward(ops, msg_dim, n, gather):
+  """orca_gru_backward against torch autograd of the oracle's GRUCell restatement (memory_updater.py:86)."""
+  rs = np.random.RandomState(msg_dim + n)
+  N = 3 * n + 5 if gather else n
+  P = {"weight_ih": rs.randn(300, msg_dim) * 0.05, "weight_hh": rs.randn(300, 100) * 0.1,
+       "bias_ih": rs.randn(300) * 0.1, "bias_hh": rs.randn(300) * 0.1}
+  P = {k: torch.from_numpy(v.astype(np.float32)) for k, v in P.items()}
+  x = torch.from_numpy(rs.randn(N, msg_dim).astype(np.float32))
+  h = torch.from_numpy(rs.randn(N, 100).astype(np.float32))
+  ids = torch.from_numpy(rs.permutation(N)[:n].astype(np.int32)) if gather else None
+  R = torch.from_numpy(rs.randn(n, 100).astype(np.float32))
+  Pg = {k: v.clone().requires_grad_() for k, v in P.items()}
+  xr = (x[ids.long()] if gather else x).clone().requires_grad_()
+  hr = (h[ids.long()] if gather else h).clone().requires_grad_()
+  (O.gru_cell(Pg, xr, hr) * R).sum().backward()
+  got = ops.gru_backward(P["weight_ih"].to(DEV), P["weight_hh"].to(DEV), P["bias_ih"].to(DEV), P["bias_hh"].to(DEV),
+                         ids.to(DEV) if gather else None, x.to(DEV), h.to(DEV), R.to(DEV), want_inputs=True)
+  for k, t in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), got[:4]):
+    assert_close_fp32(t.cpu().numpy(), Pg[k].grad.numpy(), TOL, "gru grad " + k)
+  assert_close_fp32(got[4].cpu().numpy(), xr.grad.numpy(), TOL, "gru d_x")
+  assert_close_fp32(got[5].cpu().numpy(), hr.grad.numpy(), TOL, "gru d_h")
