@@ -275,6 +275,15 @@ int orca_history_push(float* emb, const float* x, const int64_t* ids, int64_t n,
  * idx is int64, or int32 when idx64 == NULL. */
 int orca_gather_rows(const float* table, int64_t width, const int64_t* idx64, const int32_t* idx32,
                      int64_t n, float* out, void* stream);
+/* Gradient accumulation onto the rows that get_updated_memory produced (memory_updater.py:56-78): autograd's
+ * index backward of `updated_memory[nodes]` (embedding_module.py:121,160), restricted to the flagged (pending) ids,
+ * whose rows are GRU outputs -- the other rows of the table are detached upstream.
+ * orca_index_positions: pos[list[i]] = i for i < min(n, *n_dev) (list = the distinct pending ids, n_dev may be NULL).
+ * orca_scatter_add_flagged: dst[pos[id]] += rows[p] (ORCA_D floats) for every p < n whose id = idx[p] has flags[id];
+ * idx is int64, or int32 when idx64 == NULL; dst is zeroed by the caller. */
+int orca_index_positions(const int32_t* list, int64_t n, const int32_t* n_dev, int32_t* pos, void* stream);
+int orca_scatter_add_flagged(const float* rows, const int64_t* idx64, const int32_t* idx32, int64_t n,
+                             const uint8_t* flags, const int32_t* pos, int64_t n_nodes, float* dst, void* stream);
 /* out_table[ids[p]] = x[p] (ids unique; Memory.set_memory modules/memory.py:33-34) */
 int orca_scatter_rows(float* table, int64_t width, const int64_t* ids, int64_t n, const float* x,
                       void* stream);

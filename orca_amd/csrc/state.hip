@@ -183,6 +183,28 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
   for (int64_t c = lane; c < width; c += 64) out[p * width + c] = table[r * width + c];
 }
 
+// pos[list[i]] = i for the first min(n, *n_dev) entries of a list of distinct ids
+__global__ void k_index_positions(const int32_t* __restrict__ list, int64_t n, const int32_t* __restrict__ n_dev,
+                                  int32_t* __restrict__ pos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t m = n_dev ? (*n_dev < n ? *n_dev : n) : n;
+  if (i < m) pos[list[i]] = (int32_t)i;
+}
+// dst[pos[id]] += rows[p] for every position p whose id carries a flag (fp32 atomics: several positions share an id)
+__global__ __launch_bounds__(256) void k_scatter_add_flagged(const float* __restrict__ rows, const int64_t* __restrict__ idx64,
+                                                             const int32_t* __restrict__ idx32, int64_t n,
+                                                             const uint8_t* __restrict__ flags,
+                                                             const int32_t* __restrict__ pos, int64_t n_nodes,
+                                                             float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const int64_t id = idx64 ? idx64[p] : (int64_t)idx32[p];
+  if (id < 0 || id >= n_nodes || !flags[id]) return;
+  float* d = dst + (int64_t)pos[id] * D;
+  for (int c = lane; c < D; c += 64) atomicAdd(d + c, rows[p * D + c]);
+}
+
 __global__ __launch_bounds__(256) void k_scatter_rows(float* __restrict__ table, int64_t width,
                                                       const int64_t* __restrict__ ids, int64_t n,
                                                       const float* __restrict__ x) {
@@ -350,6 +372,25 @@ ORCA_API int orca_gather_rows(const float* table, int64_t width, const int64_t* 
   ORCA_REQUIRE(n >= 0 && width > 0 && (n == 0 || (table && out && (idx64 || idx32))), "orca_gather_rows: bad arguments");
   if (n == 0) return ORCA_OK;
   k_gather_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(table, width, idx64, idx32, n, out);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_index_positions(const int32_t* list, int64_t n, const int32_t* n_dev, int32_t* pos, void* stream) {
+  ORCA_REQUIRE(n >= 0 && (n == 0 || (list && pos)), "orca_index_positions: bad arguments");
+  if (n == 0) return ORCA_OK;
+  k_index_positions<<<blocks(n, 256), 256, 0, (hipStream_t)stream>>>(list, n, n_dev, pos);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_scatter_add_flagged(const float* rows, const int64_t* idx64, const int32_t* idx32, int64_t n,
+                                      const uint8_t* flags, const int32_t* pos, int64_t n_nodes, float* dst,
+                                      void* stream) {
+  ORCA_REQUIRE(n >= 0 && (n == 0 || (rows && (idx64 || idx32) && flags && pos && dst)),
+               "orca_scatter_add_flagged: bad arguments");
+  if (n == 0) return ORCA_OK;
+  k_scatter_add_flagged<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(rows, idx64, idx32, n, flags, pos, n_nodes, dst);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

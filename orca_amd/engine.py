@@ -98,20 +98,33 @@ class OrcaEngine:
   # -------------------------------------------------------------------------------------------
   def load_state_dict(self, sd):
     dev = self.device
-    sd = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in sd.items()}
-    self.time_w = sd["time_encoder.w.weight"].reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+    if sd is not getattr(self, "params", None):
+      sd = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in sd.items()}
+      # the raw tensors on the device: what the backward pass reads and an optimizer updates (train_step / refresh)
+      self.params = {k: v.detach().to(device=dev, dtype=torch.float32).contiguous().clone() for k, v in sd.items()}
+      sd = self.params
+    first = not hasattr(self, "att_blobs")
+    tw = sd["time_encoder.w.weight"].reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
     b = sd.get("time_encoder.w.bias")
-    self.time_b = (b.reshape(-1).to(device=dev, dtype=torch.float32).contiguous() if b is not None
-                   else torch.zeros(D, device=dev))
-    self.att_blobs = []
+    tb = b.reshape(-1).to(device=dev, dtype=torch.float32).contiguous() if b is not None else torch.zeros(D, device=dev)
+    if first:
+      self.time_w, self.time_b = tw.clone(), tb.clone()
+      self.att_blobs, self.gru_blob = [None] * self.L, None
+    else:                      # re-pack in place: the native driver holds these addresses
+      self.time_w.copy_(tw)
+      self.time_b.copy_(tb)
     for i in range(self.L):
       p = f"embedding_module.attention_models.{i}."
-      self.att_blobs.append(ops.tgat_pack({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, self.d_e, dev,
-                                          time_b=self.time_b))
+      self.att_blobs[i] = ops.tgat_pack({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, self.d_e, dev,
+                                        blob=self.att_blobs[i], time_b=self.time_b)
     p = "memory_updater.memory_updater."
-    self.gru_blob = ops.gru_pack(sd[p + "weight_ih"], sd[p + "weight_hh"], sd[p + "bias_ih"], sd[p + "bias_hh"], dev)
-    self.aff = {k[len("affinity_score."):]: v.to(device=dev, dtype=torch.float32)
-                for k, v in sd.items() if k.startswith("affinity_score.")}
+    self.gru_blob = ops.gru_pack(sd[p + "weight_ih"], sd[p + "weight_hh"], sd[p + "bias_ih"], sd[p + "bias_hh"], dev,
+                                 blob=self.gru_blob)
+    self.aff = {k[len("affinity_score."):]: v for k, v in self.params.items() if k.startswith("affinity_score.")}
+
+  def refresh(self):
+    """Re-packs the kernels' parameter blobs from self.params (after an optimizer step changed them in place)."""
+    self.load_state_dict(self.params)     # in place: the native driver keeps its blob addresses
 
   def set_neighbor_finder(self, csr):
     """tgn_model.py:193-195; csr is an ops.CSR (or a shim NeighborFinder carrying .csr)."""
@@ -491,6 +504,116 @@ class OrcaEngine:
     h = torch.relu(x @ self.aff["fc1.weight"].t() + self.aff["fc1.bias"])
     s = h @ self.aff["fc2.weight"].t() + self.aff["fc2.bias"]
     return s[:n].sigmoid(), s[n:].sigmoid()
+
+  # -------------------------------------------------------------------------------------------
+  def train_step(self, src, dst, neg, ts, eidx):
+    """One training batch of train.py:200-246 up to (not including) optimizer.step(): the train-ordered forward
+    of compute_edge_probabilities (tgn_model.py:95-157), the loss BCE(pos, 1) + BCE(neg, 0) (train.py:231-233) and
+    its backward.  Path B (`reuse`, no budget), dropout off.  Returns (loss, grads) with grads keyed like the
+    state_dict (parameters the loss does not reach are absent); the state advances exactly as in
+    compute_temporal_embeddings(train=True).  Gradients flow as upstream: through the attention layers into the
+    updated-memory rows of pending ids and from there into the GRU; history rows, stored messages and the memory
+    table are detached (history.py:22-24, memory.py:45-47).  An optimizer updates self.params in place; call
+    refresh() afterwards.  With several ranks every rank back-propagates its query slice and the parameter
+    gradients are all-reduced.  The link decoder (two small dense layers) runs as library
+    GEMMs under torch autograd, like its forward in compute_edge_probabilities."""
+    if not (self.reuse and self.budget == 0):
+      raise OrcaError("train_step: only the reuse path (Path B) back-propagates so far")
+    if self.csr is None:
+      raise OrcaError("OrcaEngine: set_neighbor_finder() first")
+    dev = self.device
+    src, dst, neg, eidx = (self._dev(x, torch.int64) for x in (src, dst, neg, eidx))
+    ts = self._dev(ts, torch.float64)
+    self.batch_counter += 1
+    self.test_mode = False
+    self._set_overlay_complete(False)
+    bs = src.numel()
+    nodes = torch.cat([src, dst, neg])
+    t3 = torch.cat([ts, ts, ts])
+    Q = nodes.numel()
+    lo, hi, per = self._slice(Q)
+    my_nodes = nodes[lo:hi]
+    n = my_nodes.numel()
+    # ---- forward, keeping what the backward re-reads (the tables are not touched before it has run) ----
+    nbr, eid, dt = self._sample(my_nodes, t3[lo:hi])
+    self._overlay_updated_memory(nbr, my_nodes)
+    my32 = my_nodes.to(torch.int32)
+    embs = [self._attend(1, n, nbr, eid, dt, True, self.memory, my32, self.memory, nbr, True)]
+    for layer in range(2, self.L + 1):
+      full = self._all_gather_rows(embs[-1], Q, per)
+      ops.history_push(self.hist[layer - 2], full, nodes, self.slot, self._slot_epoch(Q))
+      embs.append(self._attend(layer, n, nbr, eid, dt, True, embs[-1], None, self.hist[layer - 2], nbr, False))
+    out = self._all_gather_rows(embs[-1], Q, per)
+    # ---- link decoder + loss (tgn_model.py:150-157, train.py:231-233) ----
+    leaf = out.detach().requires_grad_()
+    aff = {k: v.detach().requires_grad_() for k, v in self.aff.items()}
+    se, de, ne = leaf[:bs], leaf[bs:2 * bs], leaf[2 * bs:]
+    x = torch.cat([torch.cat([se, se]), torch.cat([de, ne])], dim=1)
+    h = torch.relu(x @ aff["fc1.weight"].t() + aff["fc1.bias"])
+    score = (h @ aff["fc2.weight"].t() + aff["fc2.bias"]).sigmoid().squeeze(1)
+    bce = torch.nn.functional.binary_cross_entropy
+    loss = bce(score[:bs], torch.ones(bs, device=dev)) + bce(score[bs:], torch.zeros(bs, device=dev))
+    loss.backward()
+    grads = {"affinity_score." + k: v.grad for k, v in aff.items()}
+    # ---- backward through the attention layers (this rank's slice) ----
+    d = leaf.grad[lo:hi].contiguous()
+    d_tw = torch.zeros(D, dtype=torch.float32, device=dev)
+    d_tb = torch.zeros(D, dtype=torch.float32, device=dev)
+    d_nbr = None
+    for layer in range(self.L, 0, -1):
+      p = f"embedding_module.attention_models.{layer - 1}."
+      sd = {k[len(p):]: v for k, v in self.params.items() if k.startswith(p)}
+      kw = dict(nbr_ids=nbr, edge_table=self.edge_feats, edge_idx=eid, dt=dt, time_w=self.time_w, time_b=self.time_b,
+                nbr_idx=nbr)
+      if layer == 1:
+        kw.update(src_table=self.memory, src_idx=my32, nbr_table=self.memory, src_overlay=self.overlay,
+                  src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
+      else:
+        kw.update(src_table=embs[layer - 2], nbr_table=self.hist[layer - 2])
+      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, n, self.K, d, want_time_param_grads=True, **kw)
+      for k, v in g.items():
+        grads[p + k] = v
+      d_tw += tw
+      d_tb += tb
+      d = d_src
+    # ---- into the updated-memory rows of the pending ids this slice read, then through the GRU ----
+    cnt = int(self.count.item())           # distinct pending ids of the overlay work-list (set by the forward)
+    if cnt:
+      if getattr(self, "_pos", None) is None:
+        self._pos = torch.zeros(self.N, dtype=torch.int32, device=dev)
+      wl = self.worklist[:cnt]
+      ops.index_positions(wl, cnt, None, self._pos)
+      d_upd = torch.zeros(cnt, D, dtype=torch.float32, device=dev)
+      ops.scatter_add_flagged(d, my_nodes, self.pending, self._pos, d_upd)
+      ops.scatter_add_flagged(d_nbr, nbr.view(-1), self.pending, self._pos, d_upd)
+      p = "memory_updater.memory_updater."
+      gg = ops.gru_backward(self.params[p + "weight_ih"], self.params[p + "weight_hh"], self.params[p + "bias_ih"],
+                            self.params[p + "bias_hh"], wl, self.messages, self.memory, d_upd)
+      for k, v in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), gg[:4]):
+        grads[p + k] = v
+    else:
+      p = "memory_updater.memory_updater."
+      for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+        grads[p + k] = torch.zeros_like(self.params[p + k])
+    grads["time_encoder.w.weight"] = d_tw.view(D, 1)
+    if "time_encoder.w.bias" in self.params:
+      grads["time_encoder.w.bias"] = d_tb
+    if self.world > 1:                     # every rank holds the decoder's full gradient already
+      import torch.distributed as dist
+      keys = sorted(k for k in grads if not k.startswith("affinity_score."))
+      flat = torch.cat([grads[k].reshape(-1) for k in keys])
+      dist.all_reduce(flat, group=self.group)
+      o = 0
+      for k in keys:
+        m = grads[k].numel()
+        grads[k] = flat[o:o + m].view_as(grads[k])
+        o += m
+    # ---- the state moves on (tgn_model.py:127-141) ----
+    positives = nodes[:2 * bs]
+    self._persist_memory(positives)
+    ops.message_store(src, dst, eidx, ts, self.memory, self.last_update, self.edge_feats, self.time_w, self.time_b,
+                      self.slot, self._slot_epoch(2 * bs), self.messages, self.msg_ts, self.pending)
+    return loss.detach(), grads
 
   def _dev(self, x, dtype):
     if not isinstance(x, torch.Tensor):

@@ -354,6 +354,19 @@ def history_push(emb, x, ids, slot, epoch):
                                       stream()), "orca_history_push")
 
 
+def index_positions(lst, n, n_dev, pos):
+  check(_lib.load().orca_index_positions(ptr(lst), int(n), ptr(n_dev), ptr(pos), stream()), "orca_index_positions")
+
+
+def scatter_add_flagged(rows, idx, flags, pos, dst):
+  i64 = idx if idx.dtype == torch.int64 else None
+  i32 = idx if idx.dtype == torch.int32 else None
+  if i64 is None and i32 is None:
+    raise TypeError("scatter_add_flagged: idx must be int64 or int32")
+  check(_lib.load().orca_scatter_add_flagged(ptr(rows.contiguous()), ptr(i64), ptr(i32), idx.numel(), ptr(flags), ptr(pos),
+                                             flags.numel(), ptr(dst), stream()), "orca_scatter_add_flagged")
+
+
 def gather_rows(table, idx, out=None):
   n = idx.numel()
   width = table.shape[1]

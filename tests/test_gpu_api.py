@@ -77,7 +77,8 @@ def test_temporal_attention_layer(api, golden, tag):
   layer = layer.to(DEV).eval()
   mask = torch.from_numpy(g[tag + "mask_in"].copy()).to(DEV)
   t = lambda k: torch.from_numpy(g[tag + k]).to(DEV)
-  out, w = layer(t("src"), t("src_t"), t("nbr"), t("nbr_t"), t("edge"), mask)
+  with torch.no_grad():
+    out, w = layer(t("src"), t("src_t"), t("nbr"), t("nbr_t"), t("edge"), mask)
   assert_close_fp32(out.cpu().numpy(), g[tag + "out"], 1e-5, tag + "out")
   assert np.array_equal(mask.cpu().numpy(), g[tag + "mask_out"])           # mutated in place, as upstream
   if tag + "weights" in g.files:
@@ -85,7 +86,8 @@ def test_temporal_attention_layer(api, golden, tag):
   # parameters changed in place -> the packed blob follows
   with torch.no_grad():
     layer.norm.bias.add_(1.0)
-  out2, _ = layer(t("src"), t("src_t"), t("nbr"), t("nbr_t"), t("edge"), torch.from_numpy(g[tag + "mask_in"].copy()).to(DEV))
+  with torch.no_grad():
+    out2, _ = layer(t("src"), t("src_t"), t("nbr"), t("nbr_t"), t("edge"), torch.from_numpy(g[tag + "mask_in"].copy()).to(DEV))
   assert_close_fp32(out2.cpu().numpy(), g[tag + "out"] + 1.0, 1e-5, tag + "out after in-place update")
 
 
