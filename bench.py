@@ -69,6 +69,9 @@ def parse():
   ap.add_argument("--event-stride", type=int, default=8,
                   help="attach HIP events to the kernels of every n-th timed step (the event plumbing costs ~20 us of "
                        "host time per step it is on)")
+  ap.add_argument("--train-steps", type=int, default=20,
+                  help="N=1, Path B: also time this many full training steps (forward + backward + Adam + re-pack), "
+                       "reported as the secondary figure 'train_step' (0 = skip)")
   return ap.parse_args()
 
 
@@ -148,7 +151,8 @@ def main():
   eng.set_neighbor_finder(csr)
   # consecutive time-ordered batches from the 70 % mark (train.py:131-137 chronological split)
   gbs = args.bs * world
-  n_batches = args.warmup + args.steps
+  n_train = args.train_steps + 5 if (world == 1 and not args.no_reuse and args.train_steps > 0) else 0
+  n_batches = args.warmup + args.steps + n_train
   start = int(0.7 * args.edges)
   if start + n_batches * gbs > args.edges:
     start = max(0, args.edges - n_batches * gbs)
@@ -181,7 +185,7 @@ def main():
         eng.prof = {}                 # Python-dispatched path (Path A)
     barrier()
     t0 = time.perf_counter()
-    for b in batches[args.warmup:]:
+    for b in batches[args.warmup:args.warmup + args.steps]:
       eng.compute_temporal_embeddings(*b, train=True, gather_output=gather)
     barrier()
     dt = time.perf_counter() - t0
@@ -193,6 +197,23 @@ def main():
   prof = eng.profile_read() or eng.prof_summary()   # HIP events recorded around the kernels inside the timed region
   eng.profile_kernels(False)
   eng.prof = None
+  train = None
+  if n_train:       # secondary figure: the full training step on the batches that follow
+    eng.optimizer(lr=1e-4)
+    tb = batches[args.warmup + args.steps:]
+    for b in tb[:5]:
+      eng.step_optimizer(eng.train_step(*b)[1])
+    barrier()
+    t1 = time.perf_counter()
+    for b in tb[5:]:
+      loss, grads = eng.train_step(*b)
+      eng.step_optimizer(grads)
+    barrier()
+    t1 = time.perf_counter() - t1
+    train = {"edges_per_s": args.train_steps * gbs / t1, "ms_per_step": 1e3 * t1 / args.train_steps,
+             "steps": args.train_steps, "last_loss": float(loss),
+             "what": "train-ordered forward + BCE loss + backward (attention x layers, GRU) + Adam + blob re-pack; "
+                     "first-cut backward (generic MFMA GEMM + wave-per-query kernels, Python-dispatched)"}
 
   if rank == 0:
     Q = 3 * args.bs
@@ -242,9 +263,11 @@ def main():
           gms = prof["gru_update"][1]
           out["gru"] = {"rows_per_launch": rows, "flops_per_row": 2 * (3 * 100 + args.d_e + 100) * 300,
                         "achieved_tflops": rows * 2 * (3 * 100 + args.d_e + 100) * 300 / (gms * 1e-3) / 1e12}
+    if train:
+      out["train_step"] = train
     if world == 1 and args.cpu_batches > 0:
       threads = min(16, os.cpu_count() or 1)
-      out["cpu_baseline"] = cpu_baseline(args, csr, ef, sd, batches[args.warmup:], threads)
+      out["cpu_baseline"] = cpu_baseline(args, csr, ef, sd, batches[args.warmup:args.warmup + args.steps], threads)
     print(json.dumps(out), flush=True)
   if world > 1:
     import torch.distributed as dist

@@ -76,8 +76,8 @@ ORCA_API int orca_gru_backward(int msg_dim, const float* weight_ih, const float*
   rc |= orca_sgemm(s, G3, msg_dim, M, gi, 1, G3, xg, msg_dim, 1, g_weight_ih, msg_dim, 1, nullptr, 1.f, true, false, part,
                    ORCA_GEMM_SPLITS);
   rc |= orca_sgemm(s, G3, D, M, gh, 1, G3, hg, D, 1, g_weight_hh, D, 1, nullptr, 1.f, true, false, part, ORCA_GEMM_SPLITS);
-  rc |= orca_colsum(s, gi, n, G3, G3, g_bias_ih, 1.f, true);
-  rc |= orca_colsum(s, gh, n, G3, G3, g_bias_hh, 1.f, true);
+  rc |= orca_colsum(s, gi, n, G3, G3, g_bias_ih, 1.f, true, part);
+  rc |= orca_colsum(s, gh, n, G3, G3, g_bias_hh, 1.f, true, part);
   if (d_x) rc |= orca_sgemm(s, M, msg_dim, G3, gi, G3, 1, weight_ih, msg_dim, 1, d_x, msg_dim, 1, nullptr, 1.f, false, false);
   if (d_h) rc |= orca_sgemm(s, M, D, G3, gh, G3, 1, weight_hh, D, 1, d_h, D, 1, nullptr, 1.f, true, false);
   if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {

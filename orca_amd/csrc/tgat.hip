@@ -69,9 +69,19 @@ __host__ __device__ constexpr Blob blob_layout(int d_e) {
 
 // ---- folding the linear tail (setup time, fp64 accumulation) ---------------------------------------------
 // U[h][n][d] = sum_j W1[n][j] Wo[j][h*100 + d]            (fc1_w [100, 300], o_w [200, 200], row-major)
-__global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restrict__ o_w, double* __restrict__ U) {
+// U[2*D*D + j] = bo[j] + sum_k Wo[j][k] bv[k]              (the out-projection of the value bias)
+__global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restrict__ o_w, const float* __restrict__ o_b,
+                         const float* __restrict__ bv, double* __restrict__ U) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * D * D) return;
+  if (i >= 2 * D * D) {
+    const int j = i - 2 * D * D;
+    if (j < QD) {
+      double t = (double)o_b[j];
+      for (int k = 0; k < QD; ++k) t += (double)o_w[j * QD + k] * (double)bv[k];
+      U[i] = t;
+    }
+    return;
+  }
   const int h = i / (D * D), n = (i / D) % D, d = i % D;
   double acc = 0.0;
   for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * (double)o_w[j * QD + h * D + d];
@@ -91,12 +101,7 @@ __global__ void k_fold_f(const double* __restrict__ U, const float* __restrict__
     if (c < kdim) {
       for (int d = 0; d < D; ++d) acc += U[(h * D + n) * D + d] * (double)v_w[(int64_t)(h * D + d) * kdim + c];
     } else if (h == 0 && c == kdim) {
-      const float* bv = in_b + 2 * QD;
-      for (int j = 0; j < QD; ++j) {
-        double t = (double)o_b[j];
-        for (int k = 0; k < QD; ++k) t += (double)o_w[j * QD + k] * (double)bv[k];
-        acc += (double)fc1_w[n * 3 * D + j] * t;
-      }
+      for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * U[2 * D * D + j];
     }
   } else if (col < 2 * KP + D) {
     acc = (double)fc1_w[n * 3 * D + QD + (col - 2 * KP)];
@@ -209,13 +214,13 @@ ORCA_API int orca_tgat_pack(int d_e, const float* q_w, const float* k_w, const f
     const int width = L.KBT * 16;
     double* U = nullptr;
     float* F = nullptr;
-    ORCA_HIP_TRY(hipMalloc(&U, sizeof(double) * 2 * D * D));
+    ORCA_HIP_TRY(hipMalloc(&U, sizeof(double) * (2 * D * D + QD)));
     if (hipMalloc(&F, sizeof(float) * D * width) != hipSuccess) {
       (void)hipFree(U);
       orca_set_error("orca_tgat_pack: out of device memory for the fold scratch");
       return ORCA_ENOMEM;
     }
-    k_fold_u<<<(2 * D * D + 255) / 256, 256, 0, s>>>(fc1_w, o_w, U);
+    k_fold_u<<<(2 * D * D + QD + 255) / 256, 256, 0, s>>>(fc1_w, o_w, o_b, in_b + 2 * QD, U);
     k_fold_f<<<(D * width + 255) / 256, 256, 0, s>>>(U, v_w, in_b, o_w, o_b, fc1_w, kdim, L.KP, width, F);
     rc |= orca_pack_matrix(blob + L.pw_t, pw_tiles(D), L.KBT, 0, D, width, F, width, 1, s);
     const hipError_t e1 = hipStreamSynchronize(s);

@@ -101,20 +101,32 @@ __global__ void k_splitk_reduce(const float* __restrict__ part, int S, int M, in
   *c = accumulate ? *c + v : v;
 }
 
-// out[n] (+)= alpha * sum_q X[q*ld + n], n < ncols: one 256-thread block per 64 columns, fixed summation order
+// out[n] (+)= alpha * sum_q X[q*ld + n], n < ncols.  Block (x, y): 64 columns x the y-th slice of the rows; with
+// part != NULL the slices' sums go to part[y][n] and k_colsum_finish adds them in a fixed order (deterministic).
+constexpr int COLSUM_SLICES = 64;
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t Q, int64_t ld, int ncols,
-                                                float* out, float alpha, int accumulate) {
+                                                float* out, float alpha, int accumulate, float* __restrict__ part) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  const int64_t per = (Q + gridDim.y - 1) / gridDim.y;
+  const int64_t q0 = blockIdx.y * per, q1 = q0 + per < Q ? q0 + per : Q;
   float v = 0.f;
   if (c < ncols)
-    for (int64_t q = r; q < Q; q += 4) v += X[q * ld + c];
+    for (int64_t q = q0 + r; q < q1; q += 4) v += X[q * ld + c];
   red[r][threadIdx.x & 63] = v;
   __syncthreads();
   if (r == 0 && c < ncols) {
-    v = alpha * (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
-    out[c] = accumulate ? out[c] + v : v;
+    v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (part) part[(int64_t)blockIdx.y * ncols + c] = v;
+    else out[c] = accumulate ? out[c] + alpha * v : alpha * v;
   }
+}
+__global__ void k_colsum_finish(const float* __restrict__ part, int S, int ncols, float* out, float alpha, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float v = 0.f;
+  for (int z = 0; z < S; ++z) v += part[(int64_t)z * ncols + c];
+  out[c] = accumulate ? out[c] + alpha * v : alpha * v;
 }
 
 }  // namespace
@@ -140,9 +152,13 @@ int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, 
   return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
 }
 
-int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate) {
+int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate,
+                float* part) {
   if (ncols <= 0) return ORCA_OK;
-  k_colsum<<<(unsigned)((ncols + 63) / 64), 256, 0, s>>>(X, Q, ld, ncols, out, alpha, accumulate ? 1 : 0);
+  const bool split = part && Q >= 4 * COLSUM_SLICES;
+  k_colsum<<<dim3((unsigned)((ncols + 63) / 64), split ? COLSUM_SLICES : 1), 256, 0, s>>>(X, Q, ld, ncols, out, alpha,
+                                                                                     accumulate ? 1 : 0, split ? part : nullptr);
+  if (split) k_colsum_finish<<<(unsigned)((ncols + 255) / 256), 256, 0, s>>>(part, COLSUM_SLICES, ncols, out, alpha, accumulate ? 1 : 0);
   return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
 }
 
@@ -493,24 +509,24 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
 
   // ---- backward ----------------------------------------------------------------------------------------
   k_bwd_ln<<<qb, 256, 0, s>>>(y, grad_out, P->ln_w, Q, dy, gx);
-  rc |= colsum(s, gx, Q, D, D, G->ln_w, 1.f, true);
-  rc |= colsum(s, grad_out, Q, D, D, G->ln_b, 1.f, true);
+  rc |= colsum(s, gx, Q, D, D, G->ln_w, 1.f, true, part);
+  rc |= colsum(s, grad_out, Q, D, D, G->ln_b, 1.f, true, part);
   // fc2: dW2 += dy^T h1, db2 += sum dy, dh1 = dy W2
   rc |= sgemm(s, D, D, M, dy, 1, D, h1, D, 1, G->fc2_w, D, 1, nullptr, 1.f, true, false, part, SPLITS);
-  rc |= colsum(s, dy, Q, D, D, G->fc2_b, 1.f, true);
+  rc |= colsum(s, dy, Q, D, D, G->fc2_b, 1.f, true, part);
   rc |= sgemm(s, M, D, D, dy, D, 1, P->fc2_w, D, 1, dh1, D, 1, nullptr, 1.f, false, false);
   k_relu_bwd<<<ew(Q * D), 256, 0, s>>>(dh1, h1, Q * D);
   // fc1: dW1 += dz1^T x1, db1 += sum dz1, dx1 = dz1 W1
   rc |= sgemm(s, D, 3 * D, M, dh1, 1, D, x1, 3 * D, 1, G->fc1_w, 3 * D, 1, nullptr, 1.f, true, false, part, SPLITS);
-  rc |= colsum(s, dh1, Q, D, D, G->fc1_b, 1.f, true);
+  rc |= colsum(s, dh1, Q, D, D, G->fc1_b, 1.f, true, part);
   rc |= sgemm(s, M, 3 * D, D, dh1, D, 1, P->fc1_w, 3 * D, 1, dx1, 3 * D, 1, nullptr, 1.f, false, false);
   k_zero_invalid<<<ew(Q * QD), 256, 0, s>>>(dx1, Q, 3 * D, QD, invalid);     // do = 0 where the output was zeroed
   // out-proj: dWo += do^T ocat, dbo += sum do, docat = do Wo
   rc |= sgemm(s, QD, QD, M, dx1, 1, 3 * D, ocat, QD, 1, G->o_w, QD, 1, nullptr, 1.f, true, false, part, SPLITS);
-  rc |= colsum(s, dx1, Q, 3 * D, QD, G->o_b, 1.f, true);
+  rc |= colsum(s, dx1, Q, 3 * D, QD, G->o_b, 1.f, true, part);
   rc |= sgemm(s, M, QD, QD, dx1, 3 * D, 1, P->o_w, QD, 1, docat, QD, 1, nullptr, 1.f, false, false);
   // value map: dWv_h += docat_h^T xbar_h, dbv += sum docat, dxbar_h = docat_h Wv_h
-  rc |= colsum(s, docat, Q, QD, QD, G->in_b + 2 * QD, 1.f, true);
+  rc |= colsum(s, docat, Q, QD, QD, G->in_b + 2 * QD, 1.f, true, part);
   for (int h = 0; h < 2; ++h) {
     rc |= sgemm(s, D, kdim, M, docat + h * D, 1, QD, xbar + h * kdim, 2 * kdim, 1, G->v_w + (int64_t)h * D * kdim, kdim, 1,
                 nullptr, 1.f, true, false, part, SPLITS);
@@ -528,12 +544,12 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
   }
   // q projection: dWq += dq^T xq, dbq += sum dq, dxq = dq Wq
   rc |= sgemm(s, QD, QD, M, dq, 1, QD, xq, QD, 1, G->q_w, QD, 1, nullptr, 1.f, true, false, part, SPLITS);
-  rc |= colsum(s, dq, Q, QD, QD, G->in_b, 1.f, true);
+  rc |= colsum(s, dq, Q, QD, QD, G->in_b, 1.f, true, part);
   rc |= sgemm(s, M, QD, QD, dq, QD, 1, P->q_w, QD, 1, dxq, QD, 1, nullptr, 1.f, false, false);
   k_bwd_finish<<<ew(Q * D), 256, 0, s>>>(*in, Q, dx1, dxq, d_src, d_src_time, want_t ? tgrad : nullptr);
   if (want_t) {
-    rc |= colsum(s, tgrad, Q, QD, D, d_time_w, 1.f, true);
-    rc |= colsum(s, tgrad + D, Q, QD, D, d_time_b, 1.f, true);
+    rc |= colsum(s, tgrad, Q, QD, D, d_time_w, 1.f, true, part);
+    rc |= colsum(s, tgrad + D, Q, QD, D, d_time_b, 1.f, true, part);
   }
   if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
     orca_set_error("orca_tgat_backward: kernel launch failed");

@@ -615,6 +615,21 @@ class OrcaEngine:
                       self.slot, self._slot_epoch(2 * bs), self.messages, self.msg_ts, self.pending)
     return loss.detach(), grads
 
+  def optimizer(self, lr=1e-4):
+    """torch.optim.Adam over the raw parameter tensors (train.py:180): the optimizer updates self.params in place;
+    step_optimizer() feeds it train_step's gradients and re-packs the kernels' blobs."""
+    self._opt_params = {k: torch.nn.Parameter(v) for k, v in self.params.items() if v.is_floating_point()}
+    self._opt = torch.optim.Adam(self._opt_params.values(), lr=lr)
+    return self._opt
+
+  def step_optimizer(self, grads):
+    """optimizer.step() of train.py:238 with the gradients of train_step, then refresh()."""
+    for k, p in self._opt_params.items():
+      g = grads.get(k)
+      p.grad = None if g is None else g.reshape(p.shape)
+    self._opt.step()
+    self.refresh()
+
   def _dev(self, x, dtype):
     if not isinstance(x, torch.Tensor):
       x = torch.from_numpy(np.ascontiguousarray(x))
