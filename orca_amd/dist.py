@@ -35,3 +35,15 @@ def all_gather_rows(x, Q, per, group=None):
   else:
     dist.all_gather_into_tensor(full, buf, group=group)
   return full[:Q]
+
+
+def all_reduce_sum(x, group=None):
+  """In-place sum over the ranks of a flat device tensor (gradient all-reduce); staged through
+  the host under gloo (the CPU rehearsal backend), RCCL otherwise."""
+  if x.is_cuda and dist.get_backend(group) == "gloo":
+    h = x.cpu()
+    dist.all_reduce(h, group=group)
+    x.copy_(h)
+  else:
+    dist.all_reduce(x, group=group)
+  return x

@@ -599,10 +599,9 @@ class OrcaEngine:
     if "time_encoder.w.bias" in self.params:
       grads["time_encoder.w.bias"] = d_tb
     if self.world > 1:                     # every rank holds the decoder's full gradient already
-      import torch.distributed as dist
       keys = sorted(k for k in grads if not k.startswith("affinity_score."))
       flat = torch.cat([grads[k].reshape(-1) for k in keys])
-      dist.all_reduce(flat, group=self.group)
+      dist_utils.all_reduce_sum(flat, self.group)
       o = 0
       for k in keys:
         m = grads[k].numel()

@@ -20,8 +20,10 @@ def _worker(rank, world, port, q):
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
   dist.init_process_group("gloo", rank=rank, world_size=world)
-  from orca_amd.dist import all_gather_rows, query_slice
+  from orca_amd.dist import all_gather_rows, all_reduce_sum, query_slice
   ok = True
+  g = all_reduce_sum(torch.full((7,), float(rank + 1)), dist.group.WORLD)       # the gradient all-reduce of train_step
+  ok = ok and torch.equal(g, torch.full((7,), world * (world + 1) / 2.0))
   for Q in (0, 1, 2, 5, 64, 4095, 4096):
     full = torch.arange(Q * 3, dtype=torch.float32).reshape(Q, 3) * 0.5
     lo, hi, per = query_slice(Q, rank, world)

@@ -75,7 +75,27 @@ def _worker(rank, world, port, q):
       c = single.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True, plan)
       ok = ok and torch.equal(a, c) and torch.equal(multi.memory, single.memory)
       ok = ok and torch.equal(multi.hist[0], single.hist[0]) and torch.equal(multi.cache_flag[0], single.cache_flag[0])
-    q.put((rank, bool(ok), ""))
+    # training step: every rank back-propagates its slice, parameter gradients are all-reduced; the sums associate
+    # differently from the single-rank step, so gradients are compared at 1e-5 and the state bit for bit
+    multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, device=dev, group=dist.group.WORLD)
+    single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, device=dev, group=None)
+    multi.set_neighbor_finder(csr)
+    single.set_neighbor_finder(csr)
+    msg = ""
+    for b in range(4):
+      s, e = 50000 + b * bs, 50000 + (b + 1) * bs
+      neg = torch.randint(1, N + 1, (bs,), generator=g, device=dev)
+      la, ga = multi.train_step(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e])
+      lc, gc = single.train_step(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e])
+      ok = ok and abs(float(la) - float(lc)) <= 1e-6 and set(ga) == set(gc)
+      for k in gc:
+        scale = max(float(gc[k].abs().max()), 1e-12)
+        err = float((ga[k] - gc[k]).abs().max()) / scale
+        if err > 1e-5:
+          ok, msg = False, f"train_step gradient {k} differs between 2 ranks and 1 rank: rel {err:.2e}"
+      ok = ok and torch.equal(multi.memory, single.memory) and torch.equal(multi.messages, single.messages)
+      ok = ok and torch.equal(multi.hist[0], single.hist[0])
+    q.put((rank, bool(ok), msg))
     dist.barrier()
     dist.destroy_process_group()
   except Exception as ex:   # surface the failure in the parent
