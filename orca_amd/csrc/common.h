@@ -204,9 +204,9 @@ int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, 
                int64_t sbn, float* C, int64_t scm, int64_t scn, const float* bias, float alpha, bool accumulate, bool relu,
                float* part = nullptr, int splits = 1);
 // out[n] (+)= alpha * sum_q X[q*ld + n], n < ncols
-// (part: scratch of at least 64 * ncols floats for the row-sliced, deterministic two-pass form; NULL = one pass)
+// (part: scratch of 64 * ncols floats)
 int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate,
-                float* part = nullptr);
+                float* part);
 
 // generic strided pack kernel launcher (pack.hip)
 int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd, const float* src,

@@ -31,48 +31,76 @@ struct GemmArgs {
   float* part;
 };
 
+// TM = rows of the block tile (64, or 32 when the grid would otherwise leave CUs idle); the tile is TM x 64, the
+// reduction advances 16 at a time and the next slab's global loads are in flight while the current one is multiplied.
+template <int TM>
 __global__ __launch_bounds__(256) void k_sgemm(GemmArgs g) {
-  __shared__ float As[16][68], Bs[16][68];
+  constexpr int IM = TM / 32;          // 16-row MFMA tiles per wave along m
+  constexpr int EA = TM / 16;          // A elements per thread and slab
+  __shared__ float As[16][TM + 4], Bs[16][68];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 64;
   const int kbeg = blockIdx.z * g.kchunk;
   const int kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  f32x4 acc[2][2];
+  const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * 32;
+  f32x4 acc[IM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < IM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+  float ra[EA], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+      const int idx = t + 256 * e;
+      int m, k;
+      if (a_kfast) { m = idx >> 4; k = idx & 15; } else { m = idx % TM; k = idx / TM; }
+      ra[e] = (m0 + m < g.M && k0 + k < kend) ? g.A[(int64_t)(m0 + m) * g.sam + (int64_t)(k0 + k) * g.sak] : 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int idx = t + 256 * e;
-      int m, k;
-      if (a_kfast) { m = idx >> 4; k = idx & 15; } else { m = idx & 63; k = idx >> 6; }
-      As[k][m] = (m0 + m < g.M && k0 + k < kend) ? g.A[(int64_t)(m0 + m) * g.sam + (int64_t)(k0 + k) * g.sak] : 0.f;
       int n, kk;
       if (b_nfast) { n = idx & 63; kk = idx >> 6; } else { kk = idx & 15; n = idx >> 4; }
-      Bs[kk][n] = (n0 + n < g.N && k0 + kk < kend) ? g.B[(int64_t)(k0 + kk) * g.sbk + (int64_t)(n0 + n) * g.sbn] : 0.f;
+      rb[e] = (n0 + n < g.N && k0 + kk < kend) ? g.B[(int64_t)(k0 + kk) * g.sbk + (int64_t)(n0 + n) * g.sbn] : 0.f;
+    }
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+      const int idx = t + 256 * e;
+      int m, k;
+      if (a_kfast) { m = idx >> 4; k = idx & 15; } else { m = idx % TM; k = idx / TM; }
+      As[k][m] = ra[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = t + 256 * e;
+      int n, kk;
+      if (b_nfast) { n = idx & 63; kk = idx >> 6; } else { kk = idx & 15; n = idx >> 4; }
+      Bs[kk][n] = rb[e];
     }
     __syncthreads();
+    if (k0 + 16 < kend) fetch(k0 + 16);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int kr = kk * 4 + (lane >> 4);
-      float a[2], b[2];
+      float a[IM], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[kr][wm + i * 16 + (lane & 15)];
+      for (int i = 0; i < IM; ++i) a[i] = As[kr][wm + i * 16 + (lane & 15)];
 #pragma unroll
       for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wn + j * 16 + (lane & 15)];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < IM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -94,39 +122,57 @@ __global__ void k_splitk_reduce(const float* __restrict__ part, int S, int M, in
                                 float alpha, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)M * N) return;
+  // S <= ORCA_GEMM_SPLITS partials, clamped and masked instead of skipped: no control flow, so every load is in
+  // flight before the first use (a loop pays one memory round trip per iteration); fixed order: deterministic
   float v = 0.f;
-  for (int z = 0; z < S; ++z) v += part[(int64_t)z * M * N + i];   // fixed order: deterministic
+#pragma unroll
+  for (int z = 0; z < ORCA_GEMM_SPLITS; ++z) {
+    const float x = part[(int64_t)(z < S ? z : 0) * M * N + i];
+    v += z < S ? x : 0.f;
+  }
   float* c = C + (i / N) * scm + (i % N) * scn;
   v *= alpha;
   *c = accumulate ? *c + v : v;
 }
 
-// out[n] (+)= alpha * sum_q X[q*ld + n], n < ncols.  Block (x, y): 64 columns x the y-th slice of the rows; with
-// part != NULL the slices' sums go to part[y][n] and k_colsum_finish adds them in a fixed order (deterministic).
-constexpr int COLSUM_SLICES = 64;
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t Q, int64_t ld, int ncols,
-                                                float* out, float alpha, int accumulate, float* __restrict__ part) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-  const int64_t per = (Q + gridDim.y - 1) / gridDim.y;
-  const int64_t q0 = blockIdx.y * per, q1 = q0 + per < Q ? q0 + per : Q;
+// out[n] (+)= alpha * sum_q X[q*ld + n], n < ncols, in two branch-free passes (a loop over rows pays a full memory
+// round trip per iteration): block (x, y) of k_colsum sums the rows q = y + 64 * (r + 16 u) of 64 columns, 16 row
+// lanes r with COLSUM_U loads each in flight, into part[y][n]; k_colsum_finish adds the 64 slices in a fixed order.
+constexpr int COLSUM_SLICES = 64, COLSUM_U = 8;     // one pass covers 64 * 16 * 8 = 8192 rows
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ X, int64_t Q, int64_t ld, int ncols,
+                                                 float* __restrict__ part) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, r = threadIdx.x >> 6;
+  const int cc = c < ncols ? c : 0;
   float v = 0.f;
-  if (c < ncols)
-    for (int64_t q = q0 + r; q < q1; q += 4) v += X[q * ld + c];
-  red[r][threadIdx.x & 63] = v;
+  for (int64_t base = 0; base < Q; base += (int64_t)COLSUM_SLICES * 16 * COLSUM_U) {
+    float x[COLSUM_U];
+#pragma unroll
+    for (int u = 0; u < COLSUM_U; ++u) {
+      const int64_t q = base + blockIdx.y + (int64_t)COLSUM_SLICES * (r + 16 * u);
+      x[u] = X[(q < Q ? q : 0) * ld + cc];
+      if (q >= Q) x[u] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < COLSUM_U; ++u) v += x[u];
+  }
+  red[r][cl] = v;
   __syncthreads();
   if (r == 0 && c < ncols) {
-    v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (part) part[(int64_t)blockIdx.y * ncols + c] = v;
-    else out[c] = accumulate ? out[c] + alpha * v : alpha * v;
+    v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[i][cl];
+    part[(int64_t)blockIdx.y * ncols + c] = v;
   }
 }
-__global__ void k_colsum_finish(const float* __restrict__ part, int S, int ncols, float* out, float alpha, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per column: lane z holds slice z, summed by a fixed butterfly (deterministic)
+__global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ part, int ncols, float* out, float alpha,
+                                                       int accumulate) {
+  static_assert(COLSUM_SLICES == 64, "one slice per lane");
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), z = threadIdx.x & 63;
   if (c >= ncols) return;
-  float v = 0.f;
-  for (int z = 0; z < S; ++z) v += part[(int64_t)z * ncols + c];
-  out[c] = accumulate ? out[c] + alpha * v : alpha * v;
+  const float v = wave_sum(part[(int64_t)z * ncols + c]);
+  if (z == 0) out[c] = accumulate ? out[c] + alpha * v : alpha * v;
 }
 
 }  // namespace
@@ -137,6 +183,7 @@ int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, 
   if (M <= 0 || N <= 0) return ORCA_OK;
   GemmArgs g{M, N, K, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, alpha, accumulate ? 1 : 0, relu ? 1 : 0, K, nullptr};
   unsigned gz = 1;
+  if (splits > ORCA_GEMM_SPLITS) splits = ORCA_GEMM_SPLITS;   // k_splitk_reduce sums at most that many
   if (part && splits > 1 && K > 64) {
     int kc = (K + splits - 1) / splits;
     kc = (kc + 15) / 16 * 16;
@@ -145,7 +192,11 @@ int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, 
     g.part = part;
   }
   if (g.kchunk < 16) g.kchunk = 16;
-  k_sgemm<<<dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), gz), 256, 0, s>>>(g);
+  const unsigned gx = (unsigned)((N + 63) / 64);
+  if ((int64_t)gx * ((M + 63) / 64) * gz < 512)      // under two blocks per CU: halve the tile, double the blocks
+    k_sgemm<32><<<dim3(gx, (unsigned)((M + 31) / 32), gz), 256, 0, s>>>(g);
+  else
+    k_sgemm<64><<<dim3(gx, (unsigned)((M + 63) / 64), gz), 256, 0, s>>>(g);
   if (g.part)
     k_splitk_reduce<<<(unsigned)ceil_div64((int64_t)M * N, 256), 256, 0, s>>>(part, (int)gz, M, N, C, scm, scn, alpha,
                                                                             accumulate ? 1 : 0);
@@ -155,10 +206,8 @@ int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, 
 int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate,
                 float* part) {
   if (ncols <= 0) return ORCA_OK;
-  const bool split = part && Q >= 4 * COLSUM_SLICES;
-  k_colsum<<<dim3((unsigned)((ncols + 63) / 64), split ? COLSUM_SLICES : 1), 256, 0, s>>>(X, Q, ld, ncols, out, alpha,
-                                                                                     accumulate ? 1 : 0, split ? part : nullptr);
-  if (split) k_colsum_finish<<<(unsigned)((ncols + 255) / 256), 256, 0, s>>>(part, COLSUM_SLICES, ncols, out, alpha, accumulate ? 1 : 0);
+  k_colsum<<<dim3((unsigned)((ncols + 63) / 64), COLSUM_SLICES), 1024, 0, s>>>(X, Q, ld, ncols, part);
+  k_colsum_finish<<<(unsigned)((ncols + 3) / 4), 256, 0, s>>>(part, ncols, out, alpha, accumulate ? 1 : 0);
   return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
 }
 
