@@ -36,7 +36,7 @@ constexpr int MAXE = (ORCA_MAX_DE + 63) / 64;   // edge-feature registers per la
 
 struct Blob {   // float offsets inside the packed parameter blob
   int kdim, KP, NTk, KBk, KBT;
-  int64_t pw_q, b_q, pw_kt, pw_t, b_1, pw_2, b_2, ln_w, ln_b, pw_qk, b_qk, qk_flag, total;
+  int64_t pw_q, b_q, pw_kt, pw_t, b_1, pw_2, b_2, ln_w, ln_b, pw_qk, b_qk, qk_flag, scr_u, scr_f, scr_t, scr_a, total;
 };
 
 __host__ __device__ constexpr Blob blob_layout(int d_e) {
@@ -63,6 +63,12 @@ __host__ __device__ constexpr Blob blob_layout(int d_e) {
   L.pw_qk = o; o += 2 * pw_floats(L.kdim + 1, D);
   L.b_qk = o;  o += 2 * L.KP;
   L.qk_flag = o; o += 16;
+  // scratch of the pack routines (the fp64 products of the folds), kept inside the blob so that packing neither
+  // allocates nor synchronises; the kernel never reads it.  Offsets are even: the fp64 parts stay 8-byte aligned.
+  L.scr_u = o; o += 2 * (2 * D * D + QD);                          // double [2*D*D + QD]
+  L.scr_f = o; o += (int64_t)D * L.KBT * 16;                        // float  [D, KBT*16]
+  L.scr_t = o; o += 2 * QD;                                         // double [QD]
+  L.scr_a = o; o += 2 * (int64_t)(L.kdim + 1) * D + ((L.kdim + 1) * D & 1);   // float [2, kdim+1, D]
   L.total = o;
   return L;
 }
@@ -212,21 +218,11 @@ ORCA_API int orca_tgat_pack(int d_e, const float* q_w, const float* k_w, const f
   }
   {   // the folded tail (see the head of this file): multiplied out in fp64 in scratch memory, then packed
     const int width = L.KBT * 16;
-    double* U = nullptr;
-    float* F = nullptr;
-    ORCA_HIP_TRY(hipMalloc(&U, sizeof(double) * (2 * D * D + QD)));
-    if (hipMalloc(&F, sizeof(float) * D * width) != hipSuccess) {
-      (void)hipFree(U);
-      orca_set_error("orca_tgat_pack: out of device memory for the fold scratch");
-      return ORCA_ENOMEM;
-    }
+    double* U = reinterpret_cast<double*>(blob + L.scr_u);
+    float* F = blob + L.scr_f;
     k_fold_u<<<(2 * D * D + QD + 255) / 256, 256, 0, s>>>(fc1_w, o_w, o_b, in_b + 2 * QD, U);
     k_fold_f<<<(D * width + 255) / 256, 256, 0, s>>>(U, v_w, in_b, o_w, o_b, fc1_w, kdim, L.KP, width, F);
     rc |= orca_pack_matrix(blob + L.pw_t, pw_tiles(D), L.KBT, 0, D, width, F, width, 1, s);
-    const hipError_t e1 = hipStreamSynchronize(s);
-    (void)hipFree(U);
-    (void)hipFree(F);
-    ORCA_HIP_TRY(e1);
   }
   rc |= copy_pad(blob + L.b_1, fc1_b, D, 112, s);
   rc |= orca_pack_matrix(blob + L.pw_2, pw_tiles(D), pw_tiles(D), 0, D, D, fc2_w, D, 1, s);
@@ -247,14 +243,8 @@ ORCA_API int orca_tgat_pack_gather(int d_e, const float* q_w, const float* k_w, 
   ORCA_REQUIRE(q_w && k_w && in_b && time_b && blob, "orca_tgat_pack_gather: null pointer");
   Blob L = blob_layout(d_e);
   const int kdim = L.kdim;
-  double* t = nullptr;
-  float* A = nullptr;
-  ORCA_HIP_TRY(hipMalloc(&t, sizeof(double) * QD));
-  if (hipMalloc(&A, sizeof(float) * 2 * (kdim + 1) * D) != hipSuccess) {
-    (void)hipFree(t);
-    orca_set_error("orca_tgat_pack_gather: out of device memory for the fold scratch");
-    return ORCA_ENOMEM;
-  }
+  double* t = reinterpret_cast<double*>(blob + L.scr_t);
+  float* A = blob + L.scr_a;
   int rc = ORCA_OK;
   hipError_t e0 = hipMemsetAsync(blob + L.b_qk, 0, sizeof(float) * 2 * L.KP, s);
   k_fold_qt<<<1, 256, 0, s>>>(q_w, in_b, time_b, t);
@@ -264,11 +254,7 @@ ORCA_API int orca_tgat_pack_gather(int d_e, const float* q_w, const float* k_w, 
                            A + (int64_t)h * (kdim + 1) * D, D, 1, s);
   k_set_flag<<<1, 1, 0, s>>>(blob + L.qk_flag);
   if (hipGetLastError() != hipSuccess) rc = ORCA_EHIP;
-  const hipError_t e1 = hipStreamSynchronize(s);
-  (void)hipFree(t);
-  (void)hipFree(A);
   ORCA_HIP_TRY(e0);
-  ORCA_HIP_TRY(e1);
   if (rc != ORCA_OK) {
     orca_set_error("orca_tgat_pack_gather: kernel launch failed");
     return ORCA_EHIP;
