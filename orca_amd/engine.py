@@ -509,16 +509,17 @@ class OrcaEngine:
   def train_step(self, src, dst, neg, ts, eidx):
     """One training batch of train.py:200-246 up to (not including) optimizer.step(): the train-ordered forward
     of compute_edge_probabilities (tgn_model.py:95-157), the loss BCE(pos, 1) + BCE(neg, 0) (train.py:231-233) and
-    its backward.  Path B (`reuse`, no budget), dropout off.  Returns (loss, grads) with grads keyed like the
-    state_dict (parameters the loss does not reach are absent); the state advances exactly as in
-    compute_temporal_embeddings(train=True).  Gradients flow as upstream: through the attention layers into the
+    its backward.  Path A (exact recursion) and Path B (`reuse`); no budgeted reuse; dropout off.  Returns
+    (loss, grads) with grads keyed like the state_dict (parameters the loss does not reach are absent); the state
+    advances exactly as in compute_temporal_embeddings(train=True).  Gradients flow as upstream: through the
+    attention layers (Path A: also through the inner-layer embeddings of the sampled neighbours) into the
     updated-memory rows of pending ids and from there into the GRU; history rows, stored messages and the memory
     table are detached (history.py:22-24, memory.py:45-47).  An optimizer updates self.params in place; call
     refresh() afterwards.  With several ranks every rank back-propagates its query slice and the parameter
     gradients are all-reduced.  The link decoder (two small dense layers) runs as library
     GEMMs under torch autograd, like its forward in compute_edge_probabilities."""
-    if not (self.reuse and self.budget == 0):
-      raise OrcaError("train_step: only the reuse path (Path B) back-propagates so far")
+    if self.reuse and self.budget != 0:
+      raise OrcaError("train_step: the budgeted reuse path (Path C) does not back-propagate yet")
     if self.csr is None:
       raise OrcaError("OrcaEngine: set_neighbor_finder() first")
     dev = self.device
@@ -534,16 +535,46 @@ class OrcaEngine:
     lo, hi, per = self._slice(Q)
     my_nodes = nodes[lo:hi]
     n = my_nodes.numel()
-    # ---- forward, keeping what the backward re-reads (the tables are not touched before it has run) ----
-    nbr, eid, dt = self._sample(my_nodes, t3[lo:hi])
-    self._overlay_updated_memory(nbr, my_nodes)
-    my32 = my_nodes.to(torch.int32)
-    embs = [self._attend(1, n, nbr, eid, dt, True, self.memory, my32, self.memory, nbr, True)]
-    for layer in range(2, self.L + 1):
-      full = self._all_gather_rows(embs[-1], Q, per)
-      ops.history_push(self.hist[layer - 2], full, nodes, self.slot, self._slot_epoch(Q))
-      embs.append(self._attend(layer, n, nbr, eid, dt, True, embs[-1], None, self.hist[layer - 2], nbr, False))
-    out = self._all_gather_rows(embs[-1], Q, per)
+    K = self.K
+    # ---- forward, keeping what the backward re-reads (the tables are not touched before it has run).  steps:
+    # per attention call (layer, rows, sample, inputs of orca_tgat_inputs that differ between the paths) ----
+    steps = []
+    if self.reuse:                                       # embedding_module.py:154-182
+      nbr, eid, dt = self._sample(my_nodes, t3[lo:hi])
+      self._overlay_updated_memory(nbr, my_nodes)
+      my32 = my_nodes.to(torch.int32)
+      emb = self._attend(1, n, nbr, eid, dt, True, self.memory, my32, self.memory, nbr, True)
+      steps.append((1, n, (nbr, eid, dt), dict(src_table=self.memory, src_idx=my32, nbr_table=self.memory, nbr_idx=nbr),
+                    (my_nodes, nbr.view(-1))))
+      for layer in range(2, self.L + 1):
+        full = self._all_gather_rows(emb, Q, per)
+        ops.history_push(self.hist[layer - 2], full, nodes, self.slot, self._slot_epoch(Q))
+        prev = emb
+        emb = self._attend(layer, n, nbr, eid, dt, True, prev, None, self.hist[layer - 2], nbr, False)
+        steps.append((layer, n, (nbr, eid, dt), dict(src_table=prev, nbr_table=self.hist[layer - 2], nbr_idx=nbr), None))
+    else:                                                # embedding_module.py:116-147
+      f_nodes, f_ts, samples = [my_nodes], [t3[lo:hi]], []
+      for _ in range(self.L):
+        smp = self._sample(f_nodes[-1], f_ts[-1])
+        samples.append(smp)
+        f_nodes.append(torch.cat([f_nodes[-1], smp[0].flatten().to(torch.int64)]))
+        f_ts.append(torch.cat([f_ts[-1], f_ts[-1].repeat_interleave(K)]))
+      self._overlay_updated_memory(None, f_nodes[-1])
+      emb = None
+      for layer in range(1, self.L + 1):
+        lvl = self.L - layer
+        nbr, eid, dt = samples[lvl]
+        m = f_nodes[lvl].numel()
+        if layer == 1:
+          i32 = f_nodes[lvl].to(torch.int32)
+          emb = self._attend(1, m, nbr, eid, dt, True, self.memory, i32, self.memory, nbr, True)
+          steps.append((1, m, samples[lvl], dict(src_table=self.memory, src_idx=i32, nbr_table=self.memory, nbr_idx=nbr),
+                        (f_nodes[lvl], nbr.view(-1))))
+        else:
+          prev = emb
+          emb = self._attend(layer, m, nbr, eid, dt, True, prev, None, prev[m:], None, False)
+          steps.append((layer, m, samples[lvl], dict(src_table=prev, nbr_table=prev[m:]), "cat"))
+    out = self._all_gather_rows(emb, Q, per)
     # ---- link decoder + loss (tgn_model.py:150-157, train.py:231-233) ----
     leaf = out.detach().requires_grad_()
     aff = {k: v.detach().requires_grad_() for k, v in self.aff.items()}
@@ -555,28 +586,31 @@ class OrcaEngine:
     loss = bce(score[:bs], torch.ones(bs, device=dev)) + bce(score[bs:], torch.zeros(bs, device=dev))
     loss.backward()
     grads = {"affinity_score." + k: v.grad for k, v in aff.items()}
-    # ---- backward through the attention layers (this rank's slice) ----
+    # ---- backward through the attention calls, last to first (this rank's slice) ----
     d = leaf.grad[lo:hi].contiguous()
     d_tw = torch.zeros(D, dtype=torch.float32, device=dev)
     d_tb = torch.zeros(D, dtype=torch.float32, device=dev)
-    d_nbr = None
-    for layer in range(self.L, 0, -1):
+    into_memory = None
+    for layer, m, (nbr, eid, dt), tables, sink in reversed(steps):
       p = f"embedding_module.attention_models.{layer - 1}."
       sd = {k[len(p):]: v for k, v in self.params.items() if k.startswith(p)}
-      kw = dict(nbr_ids=nbr, edge_table=self.edge_feats, edge_idx=eid, dt=dt, time_w=self.time_w, time_b=self.time_b,
-                nbr_idx=nbr)
+      kw = dict(nbr_ids=nbr, edge_table=self.edge_feats, edge_idx=eid, dt=dt, time_w=self.time_w, time_b=self.time_b)
+      kw.update(tables)
       if layer == 1:
-        kw.update(src_table=self.memory, src_idx=my32, nbr_table=self.memory, src_overlay=self.overlay,
-                  src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
-      else:
-        kw.update(src_table=embs[layer - 2], nbr_table=self.hist[layer - 2])
-      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, n, self.K, d, want_time_param_grads=True, **kw)
-      for k, v in g.items():
+        kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
+      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, m, K, d, want_time_param_grads=True, **kw)
+      for k, v in g.items():                           # Path A evaluates a layer once per batch, like Path B
         grads[p + k] = v
       d_tw += tw
       d_tb += tb
-      d = d_src
+      if sink == "cat":                                # Path A: the neighbours' rows are embeddings of the level below
+        d = torch.cat([d_src, d_nbr])
+      elif sink is None:                               # Path B inner layer: history rows are detached
+        d = d_src
+      else:
+        into_memory = (sink, d_src, d_nbr)
     # ---- into the updated-memory rows of the pending ids this slice read, then through the GRU ----
+    p = "memory_updater.memory_updater."
     cnt = int(self.count.item())           # distinct pending ids of the overlay work-list (set by the forward)
     if cnt:
       if getattr(self, "_pos", None) is None:
@@ -584,15 +618,14 @@ class OrcaEngine:
       wl = self.worklist[:cnt]
       ops.index_positions(wl, cnt, None, self._pos)
       d_upd = torch.zeros(cnt, D, dtype=torch.float32, device=dev)
-      ops.scatter_add_flagged(d, my_nodes, self.pending, self._pos, d_upd)
-      ops.scatter_add_flagged(d_nbr, nbr.view(-1), self.pending, self._pos, d_upd)
-      p = "memory_updater.memory_updater."
+      (ids_src, ids_nbr), d_src, d_nbr = into_memory
+      ops.scatter_add_flagged(d_src, ids_src, self.pending, self._pos, d_upd)
+      ops.scatter_add_flagged(d_nbr, ids_nbr, self.pending, self._pos, d_upd)
       gg = ops.gru_backward(self.params[p + "weight_ih"], self.params[p + "weight_hh"], self.params[p + "bias_ih"],
                             self.params[p + "bias_hh"], wl, self.messages, self.memory, d_upd)
       for k, v in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), gg[:4]):
         grads[p + k] = v
     else:
-      p = "memory_updater.memory_updater."
       for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
         grads[p + k] = torch.zeros_like(self.params[p + k])
     grads["time_encoder.w.weight"] = d_tw.view(D, 1)

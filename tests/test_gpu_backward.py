@@ -162,21 +162,23 @@ def test_gru_backward(ops, msg_dim, n, gather):
   assert_close_fp32(got[5].cpu().numpy(), hr.grad.numpy(), TOL, "gru d_h")
 
 
-def test_engine_train_step_vs_autograd(ops):
-  """OrcaEngine.train_step (Path B, 2 layers): loss and every parameter gradient against torch autograd of the
-  oracle's pieces composed as tgn_model.py:95-157 composes them, on a warmed-up state (pending messages, pushed
-  history); and the state after the step equals the forward-only step's."""
+@pytest.mark.parametrize("reuse,L", [(True, 2), (False, 2), (False, 1)])
+def test_engine_train_step_vs_autograd(ops, reuse, L):
+  """OrcaEngine.train_step (Path B with 2 layers; Path A, the exact recursion, with 2 layers and with 1 layer = the
+  reference's default configuration): loss and every parameter gradient against torch autograd of the oracle's
+  pieces composed as tgn_model.py:95-157 / embedding_module.py:116-182 compose them, on a warmed-up state (pending
+  messages, pushed history); and the state after the step equals the forward-only step's."""
   from orca_amd import synth
   from orca_amd.engine import OrcaEngine
   N, E, bs, K, d_e = 1500, 30000, 150, 10, 172
   src, dst, eidx, ts = synth.powerlaw_graph(N, E, "cuda:0", seed=5)
   ef = synth.edge_features(E, d_e, "cuda:0")
-  sd = synth.tgn_state_dict(d_e, 2, seed=2)
+  sd = synth.tgn_state_dict(d_e, L, seed=2)
   sd["time_encoder.w.bias"] = torch.from_numpy(np.random.RandomState(1).uniform(-1, 1, 100).astype(np.float32))
   csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
   engs = []
   for _ in range(2):
-    e = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=0, device="cuda:0")
+    e = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=0, device="cuda:0")
     e.set_neighbor_finder(csr)
     engs.append(e)
   A, B = engs
@@ -188,19 +190,22 @@ def test_engine_train_step_vs_autograd(ops):
   for bt in batches[:3]:
     A.compute_temporal_embeddings(*bt, True)
     B.compute_temporal_embeddings(*bt, True)
-  mem, msg, pend, hist = (t.cpu().clone() for t in (A.memory, A.messages, A.pending, A.hist[0]))
+  mem, msg, pend = (t.cpu().clone() for t in (A.memory, A.messages, A.pending))
+  hist = A.hist[0].cpu().clone() if reuse else None
   bt = batches[3]
   loss, grads = A.train_step(*bt)
   B.compute_temporal_embeddings(*bt, True)
   torch.cuda.synchronize()
   for name in ("memory", "last_update", "messages", "msg_ts", "pending"):
     assert_close_fp32(getattr(A, name).float().cpu().numpy(), getattr(B, name).float().cpu().numpy(), 1e-6, "state " + name)
-  assert_close_fp32(A.hist[0].cpu().numpy(), B.hist[0].cpu().numpy(), 1e-6, "state hist")
+  if reuse:
+    assert_close_fp32(A.hist[0].cpu().numpy(), B.hist[0].cpu().numpy(), 1e-6, "state hist")
   # ---- the checker: torch autograd on the CPU ----
   nodes = torch.cat([bt[0], bt[1], bt[2]])
   t3 = torch.cat([bt[3]] * 3)
-  nbr, eid, _, dt = ops.sample_recent(csr, nodes, t3, K)
-  nodes, nbr, eid, dt = nodes.cpu(), nbr.cpu().long(), eid.cpu().long(), dt.cpu()
+  def sample(nd, tt):
+    nbr, eid, _, dt = ops.sample_recent(csr, nd, tt, K)
+    return nbr.cpu().long(), eid.cpu().long(), dt.cpu()
   P = {k: v.clone().float().requires_grad_() for k, v in sd.items()}
   Q = nodes.numel()
   ids = torch.nonzero(pend).flatten()
@@ -209,16 +214,29 @@ def test_engine_train_step_vs_autograd(ops):
   mem2 = mem.clone().index_put((ids,), upd)
   wt, bt_ = P["time_encoder.w.weight"].reshape(-1), P["time_encoder.w.bias"]
   efc = ef.cpu()
-  def layer(i, s_rows, n_rows):
+  def layer(i, s_rows, n_rows, smp):
+    nbr, eid, dt = smp
+    n = s_rows.shape[0]
     p = f"embedding_module.attention_models.{i}."
     return O.attention_forward({k[len(p):]: v for k, v in P.items() if k.startswith(p)}, s_rows,
-                               O.time_encode(torch.zeros(Q, 1), wt, bt_), n_rows, O.time_encode(dt, wt, bt_), efc[eid],
+                               O.time_encode(torch.zeros(n, 1), wt, bt_), n_rows, O.time_encode(dt, wt, bt_), efc[eid],
                                nbr == 0)[0]
-  emb1 = layer(0, mem2[nodes], mem2[nbr.flatten()].view(Q, K, 100))
-  hist2 = hist.clone()
-  hist2[nodes] = emb1.detach()           # single-threaded index_put: the last occurrence wins
-  emb2 = layer(1, emb1, hist2[nbr.flatten()].view(Q, K, 100))
-  se, de, ne = emb2[:bs], emb2[bs:2 * bs], emb2[2 * bs:]
+  s0 = sample(nodes, t3)
+  nc = nodes.cpu()
+  if reuse:
+    emb1 = layer(0, mem2[nc], mem2[s0[0].flatten()].view(Q, K, 100), s0)
+    hist2 = hist.clone()
+    hist2[nc] = emb1.detach()           # single-threaded index_put: the last occurrence wins
+    top = layer(1, emb1, hist2[s0[0].flatten()].view(Q, K, 100), s0)
+  elif L == 1:
+    top = layer(0, mem2[nc], mem2[s0[0].flatten()].view(Q, K, 100), s0)
+  else:
+    nodes1 = torch.cat([nodes, s0[0].flatten().to(DEV)])
+    s1 = sample(nodes1, torch.cat([t3, t3.repeat_interleave(K)]))
+    Q1 = nodes1.numel()
+    emb1 = layer(0, mem2[nodes1.cpu()], mem2[s1[0].flatten()].view(Q1, K, 100), s1)
+    top = layer(1, emb1[:Q], emb1[Q:].view(Q, K, 100), s0)
+  se, de, ne = top[:bs], top[bs:2 * bs], top[2 * bs:]
   x = torch.cat([torch.cat([se, se]), torch.cat([de, ne])], dim=1)
   h = torch.relu(x @ P["affinity_score.fc1.weight"].t() + P["affinity_score.fc1.bias"])
   score = (h @ P["affinity_score.fc2.weight"].t() + P["affinity_score.fc2.bias"]).sigmoid().squeeze(1)
@@ -237,7 +255,7 @@ def test_engine_train_step_vs_autograd(ops):
     assert k in grads, k
     assert_close_fp32(grads[k].cpu().numpy().reshape(r.shape), r, 2e-5, "train_step grad " + k)
     checked += 1
-  assert checked >= 2 * 12 + 4 + 2 + 4
+  assert checked >= L * 12 + 4 + 2 + 4
 
 
 def test_optimizer_step_and_refresh(ops):
