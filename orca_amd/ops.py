@@ -228,12 +228,18 @@ def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, **kw):
   to the mode are None."""
   dev = grad_out.device
   ps = [sd[k].detach().to(device=dev, dtype=torch.float32).contiguous() for k in TGAT_KEYS]
-  gs = [torch.zeros_like(p) for p in ps]
+  gather = kw.get("dt") is not None
+  sizes = [p.numel() for p in ps] + ([D, D] if gather and want_time_param_grads else [])
+  flat = torch.zeros(sum(-(-n // 64) * 64 for n in sizes), dtype=torch.float32, device=dev)   # one fill for all of them
+  views, o = [], 0
+  for n in sizes:
+    views.append(flat[o:o + n])
+    o += -(-n // 64) * 64
+  gs = [v.view(p.shape) for v, p in zip(views, ps)]
   P, G = _lib.TgatParams(), _lib.TgatParams()
   for (name, _), p, g in zip(_lib.TgatParams._fields_, ps, gs):
     setattr(P, name, ptr(p))
     setattr(G, name, ptr(g))
-  gather = kw.get("dt") is not None
   inp, keep = _tgat_inputs(kw, "tgat_backward")
   n = _lib.load().orca_tgat_backward_workspace_floats(int(d_e), int(Q), int(K))
   if n < 0:
@@ -245,8 +251,7 @@ def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, **kw):
   d_st = d_nt = d_tw = d_tb = None
   if gather:
     if want_time_param_grads:
-      d_tw = torch.zeros(D, dtype=torch.float32, device=dev)
-      d_tb = torch.zeros(D, dtype=torch.float32, device=dev)
+      d_tw, d_tb = views[-2], views[-1]
   else:
     d_st = torch.empty((Q, D), dtype=torch.float32, device=dev)
     d_nt = torch.empty((Q * K, D), dtype=torch.float32, device=dev)
