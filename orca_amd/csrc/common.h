@@ -210,4 +210,4 @@ int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols,
 
 // generic strided pack kernel launcher (pack.hip)
 int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd, const float* src,
-                     int64_t sn, int64_t sk, hipStream_t stream);
+                     int64_t sn, int64_t sk, hipStream_t stream, bool tail1 = false);

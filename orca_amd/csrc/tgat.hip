@@ -149,7 +149,7 @@ __global__ void k_fold_qk(const float* __restrict__ q_w, const float* __restrict
 __global__ void k_set_flag(float* p) { *p = 1.0f; }
 
 __global__ void k_pack(float* __restrict__ dst, int KB, int n0, int n_cnt, int Kd, const float* __restrict__ src,
-                       int64_t sn, int64_t sk) {
+                       int64_t sn, int64_t sk, int tail1) {
   // one thread per destination float of the n-tiles that intersect [n0, n0+n_cnt)
   int nt0 = n0 / 16;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -162,6 +162,7 @@ __global__ void k_pack(float* __restrict__ dst, int KB, int n0, int n_cnt, int K
   int nt = nt0 + (int)(blk / KB);
   int n = nt * 16 + (lane & 15);
   int k = kb * 16 + 4 * (lane >> 4) + s;
+  if (tail1 && kb == KB - 1) k = s == 0 ? kb * 16 + (lane >> 4) : Kd;   // WaveGemm TAIL1: four columns, all in step 0
   if (n < n0 || n >= n0 + n_cnt) return;
   float v = (k < Kd) ? src[(int64_t)(n - n0) * sn + (int64_t)k * sk] : 0.0f;
   dst[((int64_t)nt * KB + kb) * 256 + lane * 4 + s] = v;
@@ -175,11 +176,11 @@ __global__ void k_copy_pad(float* dst, const float* src, int n, int n_pad) {
 }  // namespace
 
 int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd, const float* src, int64_t sn,
-                     int64_t sk, hipStream_t stream) {
+                     int64_t sk, hipStream_t stream, bool tail1) {
   (void)NT_total;
   int nt_cnt = (n0 + n_cnt + 15) / 16 - n0 / 16;
   int64_t total = (int64_t)nt_cnt * KB * 256;
-  k_pack<<<(unsigned)ceil_div64(total, 256), 256, 0, stream>>>(dst, KB, n0, n_cnt, Kd, src, sn, sk);
+  k_pack<<<(unsigned)ceil_div64(total, 256), 256, 0, stream>>>(dst, KB, n0, n_cnt, Kd, src, sn, sk, tail1 ? 1 : 0);
   return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
 }
 
@@ -212,9 +213,9 @@ ORCA_API int orca_tgat_pack(int d_e, const float* q_w, const float* k_w, const f
   for (int h = 0; h < 2; ++h) {
     // folded key map of head h: out n = key column c (< kdim), reduction k = d (< 100):  Wk[h*100+d][c]
     float* kt = blob + L.pw_kt + (int64_t)h * pw_floats(kdim + 1, D);
-    rc |= orca_pack_matrix(kt, L.NTk, KB100, 0, kdim, D, k_w + (int64_t)h * D * kdim, 1, kdim, s);
+    rc |= orca_pack_matrix(kt, L.NTk, KB100, 0, kdim, D, k_w + (int64_t)h * D * kdim, 1, kdim, s, true);
     // extra output column n = kdim: bk[h*100+d]  (gives the (0.1 q_h).bk_h score offset)
-    rc |= orca_pack_matrix(kt, L.NTk, KB100, kdim, 1, D, in_b + QD + h * D, 0, 1, s);
+    rc |= orca_pack_matrix(kt, L.NTk, KB100, kdim, 1, D, in_b + QD + h * D, 0, 1, s, true);
   }
   {   // the folded tail (see the head of this file): multiplied out in fp64 in scratch memory, then packed
     const int width = L.KBT * 16;
@@ -251,7 +252,7 @@ ORCA_API int orca_tgat_pack_gather(int d_e, const float* q_w, const float* k_w, 
   k_fold_qk<<<(2 * (kdim + 1) * (D + 1) + 255) / 256, 256, 0, s>>>(q_w, k_w, in_b, t, kdim, L.KP, A, blob + L.b_qk);
   for (int h = 0; h < 2; ++h)
     rc |= orca_pack_matrix(blob + L.pw_qk + (int64_t)h * pw_floats(kdim + 1, D), L.NTk, pw_tiles(D), 0, kdim + 1, D,
-                           A + (int64_t)h * (kdim + 1) * D, D, 1, s);
+                           A + (int64_t)h * (kdim + 1) * D, D, 1, s, true);
   k_set_flag<<<1, 1, 0, s>>>(blob + L.qk_flag);
   if (hipGetLastError() != hipSuccess) rc = ORCA_EHIP;
   ORCA_HIP_TRY(e0);
@@ -280,7 +281,10 @@ __device__ __forceinline__ void for_acc(const f32x4& acc, int tile, int lane, F 
 // s_waitcnt placement gives up at control flow -- with run-time trip counts every step ended in vmcnt(0),
 // i.e. no prefetch at all); KBC = 0 is the generic run-time fallback.  A job is either active with all NT
 // tiles live (ALL) or carries a run-time live count nt.
-template <int NT, int G, int KBC, bool ALL>
+// TAIL1: the reduction length is 16*(KBC-1) + 4 (100 here): the last k-block then holds its four columns in step 0
+// of the four lane groups (k = 16*(KBC-1) + (lane >> 4), see k_pack) and costs one MFMA per tile instead of four;
+// the A operand of that step is read through a_tail.
+template <int NT, int G, int KBC, bool ALL, bool TAIL1 = false>
 struct WaveGemm {
   const f32x4* bp[NT];
   f32x4 ring[G][NT];
@@ -314,7 +318,7 @@ struct WaveGemm {
 
   // a_row: LDS pointer to this lane's A row (row l&15) already offset by 4*(l>>4) floats.
   template <typename F>
-  __device__ __forceinline__ void run(const float* a_row, int lane, F epilogue) {
+  __device__ __forceinline__ void run(const float* a_row, int lane, F epilogue, const float* a_tail = nullptr) {
     if (nt == 0) return;
     f32x4 acc[NT];
 #pragma unroll
@@ -332,6 +336,14 @@ struct WaveGemm {
           for (int t = 0; t < NT; ++t) ring[g][t] = bp[t][(kb + G) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the refill ahead of the MFMAs (the scheduler sinks it otherwise)
+        if constexpr (TAIL1) {
+          if (kb == KBC - 1) {
+            const float at = *a_tail;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, b[t][0], acc[t], 0, 0, 0);
+            continue;
+          }
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -532,7 +544,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   constexpr bool qk = QK;
   const int h2 = wave & 1;                        // P2: wave (h2, slot = wave >> 1)
   WaveGemm<1, 7, 13, true> g1;
-  WaveGemm<3, 3, 7, FOLD_ALL> g2;
+  WaveGemm<3, 3, 7, FOLD_ALL, true> g2;      // reduction length 100 = 6 k-blocks + 4 columns
   if constexpr (qk)
     g2.prefetch(blob4 + (L.pw_qk + (int64_t)h2 * pw_floats(kdim + 1, D)) / 4, NT100, wave >> 1, NW / 2, L.NTk, lane,
                 blob + L.b_qk + h2 * KPS);
@@ -640,8 +652,8 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   //      (the columns 100..111 of bufQ hold finite time values that meet zero weights).
   {
     float* dstT = bufT + h2 * KPS;
-    g2.run((qk ? bufQ : bufP + h2 * D) + a_off * ASTR + a_k, lane,
-           [&](int m, int n, float v) { dstT[m * RS + n] = v; });
+    const float* a2 = (qk ? bufQ : bufP + h2 * D) + a_off * ASTR;
+    g2.run(a2 + a_k, lane, [&](int m, int n, float v) { dstT[m * RS + n] = v; }, a2 + 96 + (lane >> 4));
   }
   __syncthreads();
   stamp();
