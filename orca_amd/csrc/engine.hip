@@ -23,6 +23,7 @@ struct orca_engine {
   int train;
   bool overlay_covers_batch;   // train order and the overlay holds every pending positive of the batch (the whole
                                // batch on this rank, or an overlay-complete state)
+  bool sliced;                 // this rank embeds a proper slice of the batch (several ranks)
   bool winners_valid;          // begin() elected the last occurrences of the push / message-store id lists
   bool persist_done;           // the memory persist of the batch was fused into attention layer 1
   int pushed_layer;            // output of this layer is already in its history table (fused push), 0 = none
@@ -55,7 +56,9 @@ constexpr int ELECT_SLOTS = 8192;          // 2 x 32 KiB of LDS
 constexpr int64_t ELECT_MAX = 6144;        // ids per table (load factor <= 0.75)
 constexpr int ELECT_PARTS_MAX = 8;         // lists up to 49,152 ids
 
-__device__ __forceinline__ int elect_part(int64_t id, int parts) { return (int)((((uint32_t)id * 0x85EBCA6Bu) >> 16) % (uint32_t)parts); }
+// part of an id: a 16-bit hash scaled to [0, parts) -- every part scans the whole list, so this runs once per id and
+// part and must not cost an integer division
+__device__ __forceinline__ int elect_part(int64_t id, int parts) { return (int)(((((uint32_t)id * 0x85EBCA6Bu) >> 16) * (uint32_t)parts) >> 16); }
 
 // An id that finds its table full (only possible when far more distinct ids hash to one part than the sizing
 // assumes) is elected by scanning the rest of the list for a later occurrence: slow, but a full table stays
@@ -136,7 +139,7 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
   }
 }
 
-// First kernel of a step.  Query block b (block index ne + b), wave w: root query i = 16 b + w of [src;dst;neg] x [t;t;t]
+// First kernel of a step.  Query block b < nbs (block index ne + b), wave w: root query i = lo + 16 b + w of [src;dst;neg] x [t;t;t]
 // (tgn_model.py:99-102) is written to nodes / qts / nodes32 and, when i lies in this rank's slice [lo, hi), its K
 // most recent neighbours are sampled into row i - lo of the sampler outputs (embedding_module.py:157), with the
 // claim pass of the overlay work-list in train order.
@@ -146,7 +149,7 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
 __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
-    int32_t* __restrict__ nodes32, int ne, int parts, int64_t n_nodes, uint8_t* __restrict__ win_push,
+    int32_t* __restrict__ nodes32, int ne, int nbs, int parts, int64_t n_nodes, uint8_t* __restrict__ win_push,
     uint8_t* __restrict__ win_msg, int32_t* __restrict__ msg_list, int32_t* __restrict__ msg_count,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ c_nbr, const int32_t* __restrict__ c_eid,
     const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int K, int32_t* __restrict__ o_nbr,
@@ -164,8 +167,17 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)((int)blockIdx.x - ne) * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
-  if (i >= 3 * bs) return;
+  const int64_t bq = (int64_t)((int)blockIdx.x - ne);
+  if (bq >= nbs) {   // query rows of the roots outside this rank's slice: one per thread (a wave each would be 8x the
+    const int64_t i = (bq - nbs) * ELECT_THREADS + threadIdx.x;          // workgroups at 8 ranks, for three stores)
+    if (i >= 3 * bs || (i >= lo && i < hi)) return;
+    nodes[i] = root(i);
+    nodes32[i] = (int32_t)root(i);
+    qts[i] = ts[i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs)];
+    return;
+  }
+  const int64_t i = lo + bq * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
+  if (i >= hi) return;
   const int64_t e = i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs);
   const int64_t v = root(i);                                            // tgn_model.py:99
   const double t = ts[e];                                               // :102
@@ -174,7 +186,6 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     nodes32[i] = (int32_t)v;
     qts[i] = t;
   }
-  if (i < lo || i >= hi) return;
   sample_recent_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, i - lo, hi - lo, K, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
 }
 
@@ -298,6 +309,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   e->bs = bs; e->Q = Q; e->train = train;
   e->timed_step = e->profile > 0 && (e->step++ % e->profile) == 0;
   e->overlay_covers_batch = train && lo == 0 && hi == Q;
+  e->sliced = !(lo == 0 && hi == Q);
   // the ids of a list are spread over `parts` tables; past a third of a table's capacity two tables already pay
   // (the workgroups run side by side and each sees half the LDS atomics)
   const int parts = Q <= ELECT_MAX / 3 ? 1 : (Q <= ELECT_MAX ? 2 : (int)ceil_div64(Q, ELECT_MAX));
@@ -346,10 +358,11 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     const int64_t* indptr; const int32_t *c_nbr, *c_eid; const double* c_ts;
     if ((rc = orca_csr_arrays(d.csr, &n_rows, nullptr, &indptr, &c_nbr, &c_eid, &c_ts)) != ORCA_OK) return rc;
     const orca_claim claim = (lazy && n > 0) ? orca_claim{d.pending, d.slot, claim_epoch, d.n_nodes, d.count} : orca_claim{};
-    const int nb = (int)ceil_div64(Q, ELECT_THREADS / 64);
+    const int nbs = (int)ceil_div64(n, ELECT_THREADS / 64);                   // a wave per root of the slice
+    const int nb = nbs + (n < Q ? (int)ceil_div64(Q, ELECT_THREADS) : 0);     // a thread per root outside it
     Timed t(e, ORCA_PROF_SAMPLE, stream);
     ORCA_LAUNCH_TIMED(k_begin_queries, (unsigned)(nb + (e->winners_valid ? 2 * parts : 0)), ELECT_THREADS, 0, stream, src, dst, neg, ts,
-                      bs, d.nodes, d.qts, d.nodes32, e->winners_valid ? 2 * parts : 0, parts, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr,
+                      bs, d.nodes, d.qts, d.nodes32, e->winners_valid ? 2 * parts : 0, nbs, parts, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr,
                       my_list, my_count,
                       indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, K, d.nbr, d.eid, d.et, d.dt, claim);
     ORCA_LAUNCH_CHECK();
@@ -490,6 +503,13 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
     if (e->list_written && !e->upd_rows && e->overlay_covers_batch) {
       e->have_list = true;
       e->list_bound = 2 * bs < d.q_max ? 2 * bs : d.q_max;
+      // A sliced step calls finish() while the ranks' layer-1 rows are still being exchanged: the GRU over the
+      // ids just stored runs now, inside that wait, instead of at the head of the next step (nothing that
+      // follows in this step reads the overlay).  One rank keeps it in begin(): the order on the device is the same.
+      if (e->sliced && e->overlay_complete) {
+        Timed t(e, ORCA_PROF_GRU, (hipStream_t)stream_);
+        if ((rc = orca_engine_drain(e, stream_)) != ORCA_OK) return rc;
+      }
     } else {
       e->overlay_complete = false;
     }
