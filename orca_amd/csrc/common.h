@@ -155,6 +155,24 @@ __device__ __forceinline__ float orca_cosf(float x) {
   p = __builtin_fmaf(u, p, 1.0f);
   return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p) ^ sign);
 }
+// sin(x) with the same fp64 reduction x = n·π + r (the backward pass of the time encoder: d cos = -sin); sin(r),
+// |r| <= π/2, is the odd Taylor polynomial through r^13 in fp32 (truncation < 7e-10, rounding ~1e-7 absolute).
+__device__ __forceinline__ float orca_sinf(float x) {
+  const double xd = (double)x;
+  const double n = __builtin_rint(xd * 0.31830988618379069122);
+  double r = __builtin_fma(-n, 3.14159265358979311600e+00, xd);
+  r = __builtin_fma(-n, 1.22464679914735320717e-16, r);
+  const unsigned sign = (unsigned)(int)n << 31;
+  const float rf = (float)r;
+  const float u = rf * rf;
+  float p = __builtin_fmaf(u, 1.6059043837e-10f, -2.5052108385e-08f);
+  p = __builtin_fmaf(u, p, 2.7557319224e-06f);
+  p = __builtin_fmaf(u, p, -1.9841269841e-04f);
+  p = __builtin_fmaf(u, p, 8.3333333333e-03f);
+  p = __builtin_fmaf(u, p, -1.6666666667e-01f);
+  p = __builtin_fmaf(u * rf, p, rf);
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p) ^ sign);
+}
 // t·ω + φ of nn.Linear(1, D) (time_encoding.py:26) with TWO roundings: the product, then the bias add.  With
 // φ = 0 (the reference's initial value and every fixture it holds) the rounding order cannot matter; with a
 // trained φ != 0 torch's own CPU linear rounds once or twice depending on the MKL code path of the host (measured:

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void k_bwd_attn_bwd(orca_tgat_inputs in, int64
         if (in.dt) {
           if (tgrad) {
             const float arg = orca_time_arg(dt, in.time_w[ct], in.time_b[ct]);
-            const float dth = -(float)sin((double)arg) * dx;
+            const float dth = -orca_sinf(arg) * dx;
             tw[i] += dt * dth;
             tb[i] += dth;
           }
@@ -471,7 +471,7 @@ __global__ void k_bwd_finish(orca_tgat_inputs in, int64_t Q, const float* __rest
   if (d_src) d_src[i] = dx1[q * 3 * D + QD + c] + dxq[q * QD + c];
   const float dst = dxq[q * QD + D + c];
   if (in.dt) {
-    if (tgrad) tgrad[q * QD + D + c] += -(float)sin((double)orca_time_arg(0.0f, in.time_w[c], in.time_b[c])) * dst;
+    if (tgrad) tgrad[q * QD + D + c] += -orca_sinf(orca_time_arg(0.0f, in.time_w[c], in.time_b[c])) * dst;
   } else if (d_src_time) {
     d_src_time[i] = dst;
   }
