@@ -162,15 +162,16 @@ def test_gru_backward(ops, msg_dim, n, gather):
   assert_close_fp32(got[5].cpu().numpy(), hr.grad.numpy(), TOL, "gru d_h")
 
 
-@pytest.mark.parametrize("reuse,L", [(True, 2), (False, 2), (False, 1)])
-def test_engine_train_step_vs_autograd(ops, reuse, L):
+@pytest.mark.parametrize("reuse,L,bs", [(True, 2, 150), (False, 2, 150), (False, 1, 150), (True, 2, 1365)])
+def test_engine_train_step_vs_autograd(ops, reuse, L, bs):
   """OrcaEngine.train_step (Path B with 2 layers; Path A, the exact recursion, with 2 layers and with 1 layer = the
   reference's default configuration): loss and every parameter gradient against torch autograd of the oracle's
   pieces composed as tgn_model.py:95-157 / embedding_module.py:116-182 compose them, on a warmed-up state (pending
-  messages, pushed history); and the state after the step equals the forward-only step's."""
+  messages, pushed history); and the state after the step equals the forward-only step's.  bs = 1365 is the bench's
+  batch shape (4095 roots: every split-K and tile variant of the backward GEMM is in play)."""
   from orca_amd import synth
   from orca_amd.engine import OrcaEngine
-  N, E, bs, K, d_e = 1500, 30000, 150, 10, 172
+  N, E, K, d_e = 1500, 30000, 10, 172
   src, dst, eidx, ts = synth.powerlaw_graph(N, E, "cuda:0", seed=5)
   ef = synth.edge_features(E, d_e, "cuda:0")
   sd = synth.tgn_state_dict(d_e, L, seed=2)
