@@ -252,3 +252,39 @@ def test_native_driver_rejects_bad_calls(golden):
   eng.reset_state()
   again = eng.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True)
   assert torch.equal(ok, again)
+
+
+def test_native_driver_long_run_vs_dispatched_path():
+  """300 consecutive train-ordered batches of the bench's shape through the native driver (eager overlay lists
+  double-buffered across steps, fused persist / push / store) against the Python-dispatched Path B on the same
+  inputs (per-batch work-lists, one kernel per operation): a drift or a hazard between steps would show in the
+  state tables.  Checked every 100 batches; an eval-ordered batch is mixed in every 50."""
+  from orca_amd import ops, synth
+  from orca_amd.engine import OrcaEngine
+  N, E, bs, K, d_e = 50_000, 2_000_000, 1365, 10, 172
+  src, dst, eidx, ts = synth.powerlaw_graph(N, E, "cuda:0", seed=8)
+  ef = synth.edge_features(E, d_e, "cuda:0")
+  sd = synth.tgn_state_dict(d_e, 2, seed=4)
+  csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
+  native = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=0, device="cuda:0")
+  plain = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=0, device="cuda:0")
+  plain.prof = {}                     # forces the Python-dispatched path
+  for e in (native, plain):
+    e.set_neighbor_finder(csr)
+  g = torch.Generator(device="cuda:0")
+  g.manual_seed(3)
+  start = int(0.6 * E)
+  for b in range(300):
+    s = start + b * bs
+    neg = torch.randint(1, N + 1, (bs,), generator=g, device="cuda:0")
+    train = b % 50 != 49
+    a = native.compute_temporal_embeddings(src[s:s + bs], dst[s:s + bs], neg, ts[s:s + bs], eidx[s:s + bs], train)
+    c = plain.compute_temporal_embeddings(src[s:s + bs], dst[s:s + bs], neg, ts[s:s + bs], eidx[s:s + bs], train)
+    plain.prof = {}                   # drop the recorded events
+    if b % 100 == 99 or b == 299:
+      assert_close_fp32(a.cpu().numpy(), c.cpu().numpy(), 1e-5, f"batch {b} embeddings")
+      assert_close_fp32(native.memory.cpu().numpy(), plain.memory.cpu().numpy(), 1e-5, f"batch {b} memory")
+      assert_close_fp32(native.hist[0].cpu().numpy(), plain.hist[0].cpu().numpy(), 1e-5, f"batch {b} history")
+      assert_close_fp32(native.messages.cpu().numpy(), plain.messages.cpu().numpy(), 1e-5, f"batch {b} messages")
+      assert torch.equal(native.pending, plain.pending) and torch.equal(native.last_update, plain.last_update)
+      assert torch.equal(native.msg_ts, plain.msg_ts)
