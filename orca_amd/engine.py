@@ -514,7 +514,8 @@ class OrcaEngine:
     advances exactly as in compute_temporal_embeddings(train=True).  Gradients flow as upstream: through the
     attention layers (Path A: also through the inner-layer embeddings of the sampled neighbours) into the
     updated-memory rows of pending ids and from there into the GRU; history rows, stored messages and the memory
-    table are detached (history.py:22-24, memory.py:45-47).  An optimizer updates self.params in place; call
+    table are detached (history.py:32-40: push / pull run under no_grad in the default configuration, without
+    train.py:43's --gradient switch, which is not built; memory.py:45-47).  An optimizer updates self.params in place; call
     refresh() afterwards.  With several ranks every rank back-propagates its query slice and the parameter
     gradients are all-reduced.  The link decoder (two small dense layers) runs as library
     GEMMs under torch autograd, like its forward in compute_edge_probabilities."""
