@@ -6,8 +6,9 @@ Follows, stage by stage, model/tgn_model.py:95-147 (compute_temporal_embeddings)
   Path B  modules/embedding_module.py:154-182   Orca-P push-and-pull      (reuse=True, budget=0)
   Path C  modules/embedding_module.py:215-285   Orca-R budgeted reuse     (reuse=True, budget>0)
 and the memory / message steps of modules/memory_updater.py:25-78, modules/memory.py:25-28,
-model/tgn_model.py:172-191.  Forward only (the reference's no_grad persist/eval path and the
-forward half of a train step); dropout is off (module.eval()).
+model/tgn_model.py:172-191.  compute_temporal_embeddings / compute_edge_probabilities are the forward (the
+reference's no_grad persist / eval path and the forward half of a train step); train_step adds the loss and the
+backward pass of train.py:225-237 for Paths A and B.  Dropout is off (module.eval()).
 
 Multi-GPU (not in the reference): state tables are replicated, each rank embeds a
 contiguous slice of the batch's (node, t) queries; the rows that later stages read across ranks
