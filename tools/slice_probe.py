@@ -10,7 +10,8 @@ from orca_amd.engine import OrcaEngine
 
 dev = torch.device("cuda:0")
 N, E, bs, K, d_e = 1_000_000, 50_000_000, 1365, 10, 172
-src, dst, eidx, ts = synth.powerlaw_graph(N, E, dev)
+import os
+src, dst, eidx, ts = synth.powerlaw_graph(N, E, dev, alpha=float(os.environ.get('SLICE_ALPHA', '1.2')))   # 0 = no hubs
 csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
 ef = synth.edge_features(E, d_e, dev)
 sd = synth.tgn_state_dict(d_e, 2)
