@@ -181,8 +181,8 @@ def main():
       eng.compute_temporal_embeddings(*b, train=True, gather_output=gather)
     if not args.no_kernel_events:
       eng.profile_kernels(True, args.event_stride)       # native driver (Path B)
-      if args.no_reuse:
-        eng.prof = {}                 # Python-dispatched path (Path A)
+      if args.no_reuse and args.layers > 1:
+        eng.prof = {}                 # Python-dispatched path (Path A with recursion; one layer runs natively)
     barrier()
     t0 = time.perf_counter()
     for b in batches[args.warmup:args.warmup + args.steps]:

@@ -472,8 +472,10 @@ class OrcaEngine:
     elif not self.test_mode:
       self._flush_all_pending()
       self.test_mode = True
-    if self.reuse and self.budget == 0 and self.prof is None:
-      # Path B end to end in the native driver (embedding, memory persist, message store)
+    one_layer_exact = not self.reuse and self.L == 1    # Path A with one layer has no recursion: the same step as
+    if ((self.reuse and self.budget == 0) or one_layer_exact) and self.prof is None:    # Path B's first layer
+      # end to end in the native driver (embedding, memory persist, message store): Path B, and the reference's
+      # default configuration (n_layer = 1, no reuse: BASELINE config 1)
       return self._step_reuse_native(src, dst, neg, ts, eidx, train, gather_output)
     self._set_overlay_complete(False)      # the Python-dispatched paths store messages without overlay rows
     nodes = torch.cat([src, dst, neg])
