@@ -22,7 +22,10 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
   hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-  headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "orca_hip.h")]
+  # every header is a dependency of every object: the sampler and the split GRU live in headers
+  inc = os.path.join(HERE, "..", "include")
+  headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+            sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
   objs, jobs = [], []
   os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
   for s in SOURCES:

@@ -122,6 +122,10 @@ class OrcaEngine:
     self.gru_blob = ops.gru_pack(sd[p + "weight_ih"], sd[p + "weight_hh"], sd[p + "bias_ih"], sd[p + "bias_hh"], dev,
                                  blob=self.gru_blob)
     self.aff = {k[len("affinity_score."):]: v for k, v in self.params.items() if k.startswith("affinity_score.")}
+    if not first and hasattr(self, "_overlay_complete"):
+      # overlay rows computed with the previous GRU weights are stale: the reference recomputes
+      # get_updated_memory with the current weights on every batch (memory_updater.py:56-78)
+      self._invalidate_overlay()
 
   def refresh(self):
     """Re-packs the kernels' parameter blobs from self.params (after an optimizer step changed them in place)."""
@@ -141,6 +145,11 @@ class OrcaEngine:
       t.zero_()
     self.test_mode = False
     self._set_overlay_complete(True)       # no pending ids
+
+  def _invalidate_overlay(self):
+    """the overlay rows no longer match GRU(messages, memory) of the pending ids (weights changed, tables restored,
+    messages stored outside the native driver)"""
+    self._set_overlay_complete(False)
 
   def _set_overlay_complete(self, flag):
     self._overlay_complete = bool(flag)
