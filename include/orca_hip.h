@@ -251,6 +251,13 @@ int orca_set_flags(uint8_t* flags, const int64_t* ids64, const int32_t* ids32, i
  * `epoch` a value greater than any used before on it. */
 int orca_segment_last(const int64_t* ids, int64_t M, int64_t* slot, int64_t epoch, int64_t n_nodes,
                       uint8_t* winner, void* stream);
+/* orca_segment_last for callers that cannot allocate or own a scratch table (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference.  The election table is
+ * a file-scope device array of ORCA_STATIC_IDS_MAX int64 (8 MiB per GPU, held until the process ends); the call
+ * allocates nothing and rejects n_nodes or M beyond that maximum with ORCA_EINVAL.  Every call on a GPU shares
+ * that GPU's table: calls that overlap on one GPU (two streams, two threads) race -- serialise them. */
+#define ORCA_STATIC_IDS_MAX (1 << 20)
+int orca_segment_last_static(const int64_t* ids, int64_t M, int64_t n_nodes, uint8_t* winner, void* stream);
 /* modules/message_aggregator.py:61-81: per distinct id the mean of its rows (arrival order) and the
  * timestamp of its last row, written at the id's LAST position p (winner[p] = 1). */
 int orca_segment_mean(const int64_t* ids, int64_t M, int64_t D, const float* msgs, const float* ts,

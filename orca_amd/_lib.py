@@ -84,6 +84,7 @@ SIGNATURES = {
     "orca_fill_u8": (i32, [vp, i64, u8, vp]),
     "orca_set_flags": (i32, [vp, vp, vp, i64, vp, u8, vp]),
     "orca_segment_last": (i32, [vp, i64, vp, i64, i64, vp, vp]),
+    "orca_segment_last_static": (i32, [vp, i64, i64, vp, vp]),
     "orca_segment_mean": (i32, [vp, i64, i64, vp, vp, vp, i64, i64, vp, vp, vp]),
     "orca_message_store": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, vp]),
     "orca_history_push": (i32, [vp, vp, vp, i64, vp, i64, i64, vp]),

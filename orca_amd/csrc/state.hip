@@ -288,6 +288,49 @@ ORCA_API int orca_segment_last(const int64_t* ids, int64_t M, int64_t* slot, int
   return ORCA_OK;
 }
 
+// ---- the entry point that allocates nothing (include/orca_hip.h: orca_segment_last_static) ---------------------
+// Its election table is this file-scope device array instead of a caller-owned `slot`: every GPU the library runs
+// on holds its own 8 MiB copy at its own address until the process ends.  In host code the name `scratch` is only a
+// stand-in for the symbol: the address kernels and memsets get is the one hipGetSymbolAddress returned for the
+// current device.
+static __device__ __align__(256) int64_t scratch[ORCA_STATIC_IDS_MAX];
+namespace {
+struct StaticSlot {
+  int64_t* ptr = nullptr;    // device address of `scratch` on this GPU
+  int64_t epoch = 1;         // next unused election value: the array keeps the last call's contents, and values
+};                           // below the epoch are stale by construction (a zero-initialised array starts below 1)
+StaticSlot static_slot[64];
+}  // namespace
+
+ORCA_API int orca_segment_last_static(const int64_t* ids, int64_t M, int64_t n_nodes, uint8_t* winner, void* stream) {
+  ORCA_REQUIRE(M >= 0 && n_nodes > 0 && (M == 0 || (ids && winner)), "orca_segment_last_static: bad arguments");
+  ORCA_REQUIRE(n_nodes <= ORCA_STATIC_IDS_MAX && M <= ORCA_STATIC_IDS_MAX,
+               "orca_segment_last_static: n_nodes=%lld / M=%lld exceed the static table of %lld ids "
+               "(use orca_segment_last with a caller-owned slot table)", (long long)n_nodes, (long long)M,
+               (long long)ORCA_STATIC_IDS_MAX);
+  int dev = 0;
+  ORCA_HIP_TRY(hipGetDevice(&dev));
+  ORCA_REQUIRE(dev >= 0 && dev < 64, "orca_segment_last_static: device %d out of range", dev);
+  StaticSlot& st = static_slot[dev];
+  if (!st.ptr) {     // once per device, with that device current
+    int64_t* p = nullptr;
+    ORCA_HIP_TRY(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+    ORCA_REQUIRE(p != nullptr, "orca_segment_last_static: no device address for the static table");
+    st.ptr = p;
+  }
+  if (M == 0) return ORCA_OK;
+  if (st.epoch > INT64_MAX - 2 * ORCA_STATIC_IDS_MAX) {   // (not reachable in practice) start over from a cleared table
+    ORCA_HIP_TRY(hipMemsetAsync(st.ptr, 0, sizeof(int64_t) * ORCA_STATIC_IDS_MAX, (hipStream_t)stream));
+    st.epoch = 1;
+  }
+  const int64_t epoch = st.epoch;
+  st.epoch += M + 1;
+  k_elect<<<blocks(M, 256), 256, 0, (hipStream_t)stream>>>(ids, M, st.ptr, epoch, n_nodes);
+  k_winner<<<blocks(M, 256), 256, 0, (hipStream_t)stream>>>(ids, M, st.ptr, epoch, n_nodes, winner);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
 ORCA_API int orca_segment_mean(const int64_t* ids, int64_t M, int64_t Dm, const float* msgs, const float* ts,
                                int64_t* slot, int64_t epoch, int64_t n_nodes, uint8_t* winner, float* out_msgs,
                                void* stream) {
