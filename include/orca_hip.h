@@ -81,9 +81,11 @@ int orca_sample_recent(const orca_csr_t* csr, const int64_t* nodes, const double
 int orca_find_before(const orca_csr_t* csr, const int64_t* nodes, const double* ts, int64_t Q,
                      int64_t* out_count, void* stream);
 /* Not in the reference ("parity unpinned"): K draws with replacement among the
- * entries before t from a counter RNG keyed (seed, query, slot), returned in time order. */
+ * entries before t from a counter RNG keyed (seed, q0 + query, slot), returned in time order.  q0 is the index of
+ * nodes[0] in the caller's numbering: a call on the slice [q0, q0+Q) of a query list draws what a call on the
+ * whole list draws for those queries. */
 int orca_sample_uniform(const orca_csr_t* csr, const int64_t* nodes, const double* ts, int64_t Q, int K,
-                        uint64_t seed, int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
+                        uint64_t seed, int64_t q0, int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
                         int* err_flag, void* stream);
 
 /* ---- time encoder: model/time_encoding.py:23-28 ------------------------------------------ */
@@ -331,15 +333,38 @@ typedef struct {
   float* emb[2];                   /* [q_max, ORCA_D] each: layer outputs ping-pong (layer l -> emb[(l+1)&1]) */
   uint8_t* winners;                /* [2*q_max] last-occurrence flags of the push / message-store id lists; may be
                                       NULL (the elections then run on `slot` with global atomics) */
-  float* upd;                      /* [q_max, ORCA_D] or NULL: for a rank that embeds a slice in train order, the
-                                      updated memory row of each of its roots (rows lo..hi); the caller all-gathers
-                                      the buffer before orca_engine_finish, which then commits the positives' rows
-                                      from it instead of recomputing the GRU of every rank's positives */
   int32_t* eager_ids;              /* [2, q_max] or NULL: the distinct ids whose raw message a train-ordered step
                                       stored (two halves, written and consumed by alternate steps) */
   int32_t* eager_count;            /* [2] their counts; zero-initialised by the caller */
   int32_t att_q_folded;            /* nonzero: every att_blob was completed by orca_tgat_pack_gather with time_b */
+  /* ---- several ranks (not in the reference): owner-computes sharding of the state ----
+   * owner(id) = id % world.  In a train-ordered step every rank embeds its slice of the batch's root queries and
+   * runs the memory persist, the raw-message store and the GRU only for the ids it owns; the rows other ranks
+   * read are exchanged through the two buffers below, which the CALLER all-gathers (RCCL) between the calls:
+   *   xh[b]: world chunks of orca_engine_xh_chunk_floats(per) floats, per = ceil(Q / world) of the current batch:
+   *          [per rows of ORCA_D floats | per winner bytes]: a rank's layer outputs for its slice and the
+   *          last-occurrence flags of its roots WITHIN the slice; layer l writes xh[(l+1)&1];
+   *   xm   : world chunks of orca_engine_xm_chunk_words(xm_cap) 32-bit words: [count, 63 unused | ids[xm_cap] |
+   *          rows[xm_cap][ORCA_D]]: GRU(message, memory) of the ids a rank owns among the batch's positives.
+   * world <= 1: all of these may be 0 / NULL. */
+  int32_t world, rank;
+  float* xh[2];
+  int32_t* xm;
+  int64_t xm_cap;                  /* rows a rank can send per step; more owned ids than this set bit 0 of *err */
+  int32_t* own_ids;                /* [q_max] the distinct ids this rank owns among the batch's positives */
+  int32_t* own_count;              /* [1], zero-initialised by the caller */
+  int32_t* err;                    /* [1] device error word, zero-initialised by the caller (bit 0: xm overflow) */
 } orca_engine_desc;
+int64_t orca_engine_xh_chunk_floats(int64_t per);
+int64_t orca_engine_xm_chunk_words(int64_t cap);
+
+/* Neighbour sampling of the step driver: ORCA_SAMPLE_RECENT (utils/util.py:134-151, the reference's only mode) or
+ * ORCA_SAMPLE_UNIFORM (orca_sample_uniform: not in the reference, BASELINE config 5) with the seed of the NEXT
+ * step; the RNG key of a root is its index in the batch's [src;dst;neg] list, so slices of several ranks draw what
+ * one rank draws. */
+#define ORCA_SAMPLE_RECENT 0
+#define ORCA_SAMPLE_UNIFORM 1
+int orca_engine_set_sampling(orca_engine_t* e, int mode, uint64_t seed);
 
 int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** out);
 /* Measurement aid: enable = n > 0 attaches a HIP event pair to the sampler / GRU / attention dispatches of every
@@ -355,7 +380,15 @@ int orca_engine_destroy(orca_engine_t* e);
 int orca_engine_set_csr(orca_engine_t* e, const orca_csr_t* csr);           /* tgn_model.py:193-195 */
 /* hands out n consecutive epochs of the shared `slot` table (for callers that use it between steps) */
 int64_t orca_engine_take_epochs(orca_engine_t* e, int64_t n);
-/* Builds the Q = 3*bs root queries [src;dst;neg] x [t;t;t]; for this rank's slice [lo,hi) of them: samples
+/* With world > 1 a train-ordered step is the owner-computes step (it needs an overlay-complete state and the
+ * exchange buffers); the caller's sequence is
+ *   begin -> [all-gather xh[0]] -> finish -> [all-gather xm] -> layer 2 .. L (all-gather xh[(l+1)&1] between
+ *   layers) -> apply.
+ * finish may be enqueued while the first all-gather is in flight; apply must follow the xm all-gather and precede
+ * the next begin.  Eval-ordered steps with world > 1 run on replicated tables: every rank redoes the row writes of
+ * the whole batch (the caller makes the replicas coherent first: memory, last_update, messages, msg_ts of an id
+ * are only maintained by its owner during owner-computes steps).
+ * Builds the Q = 3*bs root queries [src;dst;neg] x [t;t;t]; for this rank's slice [lo,hi) of them: samples
  * the K most recent neighbours, (train) applies GRU(message, memory) for the rows it will read into the
  * overlay, runs attention layer 1 -> emb[0][lo:hi).  embedding_module.py:156-177
  * eidx (the batch's edge ids, tgn_model.py:95) may be NULL; when given, and the slice is the whole batch in
@@ -372,6 +405,8 @@ int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t hi, void*
  * batch was begun with.  tgn_model.py:127-145 */
 int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* eidx,
                        const double* ts, void* stream);
+/* owner-computes step: after the xm all-gather, overlay[id] = row and pending[id] = 1 for every id any rank sent */
+int orca_engine_apply(orca_engine_t* e, void* stream);
 
 /* Eager overlay.  While the state is "overlay complete" -- overlay[id] == GRU(messages[id], memory[id]) for every id
  * with a pending message, save those the last step stored -- a train-ordered orca_engine_begin over the whole

@@ -270,6 +270,7 @@ class OracleTGN:
                 if k.startswith("memory_updater.memory_updater.")}
     self.aff = {k[len("affinity_score."):]: v for k, v in self.sd.items() if k.startswith("affinity_score.")}
     self.neighbor_finder = None
+    self.uniform_seed = None              # set to an int: seeded-uniform sampling (NOT in the reference; see sample_uniform)
     self.batch_counter = 0
     self.test_mode = False
     self.init_memory()
@@ -314,7 +315,11 @@ class OracleTGN:
     self.pending[ids] = False
 
   def _sample(self, nodes, ts):
-    nbr, eid, et, dt = self.neighbor_finder.get_temporal_neighbor(nodes, ts, self.K, with_deltas=True)
+    if self.uniform_seed is not None:     # per-batch seed as OrcaEngine._step_seed; the draw key is the query's position
+      seed = (self.uniform_seed + self.batch_counter * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+      nbr, eid, et, dt = sample_uniform(self.neighbor_finder, nodes, ts, self.K, seed)
+    else:
+      nbr, eid, et, dt = self.neighbor_finder.get_temporal_neighbor(nodes, ts, self.K, with_deltas=True)
     return nbr, torch.from_numpy(nbr.astype(np.int64)), torch.from_numpy(eid.astype(np.int64)), torch.from_numpy(dt)
 
   def _aggregate(self, layer, src_feat, nbr_feat, dt, eid_t, mask):

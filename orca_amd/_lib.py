@@ -43,8 +43,9 @@ class EngineDesc(ctypes.Structure):
                ("messages", vp), ("msg_ts", vp), ("pending", vp), ("overlay", vp),
                ("hist", vp * (ORCA_ENGINE_MAX_LAYERS - 1)), ("slot", vp), ("worklist", vp), ("count", vp),
                ("q_max", i64), ("nodes", vp), ("qts", vp), ("nodes32", vp), ("nbr", vp), ("eid", vp), ("et", vp),
-               ("dt", vp), ("emb", vp * 2), ("winners", vp), ("upd", vp), ("eager_ids", vp), ("eager_count", vp),
-               ("att_q_folded", ctypes.c_int32)])
+               ("dt", vp), ("emb", vp * 2), ("winners", vp), ("eager_ids", vp), ("eager_count", vp),
+               ("att_q_folded", ctypes.c_int32), ("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("xh", vp * 2),
+               ("xm", vp), ("xm_cap", i64), ("own_ids", vp), ("own_count", vp), ("err", vp)])
 
 
 # name -> (restype, argtypes); every symbol include/orca_hip.h declares
@@ -60,7 +61,7 @@ SIGNATURES = {
     "orca_csr_copy_host": (i32, [vp, vp, vp, vp, vp]),
     "orca_sample_recent": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
     "orca_find_before": (i32, [vp, vp, vp, i64, vp, vp]),
-    "orca_sample_uniform": (i32, [vp, vp, vp, i64, i32, u64, vp, vp, vp, vp, vp, vp]),
+    "orca_sample_uniform": (i32, [vp, vp, vp, i64, i32, u64, i64, vp, vp, vp, vp, vp, vp]),
     "orca_time_encode": (i32, [vp, i64, vp, vp, vp, vp]),
     "orca_tgat_blob_floats": (i64, [i32]),
     "orca_tgat_pack": (i32, [i32] + [vp] * 14),
@@ -99,6 +100,10 @@ SIGNATURES = {
     "orca_engine_begin": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
     "orca_engine_layer": (i32, [vp, i32, i64, i64, vp]),
     "orca_engine_finish": (i32, [vp, vp, vp, vp, vp, vp]),
+    "orca_engine_apply": (i32, [vp, vp]),
+    "orca_engine_xh_chunk_floats": (i64, [i64]),
+    "orca_engine_xm_chunk_words": (i64, [i64]),
+    "orca_engine_set_sampling": (i32, [vp, i32, u64]),
     "orca_engine_set_overlay_complete": (i32, [vp, i32]),
     "orca_engine_get_overlay_complete": (i32, [vp]),
     "orca_engine_drain": (i32, [vp, vp]),

@@ -343,72 +343,31 @@ ORCA_API int orca_find_before(const orca_csr_t* c, const int64_t* nodes, const d
   return ORCA_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Uniform sampling (not in the reference; defined here, pinned against the oracle's restatement).
-// For a query with i > 0 entries before t, slot j draws r_j = mix(seed, q, j) mod i; the K draws are
-// then ordered by position (== by (ts, position)) so the output is time-ordered like the recent
-// sampler's.  i == 0 gives an all-padding row.
-__host__ __device__ static inline uint64_t orca_mix64(uint64_t x) {  // splitmix64 finaliser
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
-
+// Uniform sampling: sample_uniform_wave (sampler.h), one wave per query
 __global__ __launch_bounds__(256) void k_sample_uniform(const int64_t* __restrict__ indptr,
                                                         const int32_t* __restrict__ nbr,
                                                         const int32_t* __restrict__ eid,
                                                         const double* __restrict__ ts, int64_t n_rows,
                                                         const int64_t* __restrict__ nodes,
                                                         const double* __restrict__ qts, int64_t Q, int K,
-                                                        uint64_t seed, int32_t* __restrict__ o_nbr,
+                                                        uint64_t seed, int64_t q0, int32_t* __restrict__ o_nbr,
                                                         int32_t* __restrict__ o_eid, float* __restrict__ o_et,
                                                         float* __restrict__ o_dt, int* err_flag) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= Q) return;
-  const int64_t v = nodes[q];
-  const double t = qts[q];
-  int64_t lo = 0, cnt = 0;
-  if (v >= 0 && v < n_rows) {
-    lo = indptr[v];
-    cnt = wave_lower_bound(ts, lo, indptr[v + 1], t, lane) - lo;
-  } else if (err_flag && lane == 0) {
-    *err_flag = 1;
-  }
-  // K <= 64: lane j owns draw j; rank it among the K draws (ties broken by slot) to sort
-  int64_t r = -1;
-  if (lane < K && cnt > 0) r = (int64_t)(orca_mix64(seed ^ orca_mix64((uint64_t)q * 64u + (uint64_t)lane)) % (uint64_t)cnt);
-  int rank = 0;
-  for (int j = 0; j < K; ++j) {
-    int64_t rj = __shfl(r, j, 64);
-    rank += (rj < r) || (rj == r && j < lane);
-  }
-  if (lane < K) {
-    int32_t n = 0, e = 0;
-    float et = 0.0f;
-    if (cnt > 0) {
-      n = nbr[lo + r];
-      e = eid[lo + r];
-      et = (float)ts[lo + r];
-    } else {
-      rank = lane;
-    }
-    int64_t o = q * K + rank;
-    o_nbr[o] = n;
-    o_eid[o] = e;
-    o_et[o] = et;
-    if (o_dt) o_dt[o] = (float)(t - (double)et);
-  }
+  sample_uniform_wave(indptr, nbr, eid, ts, n_rows, nodes[q], qts[q], q, Q, K, seed, q0 + q, o_nbr, o_eid, o_et, o_dt,
+                      err_flag, orca_claim{}, lane);
 }
 
 ORCA_API int orca_sample_uniform(const orca_csr_t* c, const int64_t* nodes, const double* ts, int64_t Q, int K,
-                                 uint64_t seed, int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
-                                 int* err_flag, void* stream) {
-  ORCA_REQUIRE(c && Q >= 0 && K >= 1 && K <= 64, "orca_sample_uniform: bad arguments (Q=%lld K=%d)", (long long)Q, K);
+                                 uint64_t seed, int64_t q0, int32_t* out_nbr, int32_t* out_eidx, float* out_et,
+                                 float* out_dt, int* err_flag, void* stream) {
+  ORCA_REQUIRE(c && Q >= 0 && K >= 1 && K <= 64 && q0 >= 0, "orca_sample_uniform: bad arguments (Q=%lld K=%d)", (long long)Q, K);
   if (Q == 0) return ORCA_OK;
-  k_sample_uniform<<<(unsigned)ceil_div64(Q, 4), 256, 0, (hipStream_t)stream>>>(
-      c->indptr, c->nbr, c->eid, c->ts, c->n_rows, nodes, ts, Q, K, seed, out_nbr, out_eidx, out_et, out_dt, err_flag);
+  ORCA_LAUNCH_TIMED(k_sample_uniform, (unsigned)ceil_div64(Q, 4), 256, 0, (hipStream_t)stream,
+                    c->indptr, c->nbr, c->eid, c->ts, c->n_rows, nodes, ts, Q, K, seed, q0, out_nbr, out_eidx, out_et, out_dt,
+                    err_flag);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

@@ -27,7 +27,11 @@ struct orca_engine {
   bool winners_valid;          // begin() elected the last occurrences of the push / message-store id lists
   bool persist_done;           // the memory persist of the batch was fused into attention layer 1
   int pushed_layer;            // output of this layer is already in its history table (fused push), 0 = none
-  bool upd_rows;               // layer 1 wrote the updated memory rows of this rank's roots to d.upd (sliced train step)
+  bool sharded;                // owner-computes step (several ranks, train order): see orca_engine_begin
+  int64_t per;                 // rows per rank slice of the current batch = ceil(Q / world)
+  int64_t xh_chunk;            // floats per rank chunk of the xh buffers for this batch
+  int sampling;                // ORCA_SAMPLE_*
+  uint64_t seed;               // uniform sampling: seed of the next step
   bool store_done;             // the raw-message store of the batch was fused into the last attention layer
   const int64_t* eidx;         // batch edge ids handed to begin() (may be null)
   // Eager overlay (see orca_engine_begin).  overlay_complete: every pending id outside the outstanding list has
@@ -65,10 +69,14 @@ __device__ __forceinline__ int elect_part(int64_t id, int parts) { return (int)(
 // full, so every occurrence of that id takes the same route and the result stays exact.
 constexpr int ELECT_UNROLL = 6;            // ids a thread has in flight (one pass covers a full table's worth)
 
+// own_world > 1: only the ids with id % own_world == own_rank take part (owner-computes sharding); the positions of
+// the others get winner = 0 (written by part 0, like the invalid ids).
 template <typename GetId>
 __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64_t n, int64_t n_nodes, GetId get,
                                              uint8_t* __restrict__ winner, int part, int parts,
-                                             int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
+                                             int32_t* __restrict__ list, int32_t* __restrict__ list_count,
+                                             int own_world = 1, int own_rank = 0) {
+  auto owned = [&](int64_t v) { return own_world <= 1 || (int)((uint32_t)v % (uint32_t)own_world) == own_rank; };
   constexpr int64_t CHUNK = (int64_t)ELECT_UNROLL * ELECT_THREADS;
   // the first chunk's ids are requested before the table is cleared: their round trip hides behind the clear
   int64_t id[ELECT_UNROLL];
@@ -88,7 +96,7 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
 #pragma unroll
     for (int u = 0; u < ELECT_UNROLL; ++u) {
       const int64_t p = p0 + (int64_t)u * ELECT_THREADS + threadIdx.x, v = id[u];
-      if (v < 0 || v >= n_nodes || elect_part(v, parts) != part) continue;
+      if (v < 0 || v >= n_nodes || !owned(v) || elect_part(v, parts) != part) continue;
       uint32_t h = ((uint32_t)v * 2654435761u) >> 19;
       int probes = 0;
       for (; probes < ELECT_SLOTS; ++probes) {
@@ -107,8 +115,8 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
 #pragma unroll
     for (int u = 0; u < ELECT_UNROLL; ++u) {
       const int64_t p = p0 + (int64_t)u * ELECT_THREADS + threadIdx.x, v = id[u];
-      const bool valid = v >= 0 && v < n_nodes;
-      const bool mine = p < n && (valid ? elect_part(v, parts) == part : part == 0);   // invalid ids: cleared by part 0
+      const bool valid = v >= 0 && v < n_nodes && owned(v);
+      const bool mine = p < n && (valid ? elect_part(v, parts) == part : part == 0);   // invalid / foreign ids: cleared by part 0
       uint8_t w = 0;
       if (mine && valid) {
         uint32_t h = ((uint32_t)v * 2654435761u) >> 19;
@@ -141,33 +149,50 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
 
 // First kernel of a step.  Query block b < nbs (block index ne + b), wave w: root query i = lo + 16 b + w of [src;dst;neg] x [t;t;t]
 // (tgn_model.py:99-102) is written to nodes / qts / nodes32 and, when i lies in this rank's slice [lo, hi), its K
-// most recent neighbours are sampled into row i - lo of the sampler outputs (embedding_module.py:157), with the
-// claim pass of the overlay work-list in train order.
-// blocks 0 .. parts-1        (elect only): winners of the raw-message store over [src;dst]  (tgn_model.py:174-176)
-// blocks parts .. 2*parts-1  (elect only): winners of the history push over all 3*bs roots (embedding_module.py:103-113, H7)
-// blocks ne .. ne+nb-1: the root queries (ne = 2*parts, or 0 when the caller elects elsewhere)
+// neighbours are sampled into row i - lo of the sampler outputs (embedding_module.py:157), with the claim pass of
+// the overlay work-list in train order.
+// blocks 0 .. ne_m-1        (elect only): winners of the raw-message store over [src;dst]  (tgn_model.py:174-176);
+//                           with own_world > 1 only among the ids this rank owns, which also form msg_list
+// blocks ne_m .. ne-1       (elect only): winners of the history push over the roots [push_lo, push_lo + push_n)
+//                           (embedding_module.py:103-113, H7): all 3*bs roots, or this rank's slice
+// blocks ne .. ne+nb-1: the root queries
+struct begin_elect {
+  int ne_m, ne;                 // message-list election blocks, all election blocks
+  int64_t push_lo, push_n;
+  uint8_t *win_push, *win_msg;
+  int32_t *msg_list, *msg_count;
+  int own_world, own_rank;
+};
+struct begin_sample {
+  int mode;                     // ORCA_SAMPLE_*
+  uint64_t seed;
+};
 __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
-    int32_t* __restrict__ nodes32, int ne, int nbs, int parts, int64_t n_nodes, uint8_t* __restrict__ win_push,
-    uint8_t* __restrict__ win_msg, int32_t* __restrict__ msg_list, int32_t* __restrict__ msg_count,
+    int32_t* __restrict__ nodes32, begin_elect el, int nbs, int64_t n_nodes,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ c_nbr, const int32_t* __restrict__ c_eid,
-    const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int K, int32_t* __restrict__ o_nbr,
-    int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt, orca_claim claim) {
+    const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int K, begin_sample smp,
+    int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt,
+    orca_claim claim) {
   __shared__ int32_t keys[ELECT_SLOTS], vals[ELECT_SLOTS];
   auto root = [&](int64_t i) {   // one load through a selected pointer: no branch around it
     const int64_t* a = i < bs ? src : (i < 2 * bs ? dst - bs : neg - 2 * bs);
     return a[i];
   };
   // the election workgroups (the longest dependent chains of this launch) take the first block indices so that
-  // they are dispatched first; ne = 2*parts of them, or 0
-  if ((int)blockIdx.x < ne) {
-    if ((int)blockIdx.x < parts) elect_in_lds(keys, vals, 2 * bs, n_nodes, root, win_msg, (int)blockIdx.x, parts, msg_list, msg_count);
-    else elect_in_lds(keys, vals, 3 * bs, n_nodes, root, win_push, (int)blockIdx.x - parts, parts, nullptr, nullptr);
+  // they are dispatched first
+  if ((int)blockIdx.x < el.ne) {
+    if ((int)blockIdx.x < el.ne_m)
+      elect_in_lds(keys, vals, 2 * bs, n_nodes, root, el.win_msg, (int)blockIdx.x, el.ne_m, el.msg_list, el.msg_count,
+                   el.own_world, el.own_rank);
+    else
+      elect_in_lds(keys, vals, el.push_n, n_nodes, [&](int64_t p) { return root(el.push_lo + p); }, el.win_push,
+                   (int)blockIdx.x - el.ne_m, el.ne - el.ne_m, nullptr, nullptr);
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int64_t bq = (int64_t)((int)blockIdx.x - ne);
+  const int64_t bq = (int64_t)((int)blockIdx.x - el.ne);
   if (bq >= nbs) {   // query rows of the roots outside this rank's slice: one per thread (a wave each would be 8x the
     const int64_t i = (bq - nbs) * ELECT_THREADS + threadIdx.x;          // workgroups at 8 ranks, for three stores)
     if (i >= 3 * bs || (i >= lo && i < hi)) return;
@@ -186,7 +211,127 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     nodes32[i] = (int32_t)v;
     qts[i] = t;
   }
-  sample_recent_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, i - lo, hi - lo, K, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
+  if (smp.mode == ORCA_SAMPLE_UNIFORM)
+    sample_uniform_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, i - lo, hi - lo, K, smp.seed, i, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
+  else
+    sample_recent_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, i - lo, hi - lo, K, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
+}
+
+// ---- owner-computes step (several ranks): kernels over the exchange buffers ---------------------------------
+constexpr int XM_HEADER = 64;      // 32-bit words ahead of the ids of an xm chunk (word 0 = count)
+__host__ __device__ inline int64_t xh_chunk_floats(int64_t per) { return ((per * (ORCA_D * 4 + 1) + 255) / 256) * 64; }
+__host__ __device__ inline int64_t xm_ids_words(int64_t cap) { return ((cap + 63) / 64) * 64; }
+__host__ __device__ inline int64_t xm_chunk_words(int64_t cap) { return XM_HEADER + xm_ids_words(cap) + cap * ORCA_D; }
+
+// History push of the all-gathered layer outputs (embedding_module.py:103-113, H7 last occurrence wins): every
+// rank flagged the last occurrence of each id WITHIN its slice; across slices the highest global position wins.
+// Only slice winners contend, so an id has at most `world` contenders (no hub serialisation at L2).
+__global__ void k_xpush_claim(const int64_t* __restrict__ nodes, int64_t Q, int64_t per, const float* __restrict__ xh,
+                              int64_t chunk, int64_t* slot, int64_t epoch, int64_t n_nodes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  const int64_t c = i / per, j = i - c * per;
+  const uint8_t* flags = reinterpret_cast<const uint8_t*>(xh + c * chunk + per * ORCA_D);
+  if (!flags[j]) return;
+  const int64_t id = nodes[i];
+  if (id < 0 || id >= n_nodes) return;
+  atomicMax(reinterpret_cast<unsigned long long*>(&slot[id]), (unsigned long long)(epoch + i));
+}
+__global__ __launch_bounds__(256) void k_xpush_write(const int64_t* __restrict__ nodes, int64_t Q, int64_t per,
+                                                     const float* __restrict__ xh, int64_t chunk,
+                                                     const int64_t* __restrict__ slot, int64_t epoch, int64_t n_nodes,
+                                                     float* __restrict__ hist) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= Q) return;
+  const int64_t c = i / per, j = i - c * per;
+  const float* base = xh + c * chunk;
+  if (!reinterpret_cast<const uint8_t*>(base + per * ORCA_D)[j]) return;
+  const int64_t id = nodes[i];
+  if (id < 0 || id >= n_nodes || slot[id] != epoch + i) return;
+  const float* row = base + j * ORCA_D;
+  for (int c2 = lane; c2 < ORCA_D; c2 += 64) hist[id * ORCA_D + c2] = row[c2];
+}
+
+// Owner's share of tgn_model.py:127-141 for the winner positions p of [src;dst] whose id this rank owns: the memory
+// persist (memory_updater.py:25-39: the overlay row of a pending id is GRU(message, memory) already) and then the
+// raw message built from the persisted rows (tgn_model.py:172-191, memory.py:25-28).  The rows of id and partner
+// are read as `pending ? overlay : memory`: for a pending positive that IS its persisted row, whoever owns it, and
+// this kernel writes neither overlay nor pending (the flags of the stored ids are raised by k_apply_rows on every
+// rank, after the exchange), so no wave can see another wave's half-made update.
+__global__ __launch_bounds__(256) void k_owner_persist_store(
+    const int64_t* __restrict__ nodes, const double* __restrict__ qts, const int64_t* __restrict__ eidx, int64_t bs,
+    const uint8_t* __restrict__ winner, int64_t n_nodes, const uint8_t* __restrict__ pending,
+    const float* __restrict__ overlay, float* __restrict__ memory, float* __restrict__ last_update,
+    const float* __restrict__ edge_feats, int d_e, const float* __restrict__ tw, const float* __restrict__ tb,
+    float* __restrict__ messages, float* __restrict__ msg_ts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= 2 * bs || !winner[p]) return;
+  const int64_t e = p < bs ? p : p - bs;
+  const int64_t id = nodes[p], partner = nodes[p < bs ? p + bs : p - bs];
+  if (id < 0 || id >= n_nodes) return;
+  const bool pend = pending[id] != 0;
+  const bool ppend = partner >= 0 && partner < n_nodes && pending[partner] != 0;
+  const float* ms = (pend ? overlay : memory) + id * ORCA_D;
+  const float* md = (ppend ? overlay : memory) + partner * ORCA_D;
+  const float tf = (float)qts[p];                                    // tgn_model.py:181
+  const float lu = pend ? msg_ts[id] : last_update[id];              // memory_updater.py:37
+  const float delta = tf - lu;                                       // tgn_model.py:187
+  const int msg_dim = 3 * ORCA_D + d_e;
+  float* row = messages + id * msg_dim;
+  const float* ef = edge_feats + eidx[e] * d_e;
+  for (int c = lane; c < ORCA_D; c += 64) {
+    const float a = ms[c];
+    row[c] = a;
+    if (pend) memory[id * ORCA_D + c] = a;                           // memory_updater.py:38
+    row[ORCA_D + c] = md[c];
+    row[2 * ORCA_D + d_e + c] = orca_cosf(orca_time_arg(delta, tw[c], tb[c]));   // tgn_model.py:188
+  }
+  for (int c = lane; c < d_e; c += 64) row[2 * ORCA_D + c] = ef[c];
+  if (lane == 0) {
+    if (pend) last_update[id] = lu;
+    msg_ts[id] = tf;
+  }
+}
+
+// xm chunk of this rank <- the overlay rows of the ids it owns among the batch's positives
+__global__ __launch_bounds__(256) void k_pack_rows(const int32_t* __restrict__ ids, const int32_t* __restrict__ count,
+                                                   int64_t cap, const float* __restrict__ overlay,
+                                                   int32_t* __restrict__ chunk, int32_t* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n = *count;
+  if (r == 0 && lane == 0) {
+    chunk[0] = (int32_t)(n < cap ? n : cap);
+    if (n > cap) atomicOr(err, 1);
+  }
+  if (r >= n || r >= cap) return;
+  const int32_t id = ids[r];
+  if (lane == 0) chunk[XM_HEADER + r] = id;
+  float* dst = reinterpret_cast<float*>(chunk + XM_HEADER + xm_ids_words(cap)) + r * ORCA_D;
+  const float* srcrow = overlay + (int64_t)id * ORCA_D;
+  for (int c = lane; c < ORCA_D; c += 64) dst[c] = srcrow[c];
+}
+
+// after the all-gather: overlay[id] = row, pending[id] = 1 for the ids of every chunk (the own chunk: flags only)
+__global__ __launch_bounds__(256) void k_apply_rows(const int32_t* __restrict__ xm, int world, int rank, int64_t cap,
+                                                    int64_t n_nodes, float* __restrict__ overlay,
+                                                    uint8_t* __restrict__ pending, int32_t* __restrict__ own_count) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w == 0 && lane == 0) *own_count = 0;       // the list this step's election filled is spent
+  const int64_t c = w / cap, r = w - c * cap;
+  if (c >= world) return;
+  const int32_t* chunk = xm + c * xm_chunk_words(cap);
+  if (r >= chunk[0]) return;
+  const int64_t id = chunk[XM_HEADER + r];
+  if (id < 0 || id >= n_nodes) return;
+  if (c != rank) {
+    const float* row = reinterpret_cast<const float*>(chunk + XM_HEADER + xm_ids_words(cap)) + r * ORCA_D;
+    for (int c2 = lane; c2 < ORCA_D; c2 += 64) overlay[id * ORCA_D + c2] = row[c2];
+  }
+  if (lane == 0) pending[id] = 1;
 }
 
 // RAII bracket: while profiling is on, arms an event pair that the next timed launch (sampler / GRU / attention)
@@ -225,6 +370,8 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
                d.nbr && d.eid && d.et && d.dt && d.emb[0] && d.emb[1], "orca_engine_create: null table or work buffer");
   for (int l = 0; l < d.n_layers; ++l) ORCA_REQUIRE(d.att_blob[l], "orca_engine_create: missing attention blob %d", l);
   for (int l = 0; l + 1 < d.n_layers; ++l) ORCA_REQUIRE(d.hist[l], "orca_engine_create: missing history table %d", l);
+  ORCA_REQUIRE(d.world <= 1 || (d.rank >= 0 && d.rank < d.world && d.q_max % d.world == 0),
+               "orca_engine_create: bad rank %d of %d (q_max must be a multiple of world)", d.rank, d.world);
   orca_engine* e = new (std::nothrow) orca_engine();
   if (!e) { orca_set_error("orca_engine_create: out of host memory"); return ORCA_ENOMEM; }
   e->d = d;
@@ -236,7 +383,11 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   e->persist_done = false;
   e->pushed_layer = 0;
   e->store_done = false;
-  e->upd_rows = false;
+  e->sharded = false;
+  e->per = 0;
+  e->xh_chunk = 0;
+  e->sampling = ORCA_SAMPLE_RECENT;
+  e->seed = 0;
   e->eidx = nullptr;
   e->overlay_complete = false;
   e->have_list = false;
@@ -297,6 +448,16 @@ ORCA_API int64_t orca_engine_take_epochs(orca_engine_t* e, int64_t n) {
   return take_epochs(e, n);
 }
 
+ORCA_API int64_t orca_engine_xh_chunk_floats(int64_t per) { return per > 0 ? xh_chunk_floats(per) : 0; }
+ORCA_API int64_t orca_engine_xm_chunk_words(int64_t cap) { return cap > 0 ? xm_chunk_words(cap) : 0; }
+
+ORCA_API int orca_engine_set_sampling(orca_engine_t* e, int mode, uint64_t seed) {
+  ORCA_REQUIRE(e && (mode == ORCA_SAMPLE_RECENT || mode == ORCA_SAMPLE_UNIFORM), "orca_engine_set_sampling: bad arguments");
+  e->sampling = mode;
+  e->seed = seed;
+  return ORCA_OK;
+}
+
 ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
                                const int64_t* eidx, const double* ts, int64_t bs, int64_t lo, int64_t hi, int train,
                                void* stream_) {
@@ -308,17 +469,39 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
                "(slice %lld..%lld) does not fit q_max=%lld", (long long)bs, (long long)lo, (long long)hi, (long long)d.q_max);
   e->bs = bs; e->Q = Q; e->train = train;
   e->timed_step = e->profile > 0 && (e->step++ % e->profile) == 0;
-  e->overlay_covers_batch = train && lo == 0 && hi == Q;
   e->sliced = !(lo == 0 && hi == Q);
+  // Several ranks, train order: the owner-computes step.  Every rank embeds its slice; the row writes of the batch
+  // (memory persist, raw-message store, GRU of the stored ids) are done by the owner of each id, and the rows other
+  // ranks read travel through the xh / xm buffers (include/orca_hip.h).
+  const int world = d.world > 1 ? d.world : 1;
+  e->sharded = world > 1 && train;
+  e->per = ceil_div64(Q, world);
+  e->xh_chunk = xh_chunk_floats(e->per > 0 ? e->per : 1);
+  if (e->sharded) {
+    ORCA_REQUIRE(d.xh[0] && d.xh[1] && d.xm && d.xm_cap > 0 && d.own_ids && d.own_count && d.err && d.winners,
+                 "orca_engine_begin: a train-ordered step of %d ranks needs the exchange buffers", world);
+    ORCA_REQUIRE(e->overlay_complete, "orca_engine_begin: the owner-computes step needs an overlay-complete state "
+                 "(rebuild the overlay rows of the pending ids first)");
+    const int64_t my_lo = (int64_t)d.rank * e->per < Q ? (int64_t)d.rank * e->per : Q;
+    const int64_t my_hi = my_lo + e->per < Q ? my_lo + e->per : Q;
+    ORCA_REQUIRE(lo == my_lo && hi == my_hi, "orca_engine_begin: slice %lld..%lld is not rank %d's (%lld..%lld)",
+                 (long long)lo, (long long)hi, d.rank, (long long)my_lo, (long long)my_hi);
+  } else {
+    ORCA_REQUIRE(!(train && e->sliced), "orca_engine_begin: a train-ordered slice needs world > 1 in the descriptor");
+  }
   // the ids of a list are spread over `parts` tables of at most ELECT_MAX / 2 ids each: the workgroups run side by
   // side, and a table filled to a third keeps the probe chains -- LDS atomic round trips, paid by the whole wave --
   // short (a hub-free batch fills a table with distinct ids; 8 x 4095 roots: 34 -> 30.6 us against 6144 per table)
-  const int parts = Q <= ELECT_MAX / 3 ? 1 : (int)ceil_div64(Q, ELECT_MAX / 2);   // <= 3072 ids per table
-  e->winners_valid = d.winners && parts <= ELECT_PARTS_MAX;
+  auto parts_for = [](int64_t n) { return n <= ELECT_MAX / 3 ? 1 : (int)ceil_div64(n, ELECT_MAX / 2); };   // <= 3072 ids per table
+  // sharded: the message list is elected among the owned ids only (about 2*bs / world of them), the push list is
+  // this rank's slice; otherwise both are elected whole with the same number of tables
+  const int parts_m = e->sharded ? parts_for(ceil_div64(2 * bs, world)) : parts_for(Q);
+  const int parts_p = e->sharded ? parts_for(hi - lo) : parts_m;
+  e->winners_valid = d.winners && parts_m <= ELECT_PARTS_MAX && parts_p <= ELECT_PARTS_MAX;
+  ORCA_REQUIRE(!e->sharded || e->winners_valid, "orca_engine_begin: batch too long for the owner-computes elections");
   e->persist_done = false;
   e->pushed_layer = 0;
   e->store_done = false;
-  e->upd_rows = false;
   e->eidx = eidx;
   if (bs == 0) return ORCA_OK;
   ORCA_REQUIRE(src && dst && neg && ts, "orca_engine_begin: null batch array");
@@ -330,12 +513,12 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   // value for an id is fixed from the moment the message is stored until the id is a positive again (nothing
   // else writes its message or its memory), so it can be computed ONCE, right after the store: the election of
   // the raw-message list also emits the list of distinct ids, and the next begin() runs the GRU over exactly that
-  // list.  While `overlay_complete` holds no batch needs a work-list of the ids it reads (no claim pass, no
-  // append kernel, no GRU over a 45,045-candidate bound).  Steps that leave pending ids without an overlay row
-  // (a sliced multi-rank step, callers that store messages outside the driver) clear the flag and the driver
-  // falls back to the per-batch work-list until the caller declares the state clean again.
+  // list (the owner-computes step: finish() does, for the ids the rank owns).  While `overlay_complete` holds no
+  // batch needs a work-list of the ids it reads (no claim pass, no append kernel, no GRU over a 45,045-candidate
+  // bound).  Steps that leave pending ids without an overlay row (callers that store messages outside the driver)
+  // clear the flag and the driver falls back to the per-batch work-list until the state is declared clean again.
   e->cur ^= 1;
-  const bool lists = d.eager_ids && d.eager_count && e->winners_valid;
+  const bool lists = !e->sharded && d.eager_ids && d.eager_count && e->winners_valid;
   int32_t* my_list = lists ? d.eager_ids + (int64_t)e->cur * d.q_max : nullptr;
   int32_t* my_count = lists ? d.eager_count + e->cur : nullptr;
   e->list_written = lists;
@@ -349,7 +532,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     }
   }
   const bool full = lo == 0 && hi == Q;
-  const bool eager = train && e->overlay_complete;       // a slice too: every rank lists and applies the global ids
+  const bool eager = train && e->overlay_complete;
   const bool lazy = train && !eager;
   e->overlay_covers_batch = train && (full || eager);
   const int64_t cand = n * (K + 1);
@@ -361,15 +544,31 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     const orca_claim claim = (lazy && n > 0) ? orca_claim{d.pending, d.slot, claim_epoch, d.n_nodes, d.count} : orca_claim{};
     const int nbs = (int)ceil_div64(n, ELECT_THREADS / 64);                   // a wave per root of the slice
     const int nb = nbs + (n < Q ? (int)ceil_div64(Q, ELECT_THREADS) : 0);     // a thread per root outside it
+    begin_elect el{};
+    if (e->winners_valid) {
+      el.ne_m = parts_m; el.ne = parts_m + parts_p;
+      el.win_msg = d.winners + d.q_max;
+      if (e->sharded) {   // slice-local push winners, straight into this rank's chunk of xh[0]
+        el.push_lo = lo; el.push_n = n;
+        el.win_push = reinterpret_cast<uint8_t*>(d.xh[0] + (int64_t)d.rank * e->xh_chunk + e->per * ORCA_D);
+        el.msg_list = d.own_ids; el.msg_count = d.own_count;
+        el.own_world = world; el.own_rank = d.rank;
+      } else {
+        el.push_lo = 0; el.push_n = Q;
+        el.win_push = d.winners;
+        el.msg_list = my_list; el.msg_count = my_count;
+        el.own_world = 1; el.own_rank = 0;
+      }
+    }
+    const begin_sample smp{e->sampling, e->seed};
     Timed t(e, ORCA_PROF_SAMPLE, stream);
-    ORCA_LAUNCH_TIMED(k_begin_queries, (unsigned)(nb + (e->winners_valid ? 2 * parts : 0)), ELECT_THREADS, 0, stream, src, dst, neg, ts,
-                      bs, d.nodes, d.qts, d.nodes32, e->winners_valid ? 2 * parts : 0, nbs, parts, d.n_nodes, d.winners, d.winners ? d.winners + d.q_max : nullptr,
-                      my_list, my_count,
-                      indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, K, d.nbr, d.eid, d.et, d.dt, claim);
+    ORCA_LAUNCH_TIMED(k_begin_queries, (unsigned)(nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
+                      bs, d.nodes, d.qts, d.nodes32, el, nbs, d.n_nodes,
+                      indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
     ORCA_LAUNCH_CHECK();
   }
   // the other half of the list buffers (consumed above) is the next step's: its counter restarts at zero
-  int32_t* next_count = (d.eager_ids && d.eager_count) ? d.eager_count + (e->cur ^ 1) : nullptr;
+  int32_t* next_count = (!e->sharded && d.eager_ids && d.eager_count) ? d.eager_count + (e->cur ^ 1) : nullptr;
   if (n == 0) {
     if (next_count) ORCA_HIP_TRY(hipMemsetAsync(next_count, 0, sizeof(int32_t), stream));
     return ORCA_OK;
@@ -403,16 +602,14 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     side.persist_n = 2 * bs;
     e->persist_done = true;
   }
-  if (train && !e->overlay_covers_batch && d.upd) {   // a slice: hand the roots' updated rows to the other ranks
-    side.src_rows_out = d.upd + lo * ORCA_D;
-    e->upd_rows = true;
-  }
-  if (lo == 0 && hi == Q && e->winners_valid && d.n_layers >= 2) {
+  if (full && e->winners_valid && d.n_layers >= 2) {
     side.push_table = d.hist[0]; side.push_ids = d.nodes; side.push_winner = d.winners;
     e->pushed_layer = 1;
   }
+  // owner-computes step with inner layers: the output goes to this rank's chunk of xh[0], which the caller all-gathers
+  float* out = (e->sharded && d.n_layers >= 2) ? d.xh[0] + (int64_t)d.rank * e->xh_chunk : d.emb[0] + lo * ORCA_D;
   Timed t(e, ORCA_PROF_TGAT, stream);
-  return orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, n, K, d.emb[0] + lo * ORCA_D, nullptr, &side, stream_);   // :177 / :181
+  return orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, n, K, out, nullptr, &side, stream_);   // :177 / :181
 }
 
 ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t hi, void* stream_) {
@@ -421,20 +618,42 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
   ORCA_REQUIRE(layer >= 2 && layer <= d.n_layers, "orca_engine_layer: layer %d outside [2,%d]", layer, d.n_layers);
   ORCA_REQUIRE(0 <= lo && lo <= hi && hi <= e->Q, "orca_engine_layer: bad slice");
   if (e->Q == 0) return ORCA_OK;
+  float* h = d.hist[layer - 2];
+  orca_tgat_inputs in{};
+  in.nbr_table = h; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;   // pull (history.py:32-36) fused into the gather
+  in.edge_table = d.edge_feats; in.edge_idx = d.eid;
+  in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b; in.q_folded = d.att_q_folded;
+  if (e->sharded) {
+    // the all-gathered chunks of the previous layer: push across the slices, then attend this rank's rows
+    const float* xprev = d.xh[layer & 1];
+    const int64_t epoch = take_epochs(e, e->Q);
+    k_xpush_claim<<<(unsigned)ceil_div64(e->Q, 256), 256, 0, (hipStream_t)stream_>>>(d.nodes, e->Q, e->per, xprev, e->xh_chunk,
+                                                                                     d.slot, epoch, d.n_nodes);
+    k_xpush_write<<<(unsigned)ceil_div64(e->Q, 4), 256, 0, (hipStream_t)stream_>>>(d.nodes, e->Q, e->per, xprev, e->xh_chunk,
+                                                                                   d.slot, epoch, d.n_nodes, h);
+    ORCA_LAUNCH_CHECK();
+    if (hi == lo) return ORCA_OK;
+    const float* mine = xprev + (int64_t)d.rank * e->xh_chunk;
+    float* out = d.emb[(layer + 1) & 1] + lo * ORCA_D;
+    if (layer < d.n_layers) {     // feeds the next exchange: rows into this rank's chunk of the other buffer, flags copied
+      float* next = d.xh[(layer + 1) & 1] + (int64_t)d.rank * e->xh_chunk;
+      ORCA_HIP_TRY(hipMemcpyAsync(next + e->per * ORCA_D, mine + e->per * ORCA_D, (size_t)e->per, hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream_));
+      out = next;
+    }
+    in.src_table = mine;
+    Timed t(e, ORCA_PROF_TGAT, (hipStream_t)stream_);
+    return orca_tgat_forward_side(d.att_blob[layer - 1], d.d_e, &in, hi - lo, d.K, out, nullptr, nullptr, stream_);
+  }
   const float* prev = d.emb[layer & 1];            // layer 2 reads emb[0], layer 3 reads emb[1], ...
   float* next = d.emb[(layer + 1) & 1];
-  float* h = d.hist[layer - 2];
   // embedding_module.py:103-113 push of every root's layer-(l-1) embedding, last occurrence wins (H7)
   int rc = ORCA_OK;
   if (e->pushed_layer != layer - 1)
     rc = e->winners_valid ? orca_history_push_winners(h, prev, d.nodes, e->Q, d.winners, d.n_nodes, stream_)
                           : orca_history_push(h, prev, d.nodes, e->Q, d.slot, take_epochs(e, e->Q), d.n_nodes, stream_);
   if (rc != ORCA_OK || hi == lo) return rc;
-  orca_tgat_inputs in{};
   in.src_table = prev + lo * ORCA_D;               // dense rows of this rank's slice
-  in.nbr_table = h; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;   // pull (history.py:32-36) fused into the gather
-  in.edge_table = d.edge_feats; in.edge_idx = d.eid;
-  in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b; in.q_folded = d.att_q_folded;
   orca_tgat_side side{};
   if (lo == 0 && hi == e->Q && e->winners_valid && layer < d.n_layers) {   // this layer's output feeds the next history
     side.push_table = d.hist[layer - 1]; side.push_ids = d.nodes; side.push_winner = d.winners;
@@ -461,14 +680,32 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
   if (bs == 0) return ORCA_OK;
   ORCA_REQUIRE(src && dst && eidx && ts, "orca_engine_finish: null batch array");
   const int msg_dim = 3 * ORCA_D + d.d_e;
+  if (e->sharded) {   // the owner's share of tgn_model.py:127-141, then GRU(message, memory) of the ids just stored
+    hipStream_t st = (hipStream_t)stream_;
+    k_owner_persist_store<<<(unsigned)ceil_div64(2 * bs, 4), 256, 0, st>>>(
+        d.nodes, d.qts, eidx, bs, d.winners + d.q_max, d.n_nodes, d.pending, d.overlay, d.memory, d.last_update, d.edge_feats,
+        d.d_e, d.time_w, d.time_b, d.messages, d.msg_ts);
+    ORCA_LAUNCH_CHECK();
+    const int64_t bound = 2 * bs < d.q_max ? 2 * bs : d.q_max;
+    int rc;
+    {
+      Timed t(e, ORCA_PROF_GRU, st);
+      rc = orca_gru_update(d.gru_blob, msg_dim, d.own_ids, bound, d.own_count, d.messages, d.memory, d.overlay, nullptr,
+                           nullptr, stream_);
+    }
+    if (rc != ORCA_OK) return rc;
+    const int64_t rows = bound < d.xm_cap ? bound : d.xm_cap;
+    k_pack_rows<<<(unsigned)ceil_div64(rows > 0 ? rows : 1, 4), 256, 0, st>>>(d.own_ids, d.own_count, d.xm_cap, d.overlay,
+                                                                              d.xm + (int64_t)d.rank * xm_chunk_words(d.xm_cap), d.err);
+    ORCA_LAUNCH_CHECK();
+    return ORCA_OK;
+  }
   auto persist = [&]() -> int {   // memory_updater.update_memory (:25-39) + clear_messages (memory.py:49-50)
     // When this rank's begin() covered the whole batch in train order, the overlay already holds
     // GRU(message, memory) of every pending positive (same messages, same memory: positives are roots of the
     // batch): the rows are committed by one kernel, and the flags need no clearing because the message store
     // that follows sets them for exactly these ids.
     if (e->persist_done) return ORCA_OK;   // attention layer 1 committed the rows (orca_tgat_side)
-    if (e->upd_rows && e->train)        // rows all-gathered from the ranks that own the roots (orca_engine_desc.upd)
-      return orca_persist_rows(d.nodes, 2 * bs, d.pending, d.upd, d.memory, d.last_update, d.msg_ts, d.n_nodes, stream_);
     if (e->overlay_covers_batch)
       return orca_persist_overlay(d.nodes, 2 * bs, d.pending, d.overlay, d.memory, d.last_update, d.msg_ts, d.n_nodes,
                                   stream_);
@@ -498,19 +735,10 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
   if (e->train) {                 // tgn_model.py:127-141
     if ((rc = persist()) != ORCA_OK) return rc;
     if ((rc = store()) != ORCA_OK) return rc;
-    // the ids that now hold a fresh message: begin() elected them into this step's list.  Every rank of a sliced
-    // step elects the same global list and applies it redundantly -- for up to 8 ranks that is cheaper than the
-    // per-slice work-list plus an exchange of the positives' rows, and the ranks stay bit-identical
-    if (e->list_written && !e->upd_rows && e->overlay_covers_batch) {
+    // the ids that now hold a fresh message: begin() elected them into this step's list
+    if (e->list_written && e->overlay_covers_batch) {
       e->have_list = true;
       e->list_bound = 2 * bs < d.q_max ? 2 * bs : d.q_max;
-      // A sliced step calls finish() while the ranks' layer-1 rows are still being exchanged: the GRU over the
-      // ids just stored runs now, inside that wait, instead of at the head of the next step (nothing that
-      // follows in this step reads the overlay).  One rank keeps it in begin(): the order on the device is the same.
-      if (e->sliced && e->overlay_complete) {
-        Timed t(e, ORCA_PROF_GRU, (hipStream_t)stream_);
-        if ((rc = orca_engine_drain(e, stream_)) != ORCA_OK) return rc;
-      }
     } else {
       e->overlay_complete = false;
     }
@@ -518,6 +746,16 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
   }
   if ((rc = store()) != ORCA_OK) return rc;   // :131-145
   return persist();                           // the positives end without a pending message: nothing to list
+}
+
+ORCA_API int orca_engine_apply(orca_engine_t* e, void* stream_) {
+  ORCA_REQUIRE(e, "orca_engine_apply: null handle");
+  const orca_engine_desc& d = e->d;
+  if (!e->sharded || e->bs == 0) return ORCA_OK;
+  k_apply_rows<<<(unsigned)ceil_div64((int64_t)d.world * d.xm_cap, 4), 256, 0, (hipStream_t)stream_>>>(
+      d.xm, d.world, d.rank, d.xm_cap, d.n_nodes, d.overlay, d.pending, d.own_count);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
 }
 
 ORCA_API int orca_engine_set_overlay_complete(orca_engine_t* e, int complete) {

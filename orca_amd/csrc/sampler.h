@@ -112,3 +112,61 @@ __device__ __forceinline__ void sample_recent_wave(const int64_t* __restrict__ i
     if (claim.slot && n >= 0 && n < claim.n_nodes && (!claim.flags || claim.flags[n])) claim.slot[n] = claim.epoch + o;
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Uniform sampling (not in the reference; defined here, pinned against the oracle's restatement).
+// For a query with i > 0 entries before t, slot j draws r_j = mix(seed, key, j) mod i, key = the query's index in
+// the caller's numbering (the GLOBAL root index in the step driver, so that a rank's slice draws what a single
+// rank would); the K draws are then ordered by position (== by (ts, position)) so the output is time-ordered
+// like the recent sampler's.  i == 0 gives an all-padding row.  K <= 64.
+__host__ __device__ static inline uint64_t orca_mix64(uint64_t x) {  // splitmix64 finaliser
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ void sample_uniform_wave(const int64_t* __restrict__ indptr, const int32_t* __restrict__ nbr,
+                                                    const int32_t* __restrict__ eid, const double* __restrict__ ts,
+                                                    int64_t n_rows, int64_t v, double t, int64_t q, int64_t Q, int K,
+                                                    uint64_t seed, int64_t key, int32_t* __restrict__ o_nbr,
+                                                    int32_t* __restrict__ o_eid, float* __restrict__ o_et,
+                                                    float* __restrict__ o_dt, int* err_flag, const orca_claim& claim,
+                                                    int lane) {
+  if (claim.slot) {
+    if (q == 0 && lane == 0) *claim.count = 0;
+    if (lane == 0 && v >= 0 && v < claim.n_nodes && (!claim.flags || claim.flags[v])) claim.slot[v] = claim.epoch + Q * K + q;
+  }
+  int64_t lo = 0, cnt = 0;
+  if (v >= 0 && v < n_rows) {
+    lo = indptr[v];
+    cnt = wave_lower_bound(ts, lo, indptr[v + 1], t, lane) - lo;
+  } else if (err_flag && lane == 0) {
+    *err_flag = 1;
+  }
+  // lane j owns draw j; rank it among the K draws (ties broken by slot) to sort
+  int64_t r = -1;
+  if (lane < K && cnt > 0) r = (int64_t)(orca_mix64(seed ^ orca_mix64((uint64_t)key * 64u + (uint64_t)lane)) % (uint64_t)cnt);
+  int rank = 0;
+  for (int j = 0; j < K; ++j) {
+    int64_t rj = __shfl(r, j, 64);
+    rank += (rj < r) || (rj == r && j < lane);
+  }
+  if (lane < K) {
+    int32_t n = 0, e = 0;
+    float et = 0.0f;
+    if (cnt > 0) {
+      n = nbr[lo + r];
+      e = eid[lo + r];
+      et = (float)ts[lo + r];
+    } else {
+      rank = lane;
+    }
+    int64_t o = q * K + rank;
+    o_nbr[o] = n;
+    o_eid[o] = e;
+    o_et[o] = et;
+    if (o_dt) o_dt[o] = (float)(t - (double)et);
+    if (claim.slot && n >= 0 && n < claim.n_nodes && (!claim.flags || claim.flags[n])) claim.slot[n] = claim.epoch + o;
+  }
+}

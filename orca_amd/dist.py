@@ -2,6 +2,10 @@
 device, so this is defined here).  One process per GPU, torch.distributed over RCCL ("nccl") on the
 node; the same code runs over gloo for the CPU / single-GPU tests.
 
+State ownership: owner(id) = id % world (owner()).  In owner-computes steps a rank keeps the memory / message rows of
+the ids it owns current and sends the rows other ranks read through fixed-size chunk buffers (all_gather_chunks);
+sync_owned_rows makes full replicas coherent again.
+
 Partition: the Q root (node, t) queries of a batch are cut into `world` contiguous slices of
 per = ceil(Q / world) rows (the last slices may be short or empty).  Exchange: every rank contributes
 its [n_local, W] rows padded to per rows; one all_gather_into_tensor returns the [world*per, W] buffer
@@ -47,3 +51,41 @@ def all_reduce_sum(x, group=None):
   else:
     dist.all_reduce(x, group=group)
   return x
+
+
+def owner(ids, world):
+  """rank that owns the state rows of each node id (rows sharded by node-id hash)"""
+  return ids % world
+
+
+def all_gather_chunks(buf, chunk, group=None, async_op=False):
+  """In-place all-gather of the first world x chunk elements of the flat buffer buf: rank r contributes
+  buf[r*chunk:(r+1)*chunk] and receives every other chunk.  Returns the work handle when async_op (None when the
+  exchange already completed: gloo with device buffers stages through the host)."""
+  world, rank = dist.get_world_size(group), dist.get_rank(group)
+  full = buf[:world * chunk]
+  mine = full[rank * chunk:(rank + 1) * chunk]
+  if buf.is_cuda and dist.get_backend(group) == "gloo":
+    hf = torch.empty(full.shape, dtype=full.dtype)
+    dist.all_gather_into_tensor(hf, mine.cpu(), group=group)
+    full.copy_(hf)
+    return None
+  work = dist.all_gather_into_tensor(full, mine, group=group, async_op=async_op)
+  return work if async_op else None
+
+
+def sync_owned_rows(tables, group=None, chunk_bytes=64 << 20):
+  """Every table [N, ...] of `tables` holds current rows only where owner(row) == this rank; afterwards every rank
+  holds every owner's rows.  Masked all-reduce in slabs of about chunk_bytes: each row has exactly one non-zero
+  contributor, so the sum is that contributor's row bit for bit (up to the sign of zero)."""
+  world, rank = dist.get_world_size(group), dist.get_rank(group)
+  for t in tables:
+    n = t.shape[0]
+    row = max(1, t[0].numel() * t.element_size()) if n else 1
+    step = max(1, chunk_bytes // row)
+    for r0 in range(0, n, step):
+      r1 = min(n, r0 + step)
+      own = (torch.arange(r0, r1, device=t.device) % world) == rank
+      part = t[r0:r1] * (own if t.dim() == 1 else own.view(-1, *([1] * (t.dim() - 1))))
+      all_reduce_sum(part, group)
+      t[r0:r1] = part

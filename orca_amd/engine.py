@@ -10,11 +10,14 @@ model/tgn_model.py:172-191.  compute_temporal_embeddings / compute_edge_probabil
 reference's no_grad persist / eval path and the forward half of a train step); train_step adds the loss and the
 backward pass of train.py:225-237 for Paths A and B.  Dropout is off (module.eval()).
 
-Multi-GPU (not in the reference): state tables are replicated, each rank embeds a
-contiguous slice of the batch's (node, t) queries; the rows that later stages read across ranks
-(history rows between layers, updated memory rows) are exchanged with all_gather.  Duplicate
-resolution (last occurrence wins) is applied after the gather in global query order, so N-rank
-results equal 1-rank results.
+Multi-GPU (not in the reference): each rank embeds a contiguous slice of the batch's (node, t)
+queries.  The state rows are owned by node id (owner(id) = id % world): in a train-ordered Path B step only the
+owner of an id runs its memory persist, raw-message store and GRU; the rows other ranks read -- layer outputs for
+the history tables, GRU(message, memory) of the stored ids -- are exchanged with two RCCL all-gathers per step
+into read replicas of the overlay / history tables.  Duplicate resolution (last occurrence wins) is by global
+query position, so N-rank results equal 1-rank results bit for bit.  Eval-ordered steps and the Python-dispatched
+paths (A, C, train_step) run on coherent replicas with the batch's row writes redone on every rank; sync_replicas()
+is the switch from the owner-computes state to that one.
 """
 import ctypes
 
@@ -31,9 +34,14 @@ D = ORCA_D
 
 class OrcaEngine:
   def __init__(self, state_dict, edge_feats, n_nodes, n_layers, n_neighbors, reuse=False, budget=0,
-               device="cuda:0", group=None):
+               device="cuda:0", group=None, sampling="recent", seed=0, exchange_cap=None, pretend=None):
     """state_dict: the TGN state_dict of the reference (key names of SURVEY §8b); edge_feats
-    [n_edges+1, d_e] (row 0 = padding); n_nodes = number of table rows (args.n_nodes, train.py:129)."""
+    [n_edges+1, d_e] (row 0 = padding); n_nodes = number of table rows (args.n_nodes, train.py:129).
+    sampling: "recent" (the reference's NeighborFinder) or "uniform" (seeded, not in the reference: BASELINE
+    config 5) with `seed`.  exchange_cap: rows a rank can send per owner-computes step (default: 1.25 x its even
+    share of the batch's positives + 256, at most all of them); a batch that gives one owner more raises at the
+    next check_errors().  pretend=(rank, world): measurement aid (tools/slice_probe.py) -- behave as that rank of
+    a world with the exchanges stubbed out."""
     self.device = torch.device(device)
     if self.device.type != "cuda":
       raise OrcaError("OrcaEngine needs a HIP device (there is no CPU fallback)")
@@ -45,6 +53,14 @@ class OrcaEngine:
       self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
     else:
       self.rank, self.world = 0, 1
+    self._pretend = pretend is not None
+    if pretend is not None:
+      self.rank, self.world = int(pretend[0]), int(pretend[1])
+    if sampling not in ("recent", "uniform"):
+      raise ValueError(f"OrcaEngine: unknown sampling mode {sampling!r}")
+    self.sampling, self.seed = sampling, int(seed)
+    self.exchange_cap = exchange_cap
+    self._sharded = False    # True: memory / last_update / messages / msg_ts rows are current only on their owner
     dev = self.device
     ef = edge_feats if isinstance(edge_feats, torch.Tensor) else torch.as_tensor(np.asarray(edge_feats))
     self.edge_feats = ef.to(device=dev, dtype=torch.float32).contiguous()
@@ -144,6 +160,7 @@ class OrcaEngine:
     for t in self.hist + self.cache_flag:
       t.zero_()
     self.test_mode = False
+    self._sharded = False
     self._set_overlay_complete(True)       # no pending ids
 
   def _invalidate_overlay(self):
@@ -158,6 +175,7 @@ class OrcaEngine:
 
   # modules/memory.py:39-43, embedding_module.py:83-91
   def backup(self):
+    self.sync_replicas()
     return ([t.clone() for t in (self.memory, self.last_update, self.messages, self.msg_ts, self.pending)],
             [h.clone() for h in self.hist], [c.clone() for c in self.cache_flag])
 
@@ -168,6 +186,7 @@ class OrcaEngine:
       t.copy_(s)
     for t, s in zip(self.cache_flag, b[2]):
       t.copy_(s)
+    self._sharded = False                  # a backup is taken from coherent replicas
     self._set_overlay_complete(False)      # the overlay rows of the restored pending ids are not part of a backup
 
   # -------------------------------------------------------------------------------------------
@@ -204,9 +223,21 @@ class OrcaEngine:
                    dt=torch.zeros(q_max * K, dtype=torch.float32, device=dev),
                    emb=[torch.zeros(q_max, D, dtype=torch.float32, device=dev) for _ in range(2)],
                    winners=torch.zeros(2 * q_max, dtype=torch.uint8, device=dev),
-                   upd=torch.zeros(q_max, D, dtype=torch.float32, device=dev) if self.world > 1 else None,
                    eager_ids=torch.zeros(2 * q_max, dtype=torch.int32, device=dev),
                    eager_count=torch.zeros(2, dtype=torch.int32, device=dev))
+    if self.world > 1:      # exchange buffers of the owner-computes step (include/orca_hip.h)
+      per_max = q_max // self.world
+      worst = max(2 * q_max // 3, 1)                       # every positive of the global batch on one owner
+      cap = self.exchange_cap if self.exchange_cap else min(worst, int(1.25 * 2 * per_max / 3) + 256)
+      self._xm_cap = int(cap)
+      self._xm_chunk = int(L.orca_engine_xm_chunk_words(self._xm_cap))
+      xh_floats = int(L.orca_engine_xh_chunk_floats(per_max)) * self.world
+      self._w.update(xh=[torch.zeros(xh_floats, dtype=torch.float32, device=dev) for _ in range(2)],
+                     xm=torch.zeros(self._xm_chunk * self.world, dtype=torch.int32, device=dev),
+                     own_ids=torch.zeros(q_max, dtype=torch.int32, device=dev),
+                     own_count=torch.zeros(1, dtype=torch.int32, device=dev))
+      if getattr(self, "_err", None) is None:
+        self._err = torch.zeros(1, dtype=torch.int32, device=dev)
     d = _lib.EngineDesc()
     d.n_nodes, d.n_layers, d.K, d.d_e = self.N, self.L, K, self.d_e
     d.csr = self.csr._h if self.csr is not None else None
@@ -225,7 +256,10 @@ class OrcaEngine:
     d.nbr, d.eid, d.et, d.dt = ptr(w["nbr"]), ptr(w["eid"]), ptr(w["et"]), ptr(w["dt"])
     d.emb[0], d.emb[1] = ptr(w["emb"][0]), ptr(w["emb"][1])
     d.winners = ptr(w["winners"])
-    d.upd = ptr(w["upd"]) if w["upd"] is not None else None
+    if self.world > 1:
+      d.world, d.rank = self.world, self.rank
+      d.xh[0], d.xh[1], d.xm, d.xm_cap = ptr(w["xh"][0]), ptr(w["xh"][1]), ptr(w["xm"]), self._xm_cap
+      d.own_ids, d.own_count, d.err = ptr(w["own_ids"]), ptr(w["own_count"]), ptr(self._err)
     d.eager_ids, d.eager_count = ptr(w["eager_ids"]), ptr(w["eager_count"])
     d.att_q_folded = 1     # load_state_dict completes every blob with orca_tgat_pack_gather
     h = _lib.vp()
@@ -262,6 +296,10 @@ class OrcaEngine:
     except Exception:
       pass
 
+  def _step_seed(self):
+    """uniform sampling: the seed of the current batch (same on every rank and in the oracle)"""
+    return (self.seed + self.batch_counter * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+
   def _step_reuse_native(self, src, dst, neg, ts, eidx, train, gather_output=True):
     """Path B + memory/messages through the C++ driver: begin -> (all-gather) -> layer ... -> finish"""
     L = _lib.load()
@@ -270,40 +308,97 @@ class OrcaEngine:
     self._ensure_native(Q)
     lo, hi, per = self._slice(Q)
     st = stream()
-    # a sliced train step on a state that is not overlay-complete exchanges the roots' updated memory rows
-    exchange_upd = self.world > 1 and train and not L.orca_engine_get_overlay_complete(self._native)
+    if self.sampling == "uniform":
+      check(L.orca_engine_set_sampling(self._native, 1, self._step_seed()), "orca_engine_set_sampling")
+    if self.world > 1 and train:
+      return self._step_owner_computes(L, src, dst, neg, ts, eidx, bs, Q, lo, hi, per, st, gather_output)
+    if self.world > 1:                # eval order: replicated row writes on coherent tables
+      self.sync_replicas()
     check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, lo, hi, int(train), st),
           "orca_engine_begin")
     emb = self._w["emb"]
-    if exchange_upd:                  # finish() commits the positives from the gathered rows
-      self._gather_in_place(self._w["upd"], per)
-    def finish():
-      check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
-    # Several ranks: the memory persist and the message store read nothing the later layers write and write
-    # nothing they read (layer >= 2 works on history rows and layer outputs only), so they are enqueued while the
-    # first exchange is in flight instead of after the last layer.  One rank keeps the reference's order: there
-    # the last attention kernel stores the messages itself.
-    early_finish = self.world > 1 and self.L >= 2
     for layer in range(2, self.L + 1):
-      if layer == 2 and early_finish:
-        work = self._gather_in_place(emb[layer & 1], per, async_op=True)
-        finish()
-        if work is not None:
-          work.wait()
-      else:
-        self._gather_in_place(emb[layer & 1], per)
+      self._gather_in_place(emb[layer & 1], per)
       check(L.orca_engine_layer(self._native, layer, lo, hi, st), "orca_engine_layer")
     out = emb[(self.L + 1) & 1]
     if gather_output:
       self._gather_in_place(out, per)
-    if not early_finish:
-      finish()
+    check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
     return out[:Q] if gather_output else out[lo:hi]
+
+  def _step_owner_computes(self, L, src, dst, neg, ts, eidx, bs, Q, lo, hi, per, st, gather_output):
+    """Train-ordered step of several ranks (include/orca_hip.h, orca_engine_desc): this rank embeds its slice and
+    does the batch's row writes for the ids it owns; two all-gathers per step carry the rows other ranks read.
+    The owner's work and the second exchange (updated memory rows) hide behind the first exchange (layer-1 rows
+    for the history tables) and the attention of the later layers."""
+    if not L.orca_engine_get_overlay_complete(self._native):
+      self.sync_replicas()
+      self._rebuild_overlay()
+    check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, lo, hi, 1, st),
+          "orca_engine_begin")
+    xh, xm = self._w["xh"], self._w["xm"]
+    hchunk = int(L.orca_engine_xh_chunk_floats(max(per, 1)))
+    def finish():
+      check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
+      return self._gather_chunks(xm, self._xm_chunk, async_op=True)
+    wm = None
+    for layer in range(2, self.L + 1):
+      wh = self._gather_chunks(xh[layer & 1], hchunk, async_op=True)
+      if layer == 2:
+        wm = finish()
+      if wh is not None:
+        wh.wait()
+      check(L.orca_engine_layer(self._native, layer, lo, hi, st), "orca_engine_layer")
+    if self.L == 1:
+      wm = finish()
+    if wm is not None:
+      wm.wait()
+    check(L.orca_engine_apply(self._native, st), "orca_engine_apply")
+    self._sharded = True
+    out = self._w["emb"][(self.L + 1) & 1]
+    if gather_output:
+      self._gather_in_place(out, per)
+      return out[:Q]
+    return out[lo:hi]
+
+  def _gather_chunks(self, buf, chunk, async_op=False):
+    """in-place all-gather of the first world x chunk elements of buf: rank r contributes chunk r"""
+    if self._pretend:
+      return None
+    return dist_utils.all_gather_chunks(buf, chunk, self.group, async_op)
+
+  def sync_replicas(self):
+    """Makes the state tables identical on every rank again after owner-computes steps, during which the memory,
+    last_update, messages and msg_ts rows of an id are only kept current by its owner (pending flags, overlay and
+    history rows are replicated all along).  A transition, not a per-step cost: it runs before an eval-ordered
+    step, a Python-dispatched path, a backup; every rank must call it."""
+    if self.world == 1 or not self._sharded or self._pretend:
+      self._sharded = False
+      return
+    dist_utils.sync_owned_rows((self.memory, self.last_update, self.messages, self.msg_ts), self.group)
+    self._sharded = False
+
+  def _rebuild_overlay(self):
+    """overlay[id] = GRU(messages[id], memory[id]) for every pending id, on coherent replicas: re-establishes the
+    overlay-complete state the owner-computes step starts from (after a restore, a weight refresh or
+    Python-dispatched steps)."""
+    if self.all_ids is None:
+      self.all_ids = torch.arange(self.N, dtype=torch.int64, device=self.device)
+    bound = self._build_worklist(None, self.all_ids, self.N)
+    ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory, self.overlay)
+    self._set_overlay_complete(True)
+
+  def check_errors(self):
+    """raises if a device-side error word is set (synchronises): an owner-computes exchange that overflowed"""
+    err = getattr(self, "_err", None)
+    if err is not None and int(err.item()) & 1:
+      raise OrcaError(f"OrcaEngine: a rank owned more than exchange_cap={self._xm_cap} of a batch's distinct positive "
+                      "ids; results after that step are invalid -- construct the engine with a larger exchange_cap")
 
   def _gather_in_place(self, buf, per, async_op=False):
     """every rank's rows [rank*per, rank*per+per) of buf -> all ranks (RCCL all-gather, in place).  async_op:
     returns the work handle (None when the exchange already completed) -- wait() before reading the rows."""
-    if self.world == 1:
+    if self.world == 1 or self._pretend:
       return None
     import torch.distributed as dist
     full = buf[:self.world * per]
@@ -339,6 +434,7 @@ class OrcaEngine:
 
   def _flush_all_pending(self):
     """memory_updater.update_memory_in_test (:42-53)."""
+    self.sync_replicas()
     if self.all_ids is None:
       self.all_ids = torch.arange(self.N, dtype=torch.int64, device=self.device)
     bound = self._build_worklist(None, self.all_ids, self.N)
@@ -347,8 +443,12 @@ class OrcaEngine:
     ops.fill_u8(self.pending, 0)
     self._set_overlay_complete(True)       # no pending ids left
 
-  def _sample(self, nodes, ts):
-    nbr, eid, _, dt = self._timed("sample_recent", ops.sample_recent, self.csr, nodes, ts, self.K)
+  def _sample(self, nodes, ts, q0=0):
+    if self.sampling == "uniform":
+      nbr, eid, _, dt = self._timed("sample_recent", ops.sample_uniform, self.csr, nodes, ts, self.K, self._step_seed(),
+                                    q0=q0)
+    else:
+      nbr, eid, _, dt = self._timed("sample_recent", ops.sample_recent, self.csr, nodes, ts, self.K)
     return nbr, eid, dt
 
   def _attend(self, layer, Q, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr_idx, from_memory):
@@ -404,7 +504,7 @@ class OrcaEngine:
     lo, hi, per = self._slice(Q)
     my_nodes = nodes[lo:hi]
     n = my_nodes.numel()
-    nbr, eid, dt = self._sample(my_nodes, ts[lo:hi])
+    nbr, eid, dt = self._sample(my_nodes, ts[lo:hi], q0=lo)
     if train:                                         # :159-161
       self._overlay_updated_memory(nbr, my_nodes)
     emb = self._attend(1, n, nbr, eid, dt, train, self.memory, my_nodes.to(torch.int32), self.memory, nbr, True)
@@ -486,6 +586,9 @@ class OrcaEngine:
       # end to end in the native driver (embedding, memory persist, message store): Path B, and the reference's
       # default configuration (n_layer = 1, no reuse: BASELINE config 1)
       return self._step_reuse_native(src, dst, neg, ts, eidx, train, gather_output)
+    if self.sampling == "uniform" and not (self.reuse and self.budget == 0):
+      raise OrcaError("OrcaEngine: uniform sampling is wired into Path B (--reuse) and the one-layer exact path only")
+    self.sync_replicas()
     self._set_overlay_complete(False)      # the Python-dispatched paths store messages without overlay rows
     nodes = torch.cat([src, dst, neg])
     t3 = torch.cat([ts, ts, ts])
@@ -540,6 +643,7 @@ class OrcaEngine:
     ts = self._dev(ts, torch.float64)
     self.batch_counter += 1
     self.test_mode = False
+    self.sync_replicas()
     self._set_overlay_complete(False)
     bs = src.numel()
     nodes = torch.cat([src, dst, neg])
@@ -553,7 +657,7 @@ class OrcaEngine:
     # per attention call (layer, rows, sample, inputs of orca_tgat_inputs that differ between the paths) ----
     steps = []
     if self.reuse:                                       # embedding_module.py:154-182
-      nbr, eid, dt = self._sample(my_nodes, t3[lo:hi])
+      nbr, eid, dt = self._sample(my_nodes, t3[lo:hi], q0=lo)
       self._overlay_updated_memory(nbr, my_nodes)
       my32 = my_nodes.to(torch.int32)
       emb = self._attend(1, n, nbr, eid, dt, True, self.memory, my32, self.memory, nbr, True)

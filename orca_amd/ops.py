@@ -112,7 +112,9 @@ def sample_recent(csr, nodes, ts, K, with_dt=True, err_flag=None):
   return nbr, eid, et, dt
 
 
-def sample_uniform(csr, nodes, ts, K, seed, err_flag=None):
+def sample_uniform(csr, nodes, ts, K, seed, err_flag=None, q0=0):
+  """orca_sample_uniform (not in the reference): K seeded draws with replacement among the entries before t, in
+  time order; q0 = index of nodes[0] in the caller's query numbering (the RNG key)."""
   nodes = _dev(nodes, torch.int64, "sample_uniform nodes")
   ts = _dev(ts, torch.float64, "sample_uniform ts")
   Q = nodes.numel()
@@ -121,8 +123,8 @@ def sample_uniform(csr, nodes, ts, K, seed, err_flag=None):
   eid = torch.empty((Q, K), dtype=torch.int32, device=dev)
   et = torch.empty((Q, K), dtype=torch.float32, device=dev)
   dt = torch.empty((Q, K), dtype=torch.float32, device=dev)
-  check(_lib.load().orca_sample_uniform(csr._h, ptr(nodes), ptr(ts), Q, K, int(seed), ptr(nbr), ptr(eid), ptr(et),
-                                        ptr(dt), ptr(err_flag), stream()), "orca_sample_uniform")
+  check(_lib.load().orca_sample_uniform(csr._h, ptr(nodes), ptr(ts), Q, K, int(seed), int(q0), ptr(nbr), ptr(eid),
+                                        ptr(et), ptr(dt), ptr(err_flag), stream()), "orca_sample_uniform")
   return nbr, eid, et, dt
 
 

@@ -20,8 +20,27 @@ def _worker(rank, world, port, q):
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
   dist.init_process_group("gloo", rank=rank, world_size=world)
-  from orca_amd.dist import all_gather_rows, all_reduce_sum, query_slice
+  from orca_amd.dist import all_gather_chunks, all_gather_rows, all_reduce_sum, query_slice, sync_owned_rows
   ok = True
+  # chunk exchange of the owner-computes step: rank r fills chunk r, everybody ends with all chunks
+  for chunk in (1, 64, 1000):
+    buf = torch.full((world * chunk + 5,), -1, dtype=torch.int32)
+    buf[rank * chunk:(rank + 1) * chunk] = torch.arange(chunk, dtype=torch.int32) + 1000 * rank
+    w = all_gather_chunks(buf, chunk, dist.group.WORLD, async_op=True)
+    if w is not None:
+      w.wait()
+    exp = torch.cat([torch.arange(chunk, dtype=torch.int32) + 1000 * r for r in range(world)])
+    ok = ok and torch.equal(buf[:world * chunk], exp) and bool((buf[world * chunk:] == -1).all())
+  # owner rows -> coherent replicas: rows current only on their owner (id % world), garbage elsewhere
+  gen = torch.Generator().manual_seed(3)
+  truth = [torch.randn(37, 5, generator=gen), torch.randn(37, generator=gen)]
+  mine = []
+  for t in truth:
+    own = (torch.arange(37) % world) == rank
+    m = torch.where(own.view(-1, *([1] * (t.dim() - 1))), t, torch.full_like(t, 123.0 + rank))
+    mine.append(m)
+  sync_owned_rows(mine, dist.group.WORLD, chunk_bytes=160)      # several slabs
+  ok = ok and all(torch.equal(a, b) for a, b in zip(mine, truth))
   g = all_reduce_sum(torch.full((7,), float(rank + 1)), dist.group.WORLD)       # the gradient all-reduce of train_step
   ok = ok and torch.equal(g, torch.full((7,), world * (world + 1) / 2.0))
   for Q in (0, 1, 2, 5, 64, 4095, 4096):

@@ -288,3 +288,82 @@ def test_native_driver_long_run_vs_dispatched_path():
       assert_close_fp32(native.messages.cpu().numpy(), plain.messages.cpu().numpy(), 1e-5, f"batch {b} messages")
       assert torch.equal(native.pending, plain.pending) and torch.equal(native.last_update, plain.last_update)
       assert torch.equal(native.msg_ts, plain.msg_ts)
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_uniform_k20_engine_vs_oracle(golden, native):
+  """BASELINE config 5's sampler in the step driver: K = 20 seeded-uniform neighbours (not in the reference:
+  parity unpinned, GPU == the oracle's CPU twin), zero-feature edges (d_e = 1), 2 layers with reuse.  The sampled
+  ids must equal the twin's bit for bit (checked through the embeddings' inputs: nbr / eid / dt buffers of the
+  driver) and embeddings / state agree with the oracle at 1e-5, natively and Python-dispatched."""
+  from orca_amd import ops, synth
+  from orca_amd.engine import OrcaEngine
+  N, E, K, bs = 20000, 300000, 20, 700
+  src, dst, ts, eidx, _ = _synthetic(41, N, E, 1)
+  ef = np.zeros((E + 1, 1), np.float32)
+  sd = {k: v.numpy() for k, v in synth.tgn_state_dict(1, 2, seed=9).items()}
+  eng = OrcaEngine(sd, ef, N + 1, 2, K, True, 0, device=DEV, sampling="uniform", seed=1234)
+  eng.set_neighbor_finder(ops.CSR.from_edges_device(*(torch.from_numpy(x).to(DEV) for x in (src, dst, eidx, ts)), N + 1))
+  if not native:
+    eng.prof = {}
+  ref = O.OracleTGN(sd, ef, N + 1, 2, K, True, 0)
+  ref.neighbor_finder = O.OracleNeighborFinder(src, dst, eidx, ts, max_node_idx=N)
+  ref.uniform_seed = 1234
+  rs = np.random.RandomState(42)
+  n_hist = 250000
+  for b in range(3):
+    s, e = n_hist + b * bs, n_hist + (b + 1) * bs
+    neg = rs.randint(1, N + 1, bs).astype(np.int64)
+    emb = eng.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True).cpu().numpy()
+    exp = ref.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True).numpy()
+    if native:      # the driver's sampler buffers against the twin, bit for bit
+      nodes = np.concatenate([src[s:e], dst[s:e], neg])
+      seed = (1234 + ref.batch_counter * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+      nbr, eid, et, dt = O.sample_uniform(ref.neighbor_finder, nodes, np.concatenate([ts[s:e]] * 3), K, seed)
+      Q = 3 * bs
+      assert np.array_equal(eng._w["nbr"][:Q * K].cpu().numpy().reshape(Q, K), nbr)
+      assert np.array_equal(eng._w["eid"][:Q * K].cpu().numpy().reshape(Q, K), eid)
+      assert np.array_equal(eng._w["dt"][:Q * K].cpu().numpy().view(np.uint32).reshape(Q, K), dt.view(np.uint32))
+    eng.prof = {} if not native else None
+    assert_close_fp32(emb, exp, 1e-5, f"batch {b} emb")
+    assert_close_fp32(eng.memory.cpu().numpy(), ref.memory.numpy(), 1e-5, f"batch {b} memory")
+    assert_close_fp32(eng.hist[0].cpu().numpy(), ref.hist[0].numpy(), 1e-5, f"batch {b} history")
+    assert np.array_equal(eng.pending.cpu().numpy().astype(bool), ref.pending)
+  assert_close_fp32(eng.messages.cpu().numpy(), ref.messages.numpy(), 1e-5, "messages")
+
+
+def test_refresh_with_new_gru_weights_drops_stale_overlay(golden):
+  """overlay rows are GRU(message, memory) computed once per stored message; after the GRU weights
+  change (an optimizer step + refresh) every pending id's row is stale and must be recomputed with the new weights,
+  as the reference recomputes get_updated_memory on every batch (memory_updater.py:56-78)."""
+  from orca_amd import ops
+  from orca_amd.engine import OrcaEngine
+  g = golden("tgn.npz")
+  sd = {k[len("g172_sd."):]: g[k] for k in g.files if k.startswith("g172_sd.")}
+  N, E, K, bs = 5000, 80000, 10, 300
+  src, dst, ts, eidx, ef = _synthetic(51, N, E, 172)
+  csr = ops.CSR.from_edges_device(*(torch.from_numpy(x).to(DEV) for x in (src, dst, eidx, ts)), N + 1)
+  eng = OrcaEngine(sd, ef, N + 1, 2, K, True, 0, device=DEV)
+  eng.set_neighbor_finder(csr)
+  rs = np.random.RandomState(52)
+  negs = [rs.randint(1, N + 1, bs).astype(np.int64) for _ in range(4)]
+
+  def batch(b):
+    s, e = 60000 + b * bs, 60000 + (b + 1) * bs
+    return src[s:e], dst[s:e], negs[b], ts[s:e], eidx[s:e]
+
+  eng.reset_state()
+  for b in range(3):
+    eng.compute_temporal_embeddings(*batch(b), True)
+  bk = eng.backup()
+  with torch.no_grad():
+    for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+      eng.params["memory_updater.memory_updater." + k].mul_(0.5)
+  eng.refresh()
+  got = eng.compute_temporal_embeddings(*batch(3), True).clone()
+  fresh = OrcaEngine({k: v.cpu() for k, v in eng.params.items()}, ef, N + 1, 2, K, True, 0, device=DEV)
+  fresh.set_neighbor_finder(csr)
+  fresh.restore(bk)
+  exp = fresh.compute_temporal_embeddings(*batch(3), True)
+  assert_close_fp32(got.cpu().numpy(), exp.cpu().numpy(), 1e-6, "embeddings after refresh")
+  assert_close_fp32(eng.memory.cpu().numpy(), fresh.memory.cpu().numpy(), 1e-6, "memory after refresh")

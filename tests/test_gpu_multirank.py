@@ -1,6 +1,9 @@
-"""N-rank == 1-rank equality of the partitioned step: two ranks share the one GPU of
+"""N-rank == 1-rank equality of the partitioned step: several ranks share the one GPU of
 the test box and exchange rows over gloo (RCCL refuses two ranks on one device; bench.py uses "nccl" on
-the 8-GPU node).  Results must be bit-identical to the single-rank engine on the same batches."""
+the 8-GPU node).  Results must be bit-identical to the single-rank engine on the same batches.
+
+Train-ordered Path B steps run the owner-computes route (state rows owned by id % world, two all-gathers per step);
+eval-ordered steps, Paths A / C and train_step run on coherent replicas."""
 import os
 import socket
 
@@ -21,12 +24,23 @@ def _free_port():
   return p
 
 
-def _worker(rank, world, port, q):
+def _state_equal(multi, single, reuse):
+  multi.sync_replicas()     # owner rows -> every replica (collective: every rank calls it)
+  ok = torch.equal(multi.memory, single.memory)
+  ok = ok and torch.equal(multi.messages, single.messages) and torch.equal(multi.pending, single.pending)
+  ok = ok and torch.equal(multi.last_update, single.last_update) and torch.equal(multi.msg_ts, single.msg_ts)
+  if reuse:
+    ok = ok and all(torch.equal(a, b) for a, b in zip(multi.hist, single.hist))
+  return ok
+
+
+def _worker(rank, world, port, q, full):
   try:
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from orca_amd import ops, synth
+    from orca_amd.dist import query_slice
     from orca_amd.engine import OrcaEngine
     dev = "cuda:0"
     N, E, bs, K, d_e = 3000, 60000, 301, 10, 172
@@ -36,82 +50,116 @@ def _worker(rank, world, port, q):
     csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
     g = torch.Generator(device=dev)
     g.manual_seed(9)
-    ok = True
-    for reuse in (True, False):
+    ok, msg = True, ""
+
+    def batch(b):
+      s, e = 50000 + b * bs, 50000 + (b + 1) * bs
+      return src[s:e], dst[s:e], torch.randint(1, N + 1, (bs,), generator=g, device=dev), ts[s:e], eidx[s:e]
+
+    for reuse in ((True, False) if full else (True,)):
       multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=reuse, device=dev, group=dist.group.WORLD)
       single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=reuse, device=dev, group=None)
       multi.set_neighbor_finder(csr)
       single.set_neighbor_finder(csr)
-      for b in range(7):
-        s, e = 50000 + b * bs, 50000 + (b + 1) * bs
-        neg = torch.randint(1, N + 1, (bs,), generator=g, device=dev)
-        train = b != 3
-        if b == 5:      # a restored backup drops the overlay-complete state: the sliced step then builds per-batch
-          multi.restore(multi.backup())      # work-lists and exchanges the roots' updated rows
+      for b in range(9):
+        bt = batch(b)
+        train = b not in (3, 4)
+        if b == 6:      # a restored backup drops the overlay-complete state: the owner-computes step rebuilds the
+          multi.restore(multi.backup())      # overlay rows of the pending ids first
           single.restore(single.backup())
-        sharded = reuse and b in (2, 6)     # outputs left on the rank that computed them (bench.py, N > 1)
-        a = multi.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], train,
-                                              gather_output=not sharded)
-        c = single.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], train)
+        sharded = reuse and b in (2, 7)     # outputs left on the rank that computed them (bench.py, N > 1)
+        a = multi.compute_temporal_embeddings(*bt, train, gather_output=not sharded)
+        c = single.compute_temporal_embeddings(*bt, train)
         if sharded:
-          from orca_amd.dist import query_slice
           lo, hi, _ = query_slice(3 * bs, rank, world)
           c = c[lo:hi]
-        ok = ok and torch.equal(a, c) and torch.equal(multi.memory, single.memory)
-        ok = ok and torch.equal(multi.messages, single.messages) and torch.equal(multi.pending, single.pending)
-        ok = ok and torch.equal(multi.last_update, single.last_update) and torch.equal(multi.msg_ts, single.msg_ts)
-        if reuse:
-          ok = ok and torch.equal(multi.hist[0], single.hist[0])
-    # Path C (budgeted reuse with a cache plan per batch): global set algebra on every rank, attention partitioned
-    multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=dist.group.WORLD)
-    single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None)
+        step_ok = torch.equal(a, c)
+        if b in (1, 4, 8) or not reuse:       # also mid-stream: sync, compare, and carry on from coherent replicas
+          step_ok = step_ok and _state_equal(multi, single, reuse)
+        if not step_ok and not msg:
+          msg = f"reuse={reuse} batch {b}: embeddings or state differ from the single-rank engine"
+        ok = ok and step_ok
+      multi.check_errors()
+    # three layers (two history exchanges per step), 20 uniformly sampled neighbours, zero-feature edges
+    # (BASELINE config 5's sampler and width): owner-computes steps only
+    ef1 = torch.zeros(E + 1, 1, device=dev)
+    sd3 = synth.tgn_state_dict(1, 3, seed=4)
+    multi = OrcaEngine(sd3, ef1, N + 1, 3, 20, reuse=True, device=dev, group=dist.group.WORLD, sampling="uniform", seed=77)
+    single = OrcaEngine(sd3, ef1, N + 1, 3, 20, reuse=True, device=dev, group=None, sampling="uniform", seed=77)
     multi.set_neighbor_finder(csr)
     single.set_neighbor_finder(csr)
-    for b in range(3):
-      s, e = 50000 + b * bs, 50000 + (b + 1) * bs
-      neg = torch.randint(1, N + 1, (bs,), generator=g, device=dev)
-      plan = torch.randint(1, N + 1, (40,), generator=g, device=dev)
-      a = multi.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True, plan)
-      c = single.compute_temporal_embeddings(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e], True, plan)
-      ok = ok and torch.equal(a, c) and torch.equal(multi.memory, single.memory)
-      ok = ok and torch.equal(multi.hist[0], single.hist[0]) and torch.equal(multi.cache_flag[0], single.cache_flag[0])
-    # training step: every rank back-propagates its slice, parameter gradients are all-reduced; the sums associate
-    # differently from the single-rank step, so gradients are compared at 1e-5 and the state bit for bit
-    multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, device=dev, group=dist.group.WORLD)
-    single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, device=dev, group=None)
-    multi.set_neighbor_finder(csr)
-    single.set_neighbor_finder(csr)
-    msg = ""
     for b in range(4):
-      s, e = 50000 + b * bs, 50000 + (b + 1) * bs
-      neg = torch.randint(1, N + 1, (bs,), generator=g, device=dev)
-      la, ga = multi.train_step(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e])
-      lc, gc = single.train_step(src[s:e], dst[s:e], neg, ts[s:e], eidx[s:e])
-      ok = ok and abs(float(la) - float(lc)) <= 1e-6 and set(ga) == set(gc)
-      for k in gc:
-        scale = max(float(gc[k].abs().max()), 1e-12)
-        err = float((ga[k] - gc[k]).abs().max()) / scale
-        if err > 1e-5:
-          ok, msg = False, f"train_step gradient {k} differs between 2 ranks and 1 rank: rel {err:.2e}"
-      ok = ok and torch.equal(multi.memory, single.memory) and torch.equal(multi.messages, single.messages)
-      ok = ok and torch.equal(multi.hist[0], single.hist[0])
+      bt = batch(b)
+      a = multi.compute_temporal_embeddings(*bt, True)
+      c = single.compute_temporal_embeddings(*bt, True)
+      if not torch.equal(a, c) and not msg:
+        msg = f"3 layers / uniform K=20: batch {b} differs"
+      ok = ok and torch.equal(a, c)
+    ok = ok and _state_equal(multi, single, True)
+    # an owner that holds more distinct positives than exchange_cap must say so
+    small = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, device=dev, group=dist.group.WORLD, exchange_cap=8)
+    small.set_neighbor_finder(csr)
+    small.compute_temporal_embeddings(*batch(0), True)
+    try:
+      small.check_errors()
+      ok, msg = False, msg or "exchange overflow was not reported"
+    except Exception as ex:
+      if "exchange_cap" not in str(ex):
+        raise
+    if full:
+      # Path C (budgeted reuse with a cache plan per batch): global set algebra on every rank, attention partitioned
+      multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=dist.group.WORLD)
+      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None)
+      multi.set_neighbor_finder(csr)
+      single.set_neighbor_finder(csr)
+      for b in range(3):
+        bt = batch(b)
+        plan = torch.randint(1, N + 1, (40,), generator=g, device=dev)
+        a = multi.compute_temporal_embeddings(*bt, True, plan)
+        c = single.compute_temporal_embeddings(*bt, True, plan)
+        ok = ok and torch.equal(a, c) and torch.equal(multi.memory, single.memory)
+        ok = ok and torch.equal(multi.hist[0], single.hist[0]) and torch.equal(multi.cache_flag[0], single.cache_flag[0])
+      # training step: every rank back-propagates its slice, parameter gradients are all-reduced; the sums associate
+      # differently from the single-rank step, so gradients are compared at 1e-5 and the state bit for bit.  Forward
+      # steps in between switch the state between the owner-computes and the coherent form.
+      multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, device=dev, group=dist.group.WORLD)
+      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, device=dev, group=None)
+      multi.set_neighbor_finder(csr)
+      single.set_neighbor_finder(csr)
+      for b in range(5):
+        bt = batch(b)
+        if b == 2:
+          a = multi.compute_temporal_embeddings(*bt, True)
+          c = single.compute_temporal_embeddings(*bt, True)
+          ok = ok and torch.equal(a, c)
+          continue
+        la, ga = multi.train_step(*bt)
+        lc, gc = single.train_step(*bt)
+        ok = ok and abs(float(la) - float(lc)) <= 1e-6 and set(ga) == set(gc)
+        for k in gc:
+          scale = max(float(gc[k].abs().max()), 1e-12)
+          err = float((ga[k] - gc[k]).abs().max()) / scale
+          if err > 1e-5:
+            ok, msg = False, f"train_step gradient {k} differs between {world} ranks and 1 rank: rel {err:.2e}"
+        ok = ok and torch.equal(multi.memory, single.memory) and torch.equal(multi.messages, single.messages)
+        ok = ok and torch.equal(multi.hist[0], single.hist[0])
     q.put((rank, bool(ok), msg))
     dist.barrier()
     dist.destroy_process_group()
-  except Exception as ex:   # surface the failure in the parent
+  except Exception:   # surface the failure in the parent
     import traceback
     q.put((rank, False, traceback.format_exc()))
 
 
-def test_two_ranks_equal_one_rank():
-  world = 2
+@pytest.mark.parametrize("world,full", [(2, True), (4, False)])
+def test_ranks_equal_one_rank(world, full):
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
   port = _free_port()
-  ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+  ps = [ctx.Process(target=_worker, args=(r, world, port, q, full)) for r in range(world)]
   for p in ps:
     p.start()
-  res = [q.get(timeout=240) for _ in range(world)]
+  res = [q.get(timeout=300) for _ in range(world)]
   for p in ps:
     p.join(timeout=60)
   for r, ok, msg in res:
