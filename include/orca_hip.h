@@ -340,22 +340,23 @@ typedef struct {
   /* ---- several ranks (not in the reference): owner-computes sharding of the state ----
    * owner(id) = id % world.  In a train-ordered step every rank embeds its slice of the batch's root queries and
    * runs the memory persist, the raw-message store and the GRU only for the ids it owns; the rows other ranks
-   * read are exchanged through the two buffers below, which the CALLER all-gathers (RCCL) between the calls:
-   *   xh[b]: world chunks of orca_engine_xh_chunk_floats(per) floats, per = ceil(Q / world) of the current batch:
-   *          [per rows of ORCA_D floats | per winner bytes]: a rank's layer outputs for its slice and the
-   *          last-occurrence flags of its roots WITHIN the slice; layer l writes xh[(l+1)&1];
-   *   xm   : world chunks of orca_engine_xm_chunk_words(xm_cap) 32-bit words: [count, 63 unused | ids[xm_cap] |
+   * read are exchanged through buffers the CALLER all-gathers (RCCL) between the calls:
+   *   emb[b]: rank-major, 3*per rows per rank, per = ceil(bs / world): a rank embeds the src, dst and neg roots of
+   *          ITS INTERACTIONS [lo, hi) = [rank*per, ...) (rows [src | dst | neg] of that range, the layout a
+   *          data-parallel link decoder wants, and the same mix of hub and random roots on every rank); layer l
+   *          reads the gathered emb[l&1] -- the history push is applied from it on every rank's replica;
+   *   xm    : world chunks of orca_engine_xm_chunk_words(xm_cap) 32-bit words: [count, 63 unused | ids[xm_cap] |
    *          rows[xm_cap][ORCA_D]]: GRU(message, memory) of the ids a rank owns among the batch's positives.
    * world <= 1: all of these may be 0 / NULL. */
   int32_t world, rank;
-  float* xh[2];
   int32_t* xm;
   int64_t xm_cap;                  /* rows a rank can send per step; more owned ids than this set bit 0 of *err */
   int32_t* own_ids;                /* [q_max] the distinct ids this rank owns among the batch's positives */
+  int32_t* own_pos;                /* [q_max] the position of the last occurrence of each in [src;dst] */
   int32_t* own_count;              /* [1], zero-initialised by the caller */
+  int64_t* slot_m;                 /* [n_nodes] second election table (message list; `slot` serves the history push) */
   int32_t* err;                    /* [1] device error word, zero-initialised by the caller (bit 0: xm overflow) */
 } orca_engine_desc;
-int64_t orca_engine_xh_chunk_floats(int64_t per);
 int64_t orca_engine_xm_chunk_words(int64_t cap);
 
 /* Neighbour sampling of the step driver: ORCA_SAMPLE_RECENT (utils/util.py:134-151, the reference's only mode) or
@@ -381,8 +382,8 @@ int orca_engine_set_csr(orca_engine_t* e, const orca_csr_t* csr);           /* t
 /* hands out n consecutive epochs of the shared `slot` table (for callers that use it between steps) */
 int64_t orca_engine_take_epochs(orca_engine_t* e, int64_t n);
 /* With world > 1 a train-ordered step is the owner-computes step (it needs an overlay-complete state and the
- * exchange buffers); the caller's sequence is
- *   begin -> [all-gather xh[0]] -> finish -> [all-gather xm] -> layer 2 .. L (all-gather xh[(l+1)&1] between
+ * exchange buffers; lo / hi of begin and layer are then bounds in INTERACTIONS, not roots); the caller's sequence is
+ *   begin -> [all-gather emb[0]] -> finish -> [all-gather xm] -> layer 2 .. L (all-gather emb[(l+1)&1] between
  *   layers) -> apply.
  * finish may be enqueued while the first all-gather is in flight; apply must follow the xm all-gather and precede
  * the next begin.  Eval-ordered steps with world > 1 run on replicated tables: every rank redoes the row writes of

@@ -44,8 +44,9 @@ class EngineDesc(ctypes.Structure):
                ("hist", vp * (ORCA_ENGINE_MAX_LAYERS - 1)), ("slot", vp), ("worklist", vp), ("count", vp),
                ("q_max", i64), ("nodes", vp), ("qts", vp), ("nodes32", vp), ("nbr", vp), ("eid", vp), ("et", vp),
                ("dt", vp), ("emb", vp * 2), ("winners", vp), ("eager_ids", vp), ("eager_count", vp),
-               ("att_q_folded", ctypes.c_int32), ("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("xh", vp * 2),
-               ("xm", vp), ("xm_cap", i64), ("own_ids", vp), ("own_count", vp), ("err", vp)])
+               ("att_q_folded", ctypes.c_int32), ("world", ctypes.c_int32), ("rank", ctypes.c_int32),
+               ("xm", vp), ("xm_cap", i64), ("own_ids", vp), ("own_pos", vp), ("own_count", vp), ("slot_m", vp),
+               ("err", vp)])
 
 
 # name -> (restype, argtypes); every symbol include/orca_hip.h declares
@@ -101,7 +102,6 @@ SIGNATURES = {
     "orca_engine_layer": (i32, [vp, i32, i64, i64, vp]),
     "orca_engine_finish": (i32, [vp, vp, vp, vp, vp, vp]),
     "orca_engine_apply": (i32, [vp, vp]),
-    "orca_engine_xh_chunk_floats": (i64, [i64]),
     "orca_engine_xm_chunk_words": (i64, [i64]),
     "orca_engine_set_sampling": (i32, [vp, i32, u64]),
     "orca_engine_set_overlay_complete": (i32, [vp, i32]),

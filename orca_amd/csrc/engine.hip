@@ -28,8 +28,8 @@ struct orca_engine {
   bool persist_done;           // the memory persist of the batch was fused into attention layer 1
   int pushed_layer;            // output of this layer is already in its history table (fused push), 0 = none
   bool sharded;                // owner-computes step (several ranks, train order): see orca_engine_begin
-  int64_t per;                 // rows per rank slice of the current batch = ceil(Q / world)
-  int64_t xh_chunk;            // floats per rank chunk of the xh buffers for this batch
+  int64_t per;                 // owner-computes step: interactions per rank of the current batch = ceil(bs / world)
+  int64_t epoch_push, epoch_msg;   // owner-computes step: the election values begin() claimed on slot / slot_m
   int sampling;                // ORCA_SAMPLE_*
   uint64_t seed;               // uniform sampling: seed of the next step
   bool store_done;             // the raw-message store of the batch was fused into the last attention layer
@@ -69,14 +69,10 @@ __device__ __forceinline__ int elect_part(int64_t id, int parts) { return (int)(
 // full, so every occurrence of that id takes the same route and the result stays exact.
 constexpr int ELECT_UNROLL = 6;            // ids a thread has in flight (one pass covers a full table's worth)
 
-// own_world > 1: only the ids with id % own_world == own_rank take part (owner-computes sharding); the positions of
-// the others get winner = 0 (written by part 0, like the invalid ids).
 template <typename GetId>
 __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64_t n, int64_t n_nodes, GetId get,
                                              uint8_t* __restrict__ winner, int part, int parts,
-                                             int32_t* __restrict__ list, int32_t* __restrict__ list_count,
-                                             int own_world = 1, int own_rank = 0) {
-  auto owned = [&](int64_t v) { return own_world <= 1 || (int)((uint32_t)v % (uint32_t)own_world) == own_rank; };
+                                             int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
   constexpr int64_t CHUNK = (int64_t)ELECT_UNROLL * ELECT_THREADS;
   // the first chunk's ids are requested before the table is cleared: their round trip hides behind the clear
   int64_t id[ELECT_UNROLL];
@@ -96,7 +92,7 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
 #pragma unroll
     for (int u = 0; u < ELECT_UNROLL; ++u) {
       const int64_t p = p0 + (int64_t)u * ELECT_THREADS + threadIdx.x, v = id[u];
-      if (v < 0 || v >= n_nodes || !owned(v) || elect_part(v, parts) != part) continue;
+      if (v < 0 || v >= n_nodes || elect_part(v, parts) != part) continue;
       uint32_t h = ((uint32_t)v * 2654435761u) >> 19;
       int probes = 0;
       for (; probes < ELECT_SLOTS; ++probes) {
@@ -115,8 +111,8 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
 #pragma unroll
     for (int u = 0; u < ELECT_UNROLL; ++u) {
       const int64_t p = p0 + (int64_t)u * ELECT_THREADS + threadIdx.x, v = id[u];
-      const bool valid = v >= 0 && v < n_nodes && owned(v);
-      const bool mine = p < n && (valid ? elect_part(v, parts) == part : part == 0);   // invalid / foreign ids: cleared by part 0
+      const bool valid = v >= 0 && v < n_nodes;
+      const bool mine = p < n && (valid ? elect_part(v, parts) == part : part == 0);   // invalid ids: cleared by part 0
       uint8_t w = 0;
       if (mine && valid) {
         uint32_t h = ((uint32_t)v * 2654435761u) >> 19;
@@ -147,20 +143,55 @@ __device__ __forceinline__ void elect_in_lds(int32_t* keys, int32_t* vals, int64
   }
 }
 
+// Segmented election for long lists (the global lists of a multi-rank step): this workgroup takes the ELECT_SEG
+// positions from p0 on, finds the last occurrence of each id among them in an LDS table (never more than ELECT_SEG
+// distinct ids in ELECT_SLOTS slots: no overflow), and publishes those with atomicMax(slot[id], epoch + p).  After the
+// kernel p is the last occurrence of its id in the whole list iff slot[id] == epoch + p.  An id has at most one
+// contender per segment, so hub ids do not serialise at L2 the way a per-position atomicMax does.  own_world > 1:
+// only the ids with id % own_world == own_rank take part.
+constexpr int ELECT_SEG = ELECT_THREADS;         // one id per thread: many short workgroups beside the sampler's waves
+constexpr int ELECT_SEG_SLOTS = 2048;            // table of a segment (load factor <= 0.5)
+template <typename GetId>
+__device__ __forceinline__ void elect_segment(int32_t* keys, int32_t* vals, int64_t p0, int64_t n, int64_t n_nodes,
+                                              GetId get, int64_t* __restrict__ slot, int64_t epoch, int own_world,
+                                              int own_rank) {
+  const int64_t p = p0 + threadIdx.x;
+  int64_t v = get(p < n ? p : n - 1);
+  if (p >= n || v < 0 || v >= n_nodes || (own_world > 1 && (int)((uint32_t)v % (uint32_t)own_world) != own_rank)) v = -1;
+  for (int i = threadIdx.x; i < ELECT_SEG_SLOTS; i += ELECT_THREADS) { keys[i] = -1; vals[i] = -1; }
+  __syncthreads();
+  uint32_t h = ((uint32_t)v * 2654435761u) >> 21;
+  if (v >= 0) {
+    for (;;) {
+      const int32_t old = atomicCAS(&keys[h], -1, (int32_t)v);
+      if (old == -1 || old == (int32_t)v) break;
+      h = (h + 1) & (ELECT_SEG_SLOTS - 1);
+    }
+    atomicMax(&vals[h], (int)threadIdx.x);
+  }
+  __syncthreads();
+  if (v >= 0 && vals[h] == (int)threadIdx.x)
+    atomicMax(reinterpret_cast<unsigned long long*>(&slot[v]), (unsigned long long)(epoch + p));
+}
+
 // First kernel of a step.  Query block b < nbs (block index ne + b), wave w: root query i = lo + 16 b + w of [src;dst;neg] x [t;t;t]
 // (tgn_model.py:99-102) is written to nodes / qts / nodes32 and, when i lies in this rank's slice [lo, hi), its K
 // neighbours are sampled into row i - lo of the sampler outputs (embedding_module.py:157), with the claim pass of
 // the overlay work-list in train order.
-// blocks 0 .. ne_m-1        (elect only): winners of the raw-message store over [src;dst]  (tgn_model.py:174-176);
-//                           with own_world > 1 only among the ids this rank owns, which also form msg_list
-// blocks ne_m .. ne-1       (elect only): winners of the history push over the roots [push_lo, push_lo + push_n)
-//                           (embedding_module.py:103-113, H7): all 3*bs roots, or this rank's slice
+// blocks 0 .. ne_m-1        (elect only): winners of the raw-message store over [src;dst]  (tgn_model.py:174-176)
+// blocks ne_m .. ne-1       (elect only): winners of the history push over all 3*bs roots (embedding_module.py:103-113, H7)
 // blocks ne .. ne+nb-1: the root queries
+// The elections are either whole-list LDS tables that write a winner byte per position (elect_in_lds: one rank), or
+// -- seg != 0, the owner-computes step of several ranks, whose lists are `world` times longer -- one workgroup per
+// ELECT_SEG positions that publishes its segment's last occurrences with atomicMax on a table in HBM
+// (elect_segment); the message list then only among the ids this rank owns.
 struct begin_elect {
   int ne_m, ne;                 // message-list election blocks, all election blocks
-  int64_t push_lo, push_n;
+  int seg;                      // 0: elect_in_lds (winner bytes); 1: elect_segment (slot tables)
   uint8_t *win_push, *win_msg;
   int32_t *msg_list, *msg_count;
+  int64_t *slot_push, *slot_msg;
+  int64_t epoch_push, epoch_msg;
   int own_world, own_rank;
 };
 struct begin_sample {
@@ -172,7 +203,7 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
     int32_t* __restrict__ nodes32, begin_elect el, int nbs, int64_t n_nodes,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ c_nbr, const int32_t* __restrict__ c_eid,
-    const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int K, begin_sample smp,
+    const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int by_e, int K, begin_sample smp,
     int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt,
     orca_claim claim) {
   __shared__ int32_t keys[ELECT_SLOTS], vals[ELECT_SLOTS];
@@ -183,74 +214,113 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
   // the election workgroups (the longest dependent chains of this launch) take the first block indices so that
   // they are dispatched first
   if ((int)blockIdx.x < el.ne) {
-    if ((int)blockIdx.x < el.ne_m)
-      elect_in_lds(keys, vals, 2 * bs, n_nodes, root, el.win_msg, (int)blockIdx.x, el.ne_m, el.msg_list, el.msg_count,
-                   el.own_world, el.own_rank);
-    else
-      elect_in_lds(keys, vals, el.push_n, n_nodes, [&](int64_t p) { return root(el.push_lo + p); }, el.win_push,
-                   (int)blockIdx.x - el.ne_m, el.ne - el.ne_m, nullptr, nullptr);
+    const int b = (int)blockIdx.x;
+    if (el.seg) {
+      if (b < el.ne_m) elect_segment(keys, vals, (int64_t)b * ELECT_SEG, 2 * bs, n_nodes, root, el.slot_msg, el.epoch_msg, el.own_world, el.own_rank);
+      else elect_segment(keys, vals, (int64_t)(b - el.ne_m) * ELECT_SEG, 3 * bs, n_nodes, root, el.slot_push, el.epoch_push, 1, 0);
+    } else {
+      if (b < el.ne_m) elect_in_lds(keys, vals, 2 * bs, n_nodes, root, el.win_msg, b, el.ne_m, el.msg_list, el.msg_count);
+      else elect_in_lds(keys, vals, 3 * bs, n_nodes, root, el.win_push, b - el.ne_m, el.ne - el.ne_m, nullptr, nullptr);
+    }
     return;
   }
   const int lane = threadIdx.x & 63;
   const int64_t bq = (int64_t)((int)blockIdx.x - el.ne);
+  // this rank's roots: the contiguous slice [lo, hi) of the 3*bs roots, or (by_e, the owner-computes step) the src,
+  // dst and neg roots of the INTERACTIONS [lo, hi) -- local query ql = k * (hi - lo) + (e - lo), root i = k * bs + e
   if (bq >= nbs) {   // query rows of the roots outside this rank's slice: one per thread (a wave each would be 8x the
     const int64_t i = (bq - nbs) * ELECT_THREADS + threadIdx.x;          // workgroups at 8 ranks, for three stores)
-    if (i >= 3 * bs || (i >= lo && i < hi)) return;
+    if (i >= 3 * bs) return;
+    const int64_t e = i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs);
+    if (by_e ? (e >= lo && e < hi) : (i >= lo && i < hi)) return;
     nodes[i] = root(i);
-    nodes32[i] = (int32_t)root(i);
-    qts[i] = ts[i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs)];
+    if (!by_e) nodes32[i] = (int32_t)root(i);
+    qts[i] = ts[e];
     return;
   }
-  const int64_t i = lo + bq * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
-  if (i >= hi) return;
-  const int64_t e = i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs);
+  const int64_t ql = bq * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
+  const int64_t nq = by_e ? 3 * (hi - lo) : hi - lo;
+  if (ql >= nq) return;
+  int64_t i, e;
+  if (by_e) {
+    const int64_t k = ql / (hi - lo);
+    e = lo + ql - k * (hi - lo);
+    i = k * bs + e;
+  } else {
+    i = lo + ql;
+    e = i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs);
+  }
   const int64_t v = root(i);                                            // tgn_model.py:99
   const double t = ts[e];                                               // :102
   if (lane == 0) {
     nodes[i] = v;
-    nodes32[i] = (int32_t)v;
+    nodes32[by_e ? ql : i] = (int32_t)v;      // by_e: in local query order (the source ids of attention layer 1)
     qts[i] = t;
   }
   if (smp.mode == ORCA_SAMPLE_UNIFORM)
-    sample_uniform_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, i - lo, hi - lo, K, smp.seed, i, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
+    sample_uniform_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, ql, nq, K, smp.seed, i, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
   else
-    sample_recent_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, i - lo, hi - lo, K, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
+    sample_recent_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, ql, nq, K, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
 }
 
 // ---- owner-computes step (several ranks): kernels over the exchange buffers ---------------------------------
 constexpr int XM_HEADER = 64;      // 32-bit words ahead of the ids of an xm chunk (word 0 = count)
-__host__ __device__ inline int64_t xh_chunk_floats(int64_t per) { return ((per * (ORCA_D * 4 + 1) + 255) / 256) * 64; }
 __host__ __device__ inline int64_t xm_ids_words(int64_t cap) { return ((cap + 63) / 64) * 64; }
 __host__ __device__ inline int64_t xm_chunk_words(int64_t cap) { return XM_HEADER + xm_ids_words(cap) + cap * ORCA_D; }
 
-// History push of the all-gathered layer outputs (embedding_module.py:103-113, H7 last occurrence wins): every
-// rank flagged the last occurrence of each id WITHIN its slice; across slices the highest global position wins.
-// Only slice winners contend, so an id has at most `world` contenders (no hub serialisation at L2).
-__global__ void k_xpush_claim(const int64_t* __restrict__ nodes, int64_t Q, int64_t per, const float* __restrict__ xh,
-                              int64_t chunk, int64_t* slot, int64_t epoch, int64_t n_nodes) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// History push of the all-gathered layer outputs (embedding_module.py:103-113, H7 last occurrence wins): the row of
+// root i = k*bs + e goes to hist[nodes[i]] iff begin()'s election found i to be the last occurrence of its id.  The
+// buffer is rank-major: rank r = e / per_e holds the roots of its n_r interactions as rows
+// 3*per_e*r + k*n_r + (e - per_e*r).
+__global__ __launch_bounds__(256) void k_xpush_write(const int64_t* __restrict__ nodes, int64_t bs, int64_t per_e,
+                                                     const float* __restrict__ rows, const int64_t* __restrict__ slot,
+                                                     int64_t epoch, int64_t n_nodes, float* __restrict__ hist) {
+  const int64_t Q = 3 * bs;
+  // 16 lanes per position (a row is 25 float4): a quarter of the waves a wave-per-row copy needs, and the three
+  // dependent loads (id, slot, row) of four positions share one wave's latency
+  const int sub = threadIdx.x & 15;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   if (i >= Q) return;
-  const int64_t c = i / per, j = i - c * per;
-  const uint8_t* flags = reinterpret_cast<const uint8_t*>(xh + c * chunk + per * ORCA_D);
-  if (!flags[j]) return;
-  const int64_t id = nodes[i];
-  if (id < 0 || id >= n_nodes) return;
-  atomicMax(reinterpret_cast<unsigned long long*>(&slot[id]), (unsigned long long)(epoch + i));
-}
-__global__ __launch_bounds__(256) void k_xpush_write(const int64_t* __restrict__ nodes, int64_t Q, int64_t per,
-                                                     const float* __restrict__ xh, int64_t chunk,
-                                                     const int64_t* __restrict__ slot, int64_t epoch, int64_t n_nodes,
-                                                     float* __restrict__ hist) {
-  const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (i >= Q) return;
-  const int64_t c = i / per, j = i - c * per;
-  const float* base = xh + c * chunk;
-  if (!reinterpret_cast<const uint8_t*>(base + per * ORCA_D)[j]) return;
   const int64_t id = nodes[i];
   if (id < 0 || id >= n_nodes || slot[id] != epoch + i) return;
-  const float* row = base + j * ORCA_D;
-  for (int c2 = lane; c2 < ORCA_D; c2 += 64) hist[id * ORCA_D + c2] = row[c2];
+  const int64_t k = i / bs, e = i - k * bs, r = e / per_e;
+  const int64_t n_r = (r + 1) * per_e <= bs ? per_e : bs - r * per_e;
+  const f32x4* src = reinterpret_cast<const f32x4*>(rows + (3 * per_e * r + k * n_r + (e - per_e * r)) * ORCA_D);
+  f32x4* dst = reinterpret_cast<f32x4*>(hist + id * ORCA_D);
+  dst[sub] = src[sub];
+  if (sub + 16 < ORCA_D / 4) dst[sub + 16] = src[sub + 16];
+}
+
+// The last occurrences of the ids this rank owns in [src;dst] (begin()'s election on slot_m) -> the lists the
+// owner's kernels walk: positions (own_pos) and ids (own_ids), *count of them; one atomicAdd per workgroup.
+__global__ __launch_bounds__(1024) void k_owner_list(const int64_t* __restrict__ nodes, int64_t n,
+                                                     const int64_t* __restrict__ slot, int64_t epoch, int64_t n_nodes,
+                                                     int own_world, int own_rank, int32_t* __restrict__ own_pos,
+                                                     int32_t* __restrict__ own_ids, int32_t* __restrict__ count) {
+  __shared__ int wave_n[16];
+  __shared__ int block_base;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t id = -1;
+  bool take = false;
+  if (p < n) {
+    id = nodes[p];
+    take = id >= 0 && id < n_nodes && (int)((uint32_t)id % (uint32_t)own_world) == own_rank && slot[id] == epoch + p;
+  }
+  const unsigned long long m = __ballot(take);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_n[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) { int c = wave_n[w]; wave_n[w] = tot; tot += c; }
+    block_base = tot ? atomicAdd(count, tot) : 0;
+  }
+  __syncthreads();
+  if (take) {
+    const int k = block_base + wave_n[wave] + __popcll(m & ((1ull << lane) - 1ull));
+    own_pos[k] = (int32_t)p;
+    own_ids[k] = (int32_t)id;
+  }
 }
 
 // Owner's share of tgn_model.py:127-141 for the winner positions p of [src;dst] whose id this rank owns: the memory
@@ -261,16 +331,17 @@ __global__ __launch_bounds__(256) void k_xpush_write(const int64_t* __restrict__
 // rank, after the exchange), so no wave can see another wave's half-made update.
 __global__ __launch_bounds__(256) void k_owner_persist_store(
     const int64_t* __restrict__ nodes, const double* __restrict__ qts, const int64_t* __restrict__ eidx, int64_t bs,
-    const uint8_t* __restrict__ winner, int64_t n_nodes, const uint8_t* __restrict__ pending,
+    const int32_t* __restrict__ own_pos, const int32_t* __restrict__ own_count, int64_t n_nodes,
+    const uint8_t* __restrict__ pending,
     const float* __restrict__ overlay, float* __restrict__ memory, float* __restrict__ last_update,
     const float* __restrict__ edge_feats, int d_e, const float* __restrict__ tw, const float* __restrict__ tb,
     float* __restrict__ messages, float* __restrict__ msg_ts) {
   const int lane = threadIdx.x & 63;
-  const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (p >= 2 * bs || !winner[p]) return;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= *own_count) return;
+  const int64_t p = own_pos[r];
   const int64_t e = p < bs ? p : p - bs;
   const int64_t id = nodes[p], partner = nodes[p < bs ? p + bs : p - bs];
-  if (id < 0 || id >= n_nodes) return;
   const bool pend = pending[id] != 0;
   const bool ppend = partner >= 0 && partner < n_nodes && pending[partner] != 0;
   const float* ms = (pend ? overlay : memory) + id * ORCA_D;
@@ -385,7 +456,7 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   e->store_done = false;
   e->sharded = false;
   e->per = 0;
-  e->xh_chunk = 0;
+  e->epoch_push = e->epoch_msg = 0;
   e->sampling = ORCA_SAMPLE_RECENT;
   e->seed = 0;
   e->eidx = nullptr;
@@ -448,7 +519,6 @@ ORCA_API int64_t orca_engine_take_epochs(orca_engine_t* e, int64_t n) {
   return take_epochs(e, n);
 }
 
-ORCA_API int64_t orca_engine_xh_chunk_floats(int64_t per) { return per > 0 ? xh_chunk_floats(per) : 0; }
 ORCA_API int64_t orca_engine_xm_chunk_words(int64_t cap) { return cap > 0 ? xm_chunk_words(cap) : 0; }
 
 ORCA_API int orca_engine_set_sampling(orca_engine_t* e, int mode, uint64_t seed) {
@@ -465,27 +535,30 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   const orca_engine_desc& d = e->d;
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t Q = 3 * bs;
-  ORCA_REQUIRE(bs >= 0 && Q <= d.q_max && 0 <= lo && lo <= hi && hi <= Q, "orca_engine_begin: batch of %lld interactions "
-               "(slice %lld..%lld) does not fit q_max=%lld", (long long)bs, (long long)lo, (long long)hi, (long long)d.q_max);
+  const int world = d.world > 1 ? d.world : 1;
+  const bool sharded = world > 1 && train;
+  ORCA_REQUIRE(bs >= 0 && Q <= d.q_max && 0 <= lo && lo <= hi && hi <= (sharded ? bs : Q), "orca_engine_begin: batch of "
+               "%lld interactions (slice %lld..%lld) does not fit q_max=%lld", (long long)bs, (long long)lo, (long long)hi,
+               (long long)d.q_max);
   e->bs = bs; e->Q = Q; e->train = train;
   e->timed_step = e->profile > 0 && (e->step++ % e->profile) == 0;
-  e->sliced = !(lo == 0 && hi == Q);
+  e->sliced = sharded || !(lo == 0 && hi == Q);
   // Several ranks, train order: the owner-computes step.  Every rank embeds its slice; the row writes of the batch
   // (memory persist, raw-message store, GRU of the stored ids) are done by the owner of each id, and the rows other
-  // ranks read travel through the xh / xm buffers (include/orca_hip.h).
-  const int world = d.world > 1 ? d.world : 1;
-  e->sharded = world > 1 && train;
-  e->per = ceil_div64(Q, world);
-  e->xh_chunk = xh_chunk_floats(e->per > 0 ? e->per : 1);
+  // ranks read travel through the emb / xm buffers (include/orca_hip.h).
+  e->sharded = sharded;
+  e->per = ceil_div64(bs, world);
   if (e->sharded) {
-    ORCA_REQUIRE(d.xh[0] && d.xh[1] && d.xm && d.xm_cap > 0 && d.own_ids && d.own_count && d.err && d.winners,
+    ORCA_REQUIRE(d.xm && d.xm_cap > 0 && d.own_ids && d.own_pos && d.own_count && d.err && d.slot_m,
                  "orca_engine_begin: a train-ordered step of %d ranks needs the exchange buffers", world);
     ORCA_REQUIRE(e->overlay_complete, "orca_engine_begin: the owner-computes step needs an overlay-complete state "
                  "(rebuild the overlay rows of the pending ids first)");
-    const int64_t my_lo = (int64_t)d.rank * e->per < Q ? (int64_t)d.rank * e->per : Q;
-    const int64_t my_hi = my_lo + e->per < Q ? my_lo + e->per : Q;
-    ORCA_REQUIRE(lo == my_lo && hi == my_hi, "orca_engine_begin: slice %lld..%lld is not rank %d's (%lld..%lld)",
+    const int64_t my_lo = (int64_t)d.rank * e->per < bs ? (int64_t)d.rank * e->per : bs;
+    const int64_t my_hi = my_lo + e->per < bs ? my_lo + e->per : bs;
+    ORCA_REQUIRE(lo == my_lo && hi == my_hi, "orca_engine_begin: interactions %lld..%lld are not rank %d's (%lld..%lld)",
                  (long long)lo, (long long)hi, d.rank, (long long)my_lo, (long long)my_hi);
+    ORCA_REQUIRE(3 * e->per * world <= d.q_max, "orca_engine_begin: %d x %lld rows per rank do not fit q_max=%lld", world,
+                 (long long)(3 * e->per), (long long)d.q_max);
   } else {
     ORCA_REQUIRE(!(train && e->sliced), "orca_engine_begin: a train-ordered slice needs world > 1 in the descriptor");
   }
@@ -493,19 +566,15 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   // side, and a table filled to a third keeps the probe chains -- LDS atomic round trips, paid by the whole wave --
   // short (a hub-free batch fills a table with distinct ids; 8 x 4095 roots: 34 -> 30.6 us against 6144 per table)
   auto parts_for = [](int64_t n) { return n <= ELECT_MAX / 3 ? 1 : (int)ceil_div64(n, ELECT_MAX / 2); };   // <= 3072 ids per table
-  // sharded: the message list is elected among the owned ids only (about 2*bs / world of them), the push list is
-  // this rank's slice; otherwise both are elected whole with the same number of tables
-  const int parts_m = e->sharded ? parts_for(ceil_div64(2 * bs, world)) : parts_for(Q);
-  const int parts_p = e->sharded ? parts_for(hi - lo) : parts_m;
-  e->winners_valid = d.winners && parts_m <= ELECT_PARTS_MAX && parts_p <= ELECT_PARTS_MAX;
-  ORCA_REQUIRE(!e->sharded || e->winners_valid, "orca_engine_begin: batch too long for the owner-computes elections");
+  const int parts = parts_for(Q);
+  e->winners_valid = !e->sharded && d.winners && parts <= ELECT_PARTS_MAX;
   e->persist_done = false;
   e->pushed_layer = 0;
   e->store_done = false;
   e->eidx = eidx;
   if (bs == 0) return ORCA_OK;
   ORCA_REQUIRE(src && dst && neg && ts, "orca_engine_begin: null batch array");
-  const int64_t n = hi - lo;
+  const int64_t n = e->sharded ? 3 * (hi - lo) : hi - lo;     // root queries of this rank
   const int K = d.K;
   int rc;
   // ---- eager overlay ----------------------------------------------------------------------------------------
@@ -531,7 +600,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
       if (rc != ORCA_OK) return rc;
     }
   }
-  const bool full = lo == 0 && hi == Q;
+  const bool full = !e->sharded && lo == 0 && hi == Q;
   const bool eager = train && e->overlay_complete;
   const bool lazy = train && !eager;
   e->overlay_covers_batch = train && (full || eager);
@@ -545,26 +614,25 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     const int nbs = (int)ceil_div64(n, ELECT_THREADS / 64);                   // a wave per root of the slice
     const int nb = nbs + (n < Q ? (int)ceil_div64(Q, ELECT_THREADS) : 0);     // a thread per root outside it
     begin_elect el{};
-    if (e->winners_valid) {
-      el.ne_m = parts_m; el.ne = parts_m + parts_p;
+    if (e->sharded) {   // the global lists, a workgroup per ELECT_SEG positions, published on the two slot tables
+      el.seg = 1;
+      el.ne_m = (int)ceil_div64(2 * bs, ELECT_SEG);
+      el.ne = el.ne_m + (d.n_layers >= 2 ? (int)ceil_div64(Q, ELECT_SEG) : 0);
+      el.slot_msg = d.slot_m; el.slot_push = d.slot;
+      el.epoch_msg = e->epoch_msg = take_epochs(e, 2 * bs);
+      el.epoch_push = e->epoch_push = take_epochs(e, Q);
+      el.own_world = world; el.own_rank = d.rank;
+    } else if (e->winners_valid) {
+      el.ne_m = parts; el.ne = 2 * parts;
       el.win_msg = d.winners + d.q_max;
-      if (e->sharded) {   // slice-local push winners, straight into this rank's chunk of xh[0]
-        el.push_lo = lo; el.push_n = n;
-        el.win_push = reinterpret_cast<uint8_t*>(d.xh[0] + (int64_t)d.rank * e->xh_chunk + e->per * ORCA_D);
-        el.msg_list = d.own_ids; el.msg_count = d.own_count;
-        el.own_world = world; el.own_rank = d.rank;
-      } else {
-        el.push_lo = 0; el.push_n = Q;
-        el.win_push = d.winners;
-        el.msg_list = my_list; el.msg_count = my_count;
-        el.own_world = 1; el.own_rank = 0;
-      }
+      el.win_push = d.winners;
+      el.msg_list = my_list; el.msg_count = my_count;
     }
     const begin_sample smp{e->sampling, e->seed};
     Timed t(e, ORCA_PROF_SAMPLE, stream);
     ORCA_LAUNCH_TIMED(k_begin_queries, (unsigned)(nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
                       bs, d.nodes, d.qts, d.nodes32, el, nbs, d.n_nodes,
-                      indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
+                      indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
     ORCA_LAUNCH_CHECK();
   }
   // the other half of the list buffers (consumed above) is the next step's: its counter restarts at zero
@@ -574,7 +642,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     return ORCA_OK;
   }
   orca_tgat_inputs in{};
-  in.src_table = d.memory; in.src_idx = d.nodes32 + lo;
+  in.src_table = d.memory; in.src_idx = e->sharded ? d.nodes32 : d.nodes32 + lo;
   in.nbr_table = d.memory; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
   in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b; in.q_folded = d.att_q_folded;
@@ -606,8 +674,8 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     side.push_table = d.hist[0]; side.push_ids = d.nodes; side.push_winner = d.winners;
     e->pushed_layer = 1;
   }
-  // owner-computes step with inner layers: the output goes to this rank's chunk of xh[0], which the caller all-gathers
-  float* out = (e->sharded && d.n_layers >= 2) ? d.xh[0] + (int64_t)d.rank * e->xh_chunk : d.emb[0] + lo * ORCA_D;
+  // owner-computes step: rank-major rows (3 * per rows per rank) instead of the batch's root order
+  float* out = d.emb[0] + (e->sharded ? 3 * e->per * d.rank : lo) * ORCA_D;
   Timed t(e, ORCA_PROF_TGAT, stream);
   return orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, n, K, out, nullptr, &side, stream_);   // :177 / :181
 }
@@ -616,7 +684,7 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
   ORCA_REQUIRE(e, "orca_engine_layer: null handle");
   const orca_engine_desc& d = e->d;
   ORCA_REQUIRE(layer >= 2 && layer <= d.n_layers, "orca_engine_layer: layer %d outside [2,%d]", layer, d.n_layers);
-  ORCA_REQUIRE(0 <= lo && lo <= hi && hi <= e->Q, "orca_engine_layer: bad slice");
+  ORCA_REQUIRE(0 <= lo && lo <= hi && hi <= (e->sharded ? e->bs : e->Q), "orca_engine_layer: bad slice");
   if (e->Q == 0) return ORCA_OK;
   float* h = d.hist[layer - 2];
   orca_tgat_inputs in{};
@@ -624,26 +692,17 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
   in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b; in.q_folded = d.att_q_folded;
   if (e->sharded) {
-    // the all-gathered chunks of the previous layer: push across the slices, then attend this rank's rows
-    const float* xprev = d.xh[layer & 1];
-    const int64_t epoch = take_epochs(e, e->Q);
-    k_xpush_claim<<<(unsigned)ceil_div64(e->Q, 256), 256, 0, (hipStream_t)stream_>>>(d.nodes, e->Q, e->per, xprev, e->xh_chunk,
-                                                                                     d.slot, epoch, d.n_nodes);
-    k_xpush_write<<<(unsigned)ceil_div64(e->Q, 4), 256, 0, (hipStream_t)stream_>>>(d.nodes, e->Q, e->per, xprev, e->xh_chunk,
-                                                                                   d.slot, epoch, d.n_nodes, h);
+    // the all-gathered rows of the previous layer: push the last occurrences begin() elected, attend this rank's rows
+    const float* prev = d.emb[layer & 1];
+    k_xpush_write<<<(unsigned)ceil_div64(e->Q, 16), 256, 0, (hipStream_t)stream_>>>(d.nodes, e->bs, e->per, prev, d.slot,
+                                                                                    e->epoch_push, d.n_nodes, h);
     ORCA_LAUNCH_CHECK();
     if (hi == lo) return ORCA_OK;
-    const float* mine = xprev + (int64_t)d.rank * e->xh_chunk;
-    float* out = d.emb[(layer + 1) & 1] + lo * ORCA_D;
-    if (layer < d.n_layers) {     // feeds the next exchange: rows into this rank's chunk of the other buffer, flags copied
-      float* next = d.xh[(layer + 1) & 1] + (int64_t)d.rank * e->xh_chunk;
-      ORCA_HIP_TRY(hipMemcpyAsync(next + e->per * ORCA_D, mine + e->per * ORCA_D, (size_t)e->per, hipMemcpyDeviceToDevice,
-                                  (hipStream_t)stream_));
-      out = next;
-    }
-    in.src_table = mine;
+    const int64_t row0 = 3 * e->per * d.rank * ORCA_D;      // this rank's rows of the rank-major buffers
+    in.src_table = prev + row0;
     Timed t(e, ORCA_PROF_TGAT, (hipStream_t)stream_);
-    return orca_tgat_forward_side(d.att_blob[layer - 1], d.d_e, &in, hi - lo, d.K, out, nullptr, nullptr, stream_);
+    return orca_tgat_forward_side(d.att_blob[layer - 1], d.d_e, &in, 3 * (hi - lo), d.K, d.emb[(layer + 1) & 1] + row0, nullptr,
+                                  nullptr, stream_);
   }
   const float* prev = d.emb[layer & 1];            // layer 2 reads emb[0], layer 3 reads emb[1], ...
   float* next = d.emb[(layer + 1) & 1];
@@ -682,11 +741,14 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
   const int msg_dim = 3 * ORCA_D + d.d_e;
   if (e->sharded) {   // the owner's share of tgn_model.py:127-141, then GRU(message, memory) of the ids just stored
     hipStream_t st = (hipStream_t)stream_;
-    k_owner_persist_store<<<(unsigned)ceil_div64(2 * bs, 4), 256, 0, st>>>(
-        d.nodes, d.qts, eidx, bs, d.winners + d.q_max, d.n_nodes, d.pending, d.overlay, d.memory, d.last_update, d.edge_feats,
+    int64_t bound = 2 * bs < d.q_max ? 2 * bs : d.q_max;     // rows the owner's kernels are launched for: more owned
+    if (bound > d.xm_cap) bound = d.xm_cap;                   // ids than xm_cap is the overflow k_pack_rows reports
+    k_owner_list<<<(unsigned)ceil_div64(2 * bs, 1024), 1024, 0, st>>>(d.nodes, 2 * bs, d.slot_m, e->epoch_msg, d.n_nodes, d.world,
+                                                                     d.rank, d.own_pos, d.own_ids, d.own_count);
+    k_owner_persist_store<<<(unsigned)ceil_div64(bound, 4), 256, 0, st>>>(
+        d.nodes, d.qts, eidx, bs, d.own_pos, d.own_count, d.n_nodes, d.pending, d.overlay, d.memory, d.last_update, d.edge_feats,
         d.d_e, d.time_w, d.time_b, d.messages, d.msg_ts);
     ORCA_LAUNCH_CHECK();
-    const int64_t bound = 2 * bs < d.q_max ? 2 * bs : d.q_max;
     int rc;
     {
       Timed t(e, ORCA_PROF_GRU, st);
@@ -694,8 +756,7 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
                            nullptr, stream_);
     }
     if (rc != ORCA_OK) return rc;
-    const int64_t rows = bound < d.xm_cap ? bound : d.xm_cap;
-    k_pack_rows<<<(unsigned)ceil_div64(rows > 0 ? rows : 1, 4), 256, 0, st>>>(d.own_ids, d.own_count, d.xm_cap, d.overlay,
+    k_pack_rows<<<(unsigned)ceil_div64(bound > 0 ? bound : 1, 4), 256, 0, st>>>(d.own_ids, d.own_count, d.xm_cap, d.overlay,
                                                                               d.xm + (int64_t)d.rank * xm_chunk_words(d.xm_cap), d.err);
     ORCA_LAUNCH_CHECK();
     return ORCA_OK;

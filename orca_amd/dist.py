@@ -22,6 +22,23 @@ def query_slice(Q, rank, world):
   return lo, min(lo + per, Q), per
 
 
+def interaction_slice(bs, rank, world):
+  """(lo, hi, per): interactions [lo, hi) of a batch of bs belong to `rank` in the owner-computes step; the rank
+  embeds their src, dst and neg roots (local query order [src | dst | neg])."""
+  return query_slice(bs, rank, world)
+
+
+def interaction_root_index(bs, world, device=None):
+  """index[i] for every root i = k*bs + e of [src;dst;neg]: its row in the rank-major buffer the owner-computes
+  step all-gathers (3*per rows per rank)."""
+  per = (bs + world - 1) // world if world > 0 else bs
+  e = torch.arange(bs, device=device)
+  r = e // max(per, 1)
+  n_r = torch.clamp(bs - r * per, max=per)
+  base = 3 * per * r + (e - r * per)
+  return torch.cat([base + k * n_r for k in range(3)])
+
+
 def all_gather_rows(x, Q, per, group=None):
   """x: this rank's [n_local, W] slice -> [Q, W] on every rank."""
   world = dist.get_world_size(group) if group is not None or dist.is_initialized() else 1

@@ -231,13 +231,13 @@ class OrcaEngine:
       cap = self.exchange_cap if self.exchange_cap else min(worst, int(1.25 * 2 * per_max / 3) + 256)
       self._xm_cap = int(cap)
       self._xm_chunk = int(L.orca_engine_xm_chunk_words(self._xm_cap))
-      xh_floats = int(L.orca_engine_xh_chunk_floats(per_max)) * self.world
-      self._w.update(xh=[torch.zeros(xh_floats, dtype=torch.float32, device=dev) for _ in range(2)],
-                     xm=torch.zeros(self._xm_chunk * self.world, dtype=torch.int32, device=dev),
+      self._w.update(xm=torch.zeros(self._xm_chunk * self.world, dtype=torch.int32, device=dev),
                      own_ids=torch.zeros(q_max, dtype=torch.int32, device=dev),
+                     own_pos=torch.zeros(q_max, dtype=torch.int32, device=dev),
                      own_count=torch.zeros(1, dtype=torch.int32, device=dev))
       if getattr(self, "_err", None) is None:
         self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.slot_m = torch.zeros(self.N, dtype=torch.int64, device=dev)
     d = _lib.EngineDesc()
     d.n_nodes, d.n_layers, d.K, d.d_e = self.N, self.L, K, self.d_e
     d.csr = self.csr._h if self.csr is not None else None
@@ -258,8 +258,9 @@ class OrcaEngine:
     d.winners = ptr(w["winners"])
     if self.world > 1:
       d.world, d.rank = self.world, self.rank
-      d.xh[0], d.xh[1], d.xm, d.xm_cap = ptr(w["xh"][0]), ptr(w["xh"][1]), ptr(w["xm"]), self._xm_cap
-      d.own_ids, d.own_count, d.err = ptr(w["own_ids"]), ptr(w["own_count"]), ptr(self._err)
+      d.xm, d.xm_cap = ptr(w["xm"]), self._xm_cap
+      d.own_ids, d.own_pos, d.own_count = ptr(w["own_ids"]), ptr(w["own_pos"]), ptr(w["own_count"])
+      d.slot_m, d.err = ptr(self.slot_m), ptr(self._err)
     d.eager_ids, d.eager_count = ptr(w["eager_ids"]), ptr(w["eager_count"])
     d.att_q_folded = 1     # load_state_dict completes every blob with orca_tgat_pack_gather
     h = _lib.vp()
@@ -305,13 +306,14 @@ class OrcaEngine:
     L = _lib.load()
     bs = src.numel()
     Q = 3 * bs
-    self._ensure_native(Q)
+    owner = self.world > 1 and train
+    self._ensure_native(3 * self.world * (-(-bs // self.world)) if owner else Q)
     lo, hi, per = self._slice(Q)
     st = stream()
     if self.sampling == "uniform":
       check(L.orca_engine_set_sampling(self._native, 1, self._step_seed()), "orca_engine_set_sampling")
-    if self.world > 1 and train:
-      return self._step_owner_computes(L, src, dst, neg, ts, eidx, bs, Q, lo, hi, per, st, gather_output)
+    if owner:
+      return self._step_owner_computes(L, src, dst, neg, ts, eidx, bs, st, gather_output)
     if self.world > 1:                # eval order: replicated row writes on coherent tables
       self.sync_replicas()
     check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, lo, hi, int(train), st),
@@ -326,24 +328,26 @@ class OrcaEngine:
     check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
     return out[:Q] if gather_output else out[lo:hi]
 
-  def _step_owner_computes(self, L, src, dst, neg, ts, eidx, bs, Q, lo, hi, per, st, gather_output):
-    """Train-ordered step of several ranks (include/orca_hip.h, orca_engine_desc): this rank embeds its slice and
-    does the batch's row writes for the ids it owns; two all-gathers per step carry the rows other ranks read.
-    The owner's work and the second exchange (updated memory rows) hide behind the first exchange (layer-1 rows
-    for the history tables) and the attention of the later layers."""
+  def _step_owner_computes(self, L, src, dst, neg, ts, eidx, bs, st, gather_output):
+    """Train-ordered step of several ranks (include/orca_hip.h, orca_engine_desc): this rank embeds the src, dst
+    and neg roots of its share of the batch's interactions and does the batch's row writes for the ids it owns;
+    two all-gathers per step carry the rows other ranks read.  The owner's work and the second exchange (updated
+    memory rows) hide behind the first exchange (layer-1 rows for the history tables) and the attention of the
+    later layers.  gather_output=False returns this rank's rows [src | dst | neg] of ITS interactions
+    (dist.interaction_slice) -- what a data-parallel link decoder consumes."""
+    lo, hi, per = dist_utils.interaction_slice(bs, self.rank, self.world)
     if not L.orca_engine_get_overlay_complete(self._native):
       self.sync_replicas()
       self._rebuild_overlay()
     check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, lo, hi, 1, st),
           "orca_engine_begin")
-    xh, xm = self._w["xh"], self._w["xm"]
-    hchunk = int(L.orca_engine_xh_chunk_floats(max(per, 1)))
+    emb, xm = self._w["emb"], self._w["xm"]
     def finish():
       check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
       return self._gather_chunks(xm, self._xm_chunk, async_op=True)
     wm = None
     for layer in range(2, self.L + 1):
-      wh = self._gather_chunks(xh[layer & 1], hchunk, async_op=True)
+      wh = self._gather_chunks(emb[layer & 1].view(-1), 3 * per * D, async_op=True)
       if layer == 2:
         wm = finish()
       if wh is not None:
@@ -356,10 +360,10 @@ class OrcaEngine:
     check(L.orca_engine_apply(self._native, st), "orca_engine_apply")
     self._sharded = True
     out = self._w["emb"][(self.L + 1) & 1]
-    if gather_output:
-      self._gather_in_place(out, per)
-      return out[:Q]
-    return out[lo:hi]
+    if gather_output:       # every rank's rows, then back into the batch's [src;dst;neg] order
+      self._gather_chunks(out.view(-1), 3 * per * D)
+      return out[dist_utils.interaction_root_index(bs, self.world, self.device)]
+    return out[3 * per * self.rank:3 * per * self.rank + 3 * (hi - lo)]
 
   def _gather_chunks(self, buf, chunk, async_op=False):
     """in-place all-gather of the first world x chunk elements of buf: rank r contributes chunk r"""

@@ -40,7 +40,7 @@ def _worker(rank, world, port, q, full):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from orca_amd import ops, synth
-    from orca_amd.dist import query_slice
+    from orca_amd.dist import interaction_slice, query_slice
     from orca_amd.engine import OrcaEngine
     dev = "cuda:0"
     N, E, bs, K, d_e = 3000, 60000, 301, 10, 172
@@ -70,7 +70,10 @@ def _worker(rank, world, port, q, full):
         sharded = reuse and b in (2, 7)     # outputs left on the rank that computed them (bench.py, N > 1)
         a = multi.compute_temporal_embeddings(*bt, train, gather_output=not sharded)
         c = single.compute_temporal_embeddings(*bt, train)
-        if sharded:
+        if sharded and train:   # the rank's own interactions: rows [src | dst | neg] of them
+          lo, hi, _ = interaction_slice(bs, rank, world)
+          c = torch.cat([c[k * bs + lo:k * bs + hi] for k in range(3)])
+        elif sharded:
           lo, hi, _ = query_slice(3 * bs, rank, world)
           c = c[lo:hi]
         step_ok = torch.equal(a, c)
