@@ -10,10 +10,14 @@ build and store): every operation of the reference's step, 4 kernel launches (DE
 Workload (BASELINE.json configs[3], the one the metric's north_star is quoted on; it fits one GPU):
 synthetic power-law temporal graph, 1M nodes / 100M edges, 172-d edge features, K=10, 2 layers,
 4096-query batches (bs = 1365 interactions -> 4095 root queries).  Everything is generated on the
-device and resident in HBM before the timed region.  N>1: state replicated, the global batch is
-N x 1365 interactions and each rank embeds its 4095-query slice (weak scaling); the layer-1 rows every rank
-pushes into the replicated history are exchanged with one RCCL all-gather per step, the final embeddings stay on
-the rank that computed them.
+device and resident in HBM before the timed region.  N>1 (one process per GPU; `--gpus N` without a launcher in
+front starts the N ranks itself): the global batch is N x 1365 interactions, each rank embeds the 4095 root queries
+of its 1365 interactions (weak scaling) and does the batch's memory / message row writes for the node ids it owns
+(id % N); two RCCL all-gathers per step carry the rows other ranks read (layer-1 rows for the history tables,
+GRU(message, memory) of the stored ids); the final embeddings stay on the rank that computed them.
+
+The timed region is R repeats of EXACTLY --steps consecutive steps (R chosen so that the region is >= 50 ms, at
+least 5); ms_per_step / value are the median repeat, between barriers, max over ranks.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
@@ -69,6 +73,10 @@ def parse():
   ap.add_argument("--event-stride", type=int, default=8,
                   help="attach HIP events to the kernels of every n-th timed step (the event plumbing costs ~20 us of "
                        "host time per step it is on)")
+  ap.add_argument("--min-region-ms", type=float, default=50.0, help="repeat the --steps block until the timed region is this long")
+  ap.add_argument("--path-a-steps", type=int, default=10,
+                  help="N=1, Path B run: also time this many steps of Path A (exact recursion, no reuse; SURVEY section 8d), "
+                       "reported as 'path_a' (0 = skip)")
   ap.add_argument("--train-steps", type=int, default=20,
                   help="N=1, Path B: also time this many full training steps (forward + backward + Adam + re-pack), "
                        "reported as the secondary figure 'train_step' (0 = skip)")
@@ -88,6 +96,25 @@ class DeviceBackedRows:
     return self.table[idx.to(self.table.device)].cpu()
 
 
+def cpu_sampler_rates(nf, batches, K, threads):
+  """The CPU restatement of the reference's sampler loop (utils/util.py:141-150 is a serial Numba loop) on the
+  batches' root queries: one core, and all cores (the same C loop over per-thread chunks of the queries; labelled,
+  the reference itself has no parallel sampler)."""
+  from concurrent.futures import ThreadPoolExecutor
+  nodes = np.concatenate([np.concatenate([x.cpu().numpy() for x in (b[0], b[1], b[2])]) for b in batches])
+  qts = np.concatenate([np.tile(b[3].cpu().numpy(), 3) for b in batches])
+  t0 = time.perf_counter()
+  nf.get_temporal_neighbor(nodes, qts, K)
+  serial = len(nodes) / (time.perf_counter() - t0)
+  cuts = np.linspace(0, len(nodes), threads + 1).astype(np.int64)
+  t0 = time.perf_counter()
+  with ThreadPoolExecutor(threads) as ex:      # ctypes releases the GIL around the C loop
+    list(ex.map(lambda i: nf.get_temporal_neighbor(nodes[cuts[i]:cuts[i + 1]], qts[cuts[i]:cuts[i + 1]], K), range(threads)))
+  par = len(nodes) / (time.perf_counter() - t0)
+  return {"queries": int(len(nodes)), "serial_queries_per_s": serial, "all_cores_queries_per_s": par, "cores": threads,
+          "what": "oracle C sampler (serial loop of utils/util.py:141-150); all-cores = the same loop on per-thread chunks"}
+
+
 def cpu_baseline(args, csr, edge_feats, sd, batches, threads):
   """The oracle (oracle/oracle.py, the CPU restatement of the reference's PyTorch+Numba path; "port")
   timed on the host cores on the first batches of the timed sequence."""
@@ -99,7 +126,7 @@ def cpu_baseline(args, csr, edge_feats, sd, batches, threads):
   ref.neighbor_finder = nf
   warm = 2
   t0 = None
-  n_edges = 0
+  n_edges = n_timed = 0
   for i, b in enumerate(batches[:warm + args.cpu_batches]):
     if i == warm:
       t0 = time.perf_counter()
@@ -107,16 +134,36 @@ def cpu_baseline(args, csr, edge_feats, sd, batches, threads):
     ref.compute_temporal_embeddings(s, d, n, t, e, True)
     if i >= warm:
       n_edges += len(s)
+      n_timed += 1
   dt = time.perf_counter() - t0
   return {"value": n_edges / dt, "unit": "temporal edges/s", "cores": threads, "kind": "port",
-          "sample": f"{args.cpu_batches} consecutive {args.bs}-interaction batches of the same workload after {warm} "
+          "sample": f"{n_timed} consecutive {args.bs}-interaction batches of the same workload after {warm} "
                     f"warm-up batches, oracle.OracleTGN ({'Path A' if args.no_reuse else 'Path B'}, forward, torch CPU "
-                    f"fp32 + serial C sampler), {dt:.1f} s of CPU work"}
+                    f"fp32 + serial C sampler), {dt:.1f} s of CPU work",
+          "sampler": cpu_sampler_rates(nf, batches[:min(len(batches), 50)], args.k, threads)}
+
+
+def launch_ranks(args):
+  """`python bench.py --gpus N` with no launcher in front: start the N ranks as children (torch.distributed.run,
+  one per GPU, rendezvous on 127.0.0.1) BEFORE this process touches the GPU, and exit with their status."""
+  import socket
+  import subprocess
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  raise SystemExit(subprocess.call(cmd))
 
 
 def main():
   args = parse()
+  if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    launch_ranks(args)
   world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != args.gpus:
+    raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
   rank = int(os.environ.get("RANK", "0"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
   if not torch.cuda.is_available():
@@ -152,8 +199,10 @@ def main():
   # consecutive time-ordered batches from the 70 % mark (train.py:131-137 chronological split)
   gbs = args.bs * world
   n_train = args.train_steps + 5 if (world == 1 and not args.no_reuse and args.train_steps > 0) else 0
-  n_batches = args.warmup + args.steps + n_train
   start = int(0.7 * args.edges)
+  n_avail = (args.edges - start) // gbs - args.warmup - n_train          # batches left for the timed region
+  max_repeats = max(1, min(64, n_avail // max(args.steps, 1)))
+  n_batches = args.warmup + args.steps * max_repeats + n_train
   if start + n_batches * gbs > args.edges:
     start = max(0, args.edges - n_batches * gbs)
   g = torch.Generator(device=dev)
@@ -183,24 +232,36 @@ def main():
       eng.profile_kernels(True, args.event_stride)       # native driver (Path B)
       if args.no_reuse and args.layers > 1:
         eng.prof = {}                 # Python-dispatched path (Path A with recursion; one layer runs natively)
-    barrier()
-    t0 = time.perf_counter()
-    for b in batches[args.warmup:args.warmup + args.steps]:
-      eng.compute_temporal_embeddings(*b, train=True, gather_output=gather)
-    barrier()
-    dt = time.perf_counter() - t0
-  if world > 1:
-    import torch.distributed as dist
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    # R repeats of exactly --steps steps, each between barriers (max over ranks); R is fixed after the first
+    # repeat so that the whole timed region lasts >= --min-region-ms (at least 5 repeats, at most 64)
+    def max_over_ranks(x):
+      if world == 1:
+        return x
+      import torch.distributed as dist
+      tt = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+      dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+      return float(tt.item())
+    reps, r, n_rep = [], 0, 5
+    while r < n_rep:
+      blk = batches[args.warmup + r * args.steps:args.warmup + (r + 1) * args.steps]
+      barrier()
+      t0 = time.perf_counter()
+      for b in blk:
+        eng.compute_temporal_embeddings(*b, train=True, gather_output=gather)
+      barrier()
+      reps.append(max_over_ranks(time.perf_counter() - t0))
+      if r == 0:
+        n_rep = int(max_over_ranks(float(min(max_repeats, max(5, int(np.ceil(1.25 * args.min_region_ms * 1e-3 / max(reps[0], 1e-9))))))))
+      r += 1
+    dt = float(np.median(reps))
+    eng.check_errors()
   prof = eng.profile_read() or eng.prof_summary()   # HIP events recorded around the kernels inside the timed region
   eng.profile_kernels(False)
   eng.prof = None
   train = None
   if n_train:       # secondary figure: the full training step on the batches that follow
     eng.optimizer(lr=1e-4)
-    tb = batches[args.warmup + args.steps:]
+    tb = batches[args.warmup + args.steps * max_repeats:]
     for b in tb[:5]:
       eng.step_optimizer(eng.train_step(*b)[1])
     barrier()
@@ -215,6 +276,24 @@ def main():
              "what": "train-ordered forward + BCE loss + backward (attention x layers, GRU) + Adam + blob re-pack; "
                      "first-cut backward (generic MFMA GEMM + wave-per-query kernels, Python-dispatched)"}
 
+  path_a = None
+  if world == 1 and not args.no_reuse and args.layers > 1 and args.path_a_steps > 0:
+    # secondary figure: the exact TGN recursion (Path A, modules/embedding_module.py:116-147) on the
+    # same workload -- (1+K) times the attention evaluations of Path B's first layer, Python-dispatched
+    ea = OrcaEngine(sd, ef, args.nodes + 1, args.layers, args.k, reuse=False, budget=0, device=dev)
+    ea.set_neighbor_finder(csr)
+    with torch.no_grad():
+      for b in batches[:3]:
+        ea.compute_temporal_embeddings(*b, train=True)
+      barrier()
+      t1 = time.perf_counter()
+      for b in batches[3:3 + args.path_a_steps]:
+        ea.compute_temporal_embeddings(*b, train=True)
+      barrier()
+      t1 = time.perf_counter() - t1
+    path_a = {"edges_per_s": args.path_a_steps * gbs / t1, "ms_per_step": 1e3 * t1 / args.path_a_steps,
+              "steps": args.path_a_steps, "what": "Path A (no reuse, exact recursion), forward train-order step, same batches"}
+    del ea
   if rank == 0:
     Q = 3 * args.bs
     out = {
@@ -223,6 +302,7 @@ def main():
         "unit": "temporal edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
+        "repeats": len(reps), "timed_region_s": float(sum(reps)),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic power-law temporal graph {args.nodes} nodes/{args.edges} edges, "
@@ -231,6 +311,8 @@ def main():
                                f"{Q}-query batches ({args.bs} interactions) per GPU, forward train-order step",
                    "root_queries_per_s": args.steps * gbs * 3 / dt,
                    "outputs": "on the rank that computed them" if world > 1 and not args.no_reuse else "one tensor",
+                   "parallelism": (f"{world} ranks: roots partitioned by interaction, state rows owned by id % {world}, "
+                                   "2 all-gathers per step") if world > 1 else "1 rank",
                    "setup_s": round(t_setup, 1)},
     }
     if "tgat_forward" in prof:
@@ -265,9 +347,11 @@ def main():
                         "achieved_tflops": rows * 2 * (3 * 100 + args.d_e + 100) * 300 / (gms * 1e-3) / 1e12}
     if train:
       out["train_step"] = train
+    if path_a:
+      out["path_a"] = path_a
     if world == 1 and args.cpu_batches > 0:
       threads = min(16, os.cpu_count() or 1)
-      out["cpu_baseline"] = cpu_baseline(args, csr, ef, sd, batches[args.warmup:args.warmup + args.steps], threads)
+      out["cpu_baseline"] = cpu_baseline(args, csr, ef, sd, batches[args.warmup:], threads)
     print(json.dumps(out), flush=True)
   if world > 1:
     import torch.distributed as dist

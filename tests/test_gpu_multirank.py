@@ -167,3 +167,45 @@ def test_ranks_equal_one_rank(world, full):
     p.join(timeout=60)
   for r, ok, msg in res:
     assert ok, f"rank {r}: {msg or 'results differ from the single-rank engine'}"
+
+
+def _rccl_worker(port, q):
+  try:
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    from orca_amd.dist import all_gather_chunks, all_gather_rows, all_reduce_sum, sync_owned_rows
+    dev = "cuda:0"
+    buf = torch.arange(1000, dtype=torch.int32, device=dev)
+    w = all_gather_chunks(buf, 640, dist.group.WORLD, async_op=True)     # in-place all_gather_into_tensor on RCCL
+    if w is not None:
+      w.wait()
+    ok = torch.equal(buf, torch.arange(1000, dtype=torch.int32, device=dev))
+    t = torch.randn(50, 7, device=dev)
+    c = t.clone()
+    sync_owned_rows([t], dist.group.WORLD)
+    ok = ok and torch.equal(t, c)
+    g = all_reduce_sum(torch.ones(9, device=dev), dist.group.WORLD)
+    ok = ok and torch.equal(g, torch.ones(9, device=dev))
+    x = all_gather_rows(c, 50, 50, dist.group.WORLD)
+    ok = ok and torch.equal(x, c)
+    torch.cuda.synchronize()
+    q.put((bool(ok), ""))
+    dist.destroy_process_group()
+  except Exception:
+    import traceback
+    q.put((False, traceback.format_exc()))
+
+
+def test_exchange_helpers_on_rccl_single_rank():
+  """The exchange helpers of the owner-computes step on the RCCL backend itself ("nccl"): one rank is all a
+  one-GPU box allows (RCCL refuses two ranks per device), which still runs the in-place all-gather, the masked
+  all-reduce and the async work handle through RCCL rather than through the gloo staging of the other tests."""
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+  p.start()
+  ok, msg = q.get(timeout=240)
+  p.join(timeout=60)
+  assert ok, msg
