@@ -67,6 +67,9 @@ def parse():
   ap.add_argument("--bs", type=int, default=1365, help="interactions per rank per batch (3*bs root queries)")
   ap.add_argument("--k", type=int, default=10)
   ap.add_argument("--layers", type=int, default=2)
+  ap.add_argument("--sampling", choices=("recent", "uniform"), default="recent",
+                  help="uniform = seeded-uniform neighbours (BASELINE config 5: --nodes 10000000 --edges 1000000000 --k 20 --d-e 1 "
+                       "--sampling uniform); not in the reference")
   ap.add_argument("--no-reuse", action="store_true", help="Path A (exact TGN recursion) instead of Path B")
   ap.add_argument("--cpu-batches", type=int, default=200, help="batches of the CPU baseline sample (0 = skip)")
   ap.add_argument("--no-kernel-events", action="store_true")
@@ -124,6 +127,8 @@ def cpu_baseline(args, csr, edge_feats, sd, batches, threads):
   ref = O.OracleTGN(sd, torch.zeros(1, args.d_e), args.nodes + 1, args.layers, args.k, not args.no_reuse, 0)
   ref.edge_feats = DeviceBackedRows(edge_feats)
   ref.neighbor_finder = nf
+  if args.sampling == "uniform":
+    ref.uniform_seed = 2024
   warm = 2
   t0 = None
   n_edges = n_timed = 0
@@ -191,10 +196,10 @@ def main():
   t_setup = time.perf_counter()
   src, dst, eidx, ts = synth.powerlaw_graph(args.nodes, args.edges, dev)
   csr = ops.CSR.from_edges_device(src, dst, eidx, ts, args.nodes + 1)
-  ef = synth.edge_features(args.edges, args.d_e, dev)
+  ef = synth.edge_features(args.edges, args.d_e, dev, zero=args.d_e == 1)
   sd = synth.tgn_state_dict(args.d_e, args.layers)
   eng = OrcaEngine(sd, ef, args.nodes + 1, args.layers, args.k, reuse=not args.no_reuse, budget=0, device=dev,
-                   group=group)
+                   group=group, sampling=args.sampling, seed=2024)
   eng.set_neighbor_finder(csr)
   # consecutive time-ordered batches from the 70 % mark (train.py:131-137 chronological split)
   gbs = args.bs * world
@@ -277,7 +282,7 @@ def main():
                      "first-cut backward (generic MFMA GEMM + wave-per-query kernels, Python-dispatched)"}
 
   path_a = None
-  if world == 1 and not args.no_reuse and args.layers > 1 and args.path_a_steps > 0:
+  if world == 1 and not args.no_reuse and args.layers > 1 and args.path_a_steps > 0 and args.sampling == "recent":
     # secondary figure: the exact TGN recursion (Path A, modules/embedding_module.py:116-147) on the
     # same workload -- (1+K) times the attention evaluations of Path B's first layer, Python-dispatched
     ea = OrcaEngine(sd, ef, args.nodes + 1, args.layers, args.k, reuse=False, budget=0, device=dev)
@@ -306,7 +311,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic power-law temporal graph {args.nodes} nodes/{args.edges} edges, "
-                               f"{args.d_e}-d edge feats, K={args.k}, {args.layers} layers, "
+                               f"{args.d_e}-d edge feats, K={args.k}{' seeded-uniform' if args.sampling == 'uniform' else ''}, {args.layers} layers, "
                                f"{'Path A exact recursion' if args.no_reuse else 'Path B --reuse'}, "
                                f"{Q}-query batches ({args.bs} interactions) per GPU, forward train-order step",
                    "root_queries_per_s": args.steps * gbs * 3 / dt,

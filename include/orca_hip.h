@@ -69,6 +69,10 @@ int orca_csr_arrays(const orca_csr_t* csr, int64_t* n_rows, int64_t* nnz, const 
 int orca_csr_copy_host(const orca_csr_t* csr, int64_t* indptr_host, int32_t* nbr_host, int32_t* eidx_host,
                        double* ts_host);
 
+/* same for the entries [begin, end) only (the adjacency lists of a few nodes of a graph too large to copy whole) */
+int orca_csr_copy_range_host(const orca_csr_t* csr, int64_t begin, int64_t end, int32_t* nbr_host, int32_t* eidx_host,
+                             double* ts_host);
+
 /* NeighborFinder.get_temporal_neighbor (utils/util.py:134-151) + the Δt of
  * modules/embedding_module.py:130-131.  Outputs are [Q, K] row-major, right-aligned, zero padded;
  * neighbours are STRICTLY before t (np.searchsorted side='left').  out_dt may be NULL.  K >= 1

@@ -60,6 +60,7 @@ SIGNATURES = {
     "orca_csr_arrays": (i32, [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp),
                               ctypes.POINTER(vp), ctypes.POINTER(vp)]),
     "orca_csr_copy_host": (i32, [vp, vp, vp, vp, vp]),
+    "orca_csr_copy_range_host": (i32, [vp, i64, i64, vp, vp, vp]),
     "orca_sample_recent": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
     "orca_find_before": (i32, [vp, vp, vp, i64, vp, vp]),
     "orca_sample_uniform": (i32, [vp, vp, vp, i64, i32, u64, i64, vp, vp, vp, vp, vp, vp]),

@@ -284,6 +284,17 @@ ORCA_API int orca_csr_copy_host(const orca_csr_t* c, int64_t* indptr, int32_t* n
   return ORCA_OK;
 }
 
+ORCA_API int orca_csr_copy_range_host(const orca_csr_t* c, int64_t begin, int64_t end, int32_t* nbr, int32_t* eidx,
+                                      double* ts) {
+  ORCA_REQUIRE(c && 0 <= begin && begin <= end && end <= c->nnz, "orca_csr_copy_range_host: bad range");
+  const size_t n = (size_t)(end - begin);
+  if (n == 0) return ORCA_OK;
+  if (nbr) ORCA_HIP_TRY(hipMemcpy(nbr, c->nbr + begin, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (eidx) ORCA_HIP_TRY(hipMemcpy(eidx, c->eid + begin, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (ts) ORCA_HIP_TRY(hipMemcpy(ts, c->ts + begin, n * sizeof(double), hipMemcpyDeviceToHost));
+  return ORCA_OK;
+}
+
 __global__ __launch_bounds__(256) void k_sample_recent(const int64_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ nbr,
                                                        const int32_t* __restrict__ eid,

@@ -84,6 +84,27 @@ class CSR:
       check(_lib.load().orca_csr_copy_host(self._h, ptr(indptr), ptr(nbr), ptr(eidx), ptr(ts)), "orca_csr_copy_host")
     return indptr, nbr, eidx, ts
 
+  def rows_host(self, nodes):
+    """(indptr, nbr, eidx, ts) of a CSR with the same number of rows that holds the adjacency lists of `nodes` only
+    (every other row empty): what a host-side check of a few queries needs from a graph too large to copy whole."""
+    L = _lib.load()
+    full = np.empty(self.n_rows + 1, np.int64)
+    with torch.cuda.device(self.device):
+      check(L.orca_csr_copy_host(self._h, ptr(full), None, None, None), "orca_csr_copy_host")
+      nodes = np.unique(np.asarray(nodes, dtype=np.int64))
+      deg = np.zeros(self.n_rows, np.int64)
+      deg[nodes] = full[nodes + 1] - full[nodes]
+      indptr = np.zeros(self.n_rows + 1, np.int64)
+      np.cumsum(deg, out=indptr[1:])
+      nnz = int(indptr[-1])
+      nbr, eidx, ts = np.empty(nnz, np.int32), np.empty(nnz, np.int32), np.empty(nnz, np.float64)
+      for v in nodes:
+        a, b = int(indptr[v]), int(indptr[v + 1])
+        if b > a:
+          check(L.orca_csr_copy_range_host(self._h, int(full[v]), int(full[v + 1]), ptr(nbr[a:b]), ptr(eidx[a:b]),
+                                           ptr(ts[a:b])), "orca_csr_copy_range_host")
+    return indptr, nbr, eidx, ts
+
   def close(self):
     if self._h is not None and self._h.value:
       _lib.load().orca_csr_destroy(self._h)
