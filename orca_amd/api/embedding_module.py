@@ -1,6 +1,9 @@
 """modules/embedding_module.py:64-330,364-427 -- GraphAttentionEmbedding: the recursion / reuse control of
 the three embedding algorithms, re-expressed on device tensors (ids, flags and tables stay in HBM; the
-gathers, time encodings and attention of one layer are ONE fused kernel launch)."""
+gathers, time encodings and attention of one layer are ONE fused kernel launch).  Under autograd (the reference's
+training loop, train.py:225-226) every attention evaluation is an orca::tgat_gather node: gradients flow into the
+layer parameters, into the previous layer's output rows and into the updated-memory rows (hence the GRU); history
+rows are detached as upstream (history.py:32-40)."""
 import numpy as np
 import torch
 from torch import nn
@@ -75,24 +78,34 @@ class GraphAttentionEmbedding(nn.Module):
     if train:
       view, _ = memory_updater.get_updated_memory(memory, torch.cat(
           [ids64] + ([ids32.flatten().to(torch.int64)] if ids32 is not None else [])))
-      return dict(table=view.table, overlay=view.overlay, flags=view.flags)
+      return dict(table=view.table, overlay=view.overlay, flags=view.flags, upd_rows=view.upd_rows, pos=view.pos)
     table = memory.memory if hasattr(memory, "memory") else memory
     return dict(table=table.contiguous(), overlay=None, flags=None)
 
   def _attend(self, layer, Q, K, nbr, eid, dt, src, src_idx, nb, nbr_idx):
     te = self.time_encoder.w
+    att = self.attention_models[layer - 1]
+    tw, tb = te.weight.detach().reshape(-1).contiguous(), te.bias.detach().contiguous()
+    if torch.is_grad_enabled() and (any(p.requires_grad for p in att.parameters()) or src["table"].requires_grad or
+                                    nb["table"].requires_grad or src.get("upd_rows") is not None):
+      # the training loop (train.py:225-226): the layer as an autograd node (orca::tgat_gather, torch_ops.py)
+      from .. import torch_ops  # noqa: F401
+      named = dict(att.named_parameters())
+      m = src if src.get("flags") is not None else nb
+      return torch.ops.orca.tgat_gather([named[k] for k in ops.TGAT_KEYS], att.packed(), self.n_edge_features, Q, K,
+                                        src["table"], src_idx, nb["table"], nbr_idx, nbr, self._edge_table(), eid, dt,
+                                        tw, tb, m.get("overlay"), m.get("flags"), m.get("upd_rows"), m.get("pos"), False)
     kw = dict(src_table=src["table"], src_idx=src_idx, nbr_table=nb["table"], nbr_idx=nbr_idx, nbr_ids=nbr,
-              edge_table=self._edge_table(), edge_idx=eid, dt=dt, time_w=te.weight.reshape(-1).contiguous(),
-              time_b=te.bias.contiguous())
+              edge_table=self._edge_table(), edge_idx=eid, dt=dt, time_w=tw, time_b=tb)
     if src.get("flags") is not None:
       kw.update(src_overlay=src["overlay"], src_flags=src["flags"])
     if nb.get("flags") is not None:
       kw.update(nbr_overlay=nb["overlay"], nbr_flags=nb["flags"])
-    out, _ = ops.tgat_forward(self.attention_models[layer - 1].packed(), self.n_edge_features, Q, K, **kw)
+    with torch.no_grad():
+      out, _ = ops.tgat_forward(att.packed(), self.n_edge_features, Q, K, **kw)
     return out
 
   # ---- Path A: :116-147 --------------------------------------------------------------------------
-  @torch.no_grad()
   def compute_embedding(self, memory, source_nodes, timestamps, n_layers, n_neighbors, memory_updater=None, train=True):
     assert (n_layers >= 0)
     nodes = self._dev(source_nodes, torch.int64)
@@ -100,7 +113,7 @@ class GraphAttentionEmbedding(nn.Module):
     if n_layers == 0:
       m = self._memory_tables(memory, None, nodes, memory_updater, train)
       from .memory_updater import UpdatedMemoryView
-      return UpdatedMemoryView(m["table"], m["overlay"], m["flags"])[nodes]
+      return UpdatedMemoryView(m["table"], m["overlay"], m["flags"], m.get("upd_rows"), m.get("pos"))[nodes]
     K = n_neighbors
     f_nodes, f_ts, samples = [nodes], [ts], []
     for _ in range(n_layers):
@@ -121,7 +134,6 @@ class GraphAttentionEmbedding(nn.Module):
     return emb
 
   # ---- Path B: :154-182 --------------------------------------------------------------------------
-  @torch.no_grad()
   def compute_embedding_reuse(self, memory, source_nodes, timestamps, n_layers, n_neighbors, batch_id,
                               memory_updater=None, train=True):
     nodes = self._dev(source_nodes, torch.int64)
@@ -147,7 +159,6 @@ class GraphAttentionEmbedding(nn.Module):
     u = u[self.histories[0].flag[u] == 0]
     return u[1:]                                                    # :212 drops the first id (the dummy node 0)
 
-  @torch.no_grad()
   def compute_embedding_budget_reuse(self, memory, source_nodes, timestamps, n_layers, n_neighbors, batch_id,
                                      cache_plan, memory_updater=None, train=True):
     nodes = self._dev(source_nodes, torch.int64)

@@ -48,7 +48,8 @@ class History(torch.nn.Module):
   @torch.no_grad()
   def pull(self, inds):
     """history.py:32-36"""
-    return ops.gather_rows(self.emb, self._ids(inds))
+    from .. import torch_ops  # noqa: F401  (registers the orca:: ops)
+    return torch.ops.orca.history_pull(self.emb, self._ids(inds))
 
   @torch.no_grad()
   def push(self, x, inds):
@@ -57,7 +58,8 @@ class History(torch.nn.Module):
     if self._slot.device != self.emb.device or self._slot.numel() != self.emb.shape[0]:   # emb was rebound
       self._slot = torch.zeros(self.emb.shape[0], dtype=torch.int64, device=self.emb.device)
       self._epoch = 1
-    ops.history_push(self.emb, x.float().contiguous(), ids, self._slot, self._epoch)
+    from .. import torch_ops  # noqa: F401
+    torch.ops.orca.history_push(self.emb, x.detach().float().contiguous(), ids, self._slot, self._epoch)
     self._epoch += ids.numel() + 1
 
   def push_and_pull(self, x, push_inds, pull_inds):

@@ -11,8 +11,11 @@ class UpdatedMemoryView:
   (memory_updater.py:72): the persistent table plus an overlay holding GRU(message, memory) for the
   rows that had a pending message.  Indexing gathers the effective rows."""
 
-  def __init__(self, table, overlay, flags):
+  def __init__(self, table, overlay, flags, upd_rows=None, pos=None):
     self.table, self.overlay, self.flags = table, overlay, flags
+    # under autograd: the flagged rows again, compactly and attached to the graph (orca::gru_overlay), and
+    # pos[id] = the row of id among them -- gradients reach the GRU parameters through these
+    self.upd_rows, self.pos = upd_rows, pos
     self.shape = table.shape
 
   def __getitem__(self, idx):
@@ -23,7 +26,12 @@ class UpdatedMemoryView:
     base = ops.gather_rows(self.table, rows)
     if self.flags is None:
       return base
-    return torch.where(self.flags[rows].bool().unsqueeze(1), ops.gather_rows(self.overlay, rows), base)
+    sel = self.flags[rows].bool()
+    if self.upd_rows is not None and self.upd_rows.requires_grad:     # differentiable gather of the GRU rows
+      upd = self.upd_rows[torch.where(sel, self.pos[rows].long(), torch.zeros_like(rows))]
+    else:
+      upd = ops.gather_rows(self.overlay, rows)
+    return torch.where(sel.unsqueeze(1), upd, base)
 
   def materialize(self):
     return torch.where(self.flags.bool().unsqueeze(1), self.overlay, self.table) if self.flags is not None else self.table
@@ -59,7 +67,8 @@ class GRUMemoryUpdater(nn.Module):
       s = self._scratch = dict(slot=torch.zeros(n, dtype=torch.int64, device=dev), epoch=1,
                                worklist=torch.zeros(n, dtype=torch.int32, device=dev),
                                count=torch.zeros(1, dtype=torch.int32, device=dev),
-                               overlay=torch.zeros(n, ops.D, device=dev))
+                               overlay=torch.zeros(n, ops.D, device=dev),
+                               pos=torch.zeros(n, dtype=torch.int32, device=dev))
     return s
 
   def _worklist(self, memory, ids64):
@@ -93,22 +102,39 @@ class GRUMemoryUpdater(nn.Module):
                    memory.memory, memory.memory, memory.last_update, memory.timestamps)
     ops.fill_u8(memory.pending, 0)
 
-  @torch.no_grad()
   def get_updated_memory(self, memory, index=None):
     """memory_updater.py:56-78 -> (updated memory, updated last_update).  The memory is returned as an
-    UpdatedMemoryView (table + overlay), not a clone of the full table."""
+    UpdatedMemoryView (table + overlay), not a clone of the full table.  With autograd on (the training loop,
+    train.py:225-226) the GRU rows stay in the graph: gradients of whatever reads the view reach the GRU
+    parameters, as upstream; the memory table and the stored messages are data (memory.py:45-47)."""
     n = memory.n_nodes
-    ids = (torch.arange(n, dtype=torch.int64, device=memory.memory.device) if index is None
-           else self._ids(memory, index))
-    s = self._worklist(memory, ids)
-    ops.gru_update(self.packed(), self.message_dimension, s["worklist"], min(max(ids.numel(), 1), n), s["count"],
-                   memory.messages, memory.memory, s["overlay"])
-    sel = torch.zeros(n, dtype=torch.uint8, device=memory.memory.device)
-    if ids.numel():
-      sel[ids] = memory.pending[ids]
-    view = UpdatedMemoryView(memory.memory, s["overlay"], sel)
-    last = torch.where(sel.bool(), memory.timestamps, memory.last_update)
-    return view, last
+    c = self.memory_updater
+    grad = torch.is_grad_enabled() and any(p.requires_grad for p in c.parameters())
+    with torch.no_grad():
+      ids = (torch.arange(n, dtype=torch.int64, device=memory.memory.device) if index is None
+             else self._ids(memory, index))
+      s = self._worklist(memory, ids)
+      bound = min(max(ids.numel(), 1), n)
+      sel = torch.zeros(n, dtype=torch.uint8, device=memory.memory.device)
+      if ids.numel():
+        sel[ids] = memory.pending[ids]
+      last = torch.where(sel.bool(), memory.timestamps, memory.last_update)
+    upd = None
+    if grad:
+      # the rows stay in the autograd graph: GRUCell as the custom op orca::gru_cell on the gathered rows of the
+      # work-list (its length is read back: the one host sync of this path), then copied into the overlay table
+      from .. import torch_ops  # noqa: F401  (registers the orca:: ops)
+      wl = s["worklist"][:int(s["count"].item())].long()
+      upd = torch.ops.orca.gru_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, self.packed(),
+                                    memory.messages.detach()[wl], memory.memory.detach()[wl])
+      with torch.no_grad():
+        s["overlay"][wl] = upd.detach()
+        s["pos"][wl] = torch.arange(wl.numel(), dtype=torch.int32, device=wl.device)
+    else:
+      with torch.no_grad():
+        ops.gru_update(self.packed(), self.message_dimension, s["worklist"], bound, s["count"], memory.messages,
+                       memory.memory, s["overlay"])
+    return UpdatedMemoryView(memory.memory, s["overlay"], sel, upd, s["pos"] if grad else None), last
 
 
 def get_memory_updater(module_type, message_dimension, memory_dimension, device):

@@ -58,11 +58,10 @@ class NeighborFinder:
     ts = torch.as_tensor(np.asarray(timestamps) if not isinstance(timestamps, torch.Tensor) else timestamps)
     nodes = nodes.to(device=self.device, dtype=torch.int64)
     ts = ts.to(device=self.device, dtype=torch.float64)
-    err = torch.zeros(1, dtype=torch.int32, device=self.device)
-    out = ops.sample_recent(self.csr, nodes, ts, int(n_neighbors), err_flag=err)
-    if int(err.item()):
+    if nodes.numel() and (int(nodes.min()) < 0 or int(nodes.max()) >= self.csr.n_rows):
       raise IndexError("list index out of range: node id outside the neighbor finder")
-    return out
+    from .. import torch_ops  # noqa: F401  (registers the orca:: ops)
+    return torch.ops.orca.sample_recent(self.csr._h.value, nodes, ts, int(n_neighbors))
 
   def get_temporal_neighbor(self, source_nodes, timestamps, n_neighbors):
     """utils/util.py:134-151: NumPy in, NumPy (int32, int32, float32) [Q, K] out, right-aligned, zero padded."""

@@ -20,34 +20,11 @@ class MergeLayer(nn.Module):
     return self.fc2(self.act(self.fc1(torch.cat([x1, x2], dim=1))))
 
 
-class _AttentionFn(torch.autograd.Function):
-  """forward = the fused HIP kernel, backward = orca_tgat_backward (both through the C ABI)."""
-
-  @staticmethod
-  def forward(ctx, layer, B, K, src, st, nbr, nt, edge, mask, *params):
-    before = mask.clone()                       # the forward un-masks slot 0 of all-padded rows in place (:46-47)
-    out, wts = ops.tgat_forward(layer.packed(), layer.n_edge_features, B, K, want_weights=True, src_table=src,
-                                nbr_table=nbr, edge_table=edge, mask=mask.view(torch.uint8), src_time=st, nbr_time=nt)
-    ctx.layer, ctx.B, ctx.K = layer, B, K
-    ctx.save_for_backward(src, st, nbr, nt, edge, before, *params)
-    ctx.mark_non_differentiable(wts)
-    return out, wts
-
-  @staticmethod
-  def backward(ctx, g_out, _g_wts):
-    src, st, nbr, nt, edge, before, *params = ctx.saved_tensors
-    sd = dict(zip(ops.TGAT_KEYS, params))
-    grads, d_src, d_nbr, d_st, d_nt, _, _ = ops.tgat_backward(
-        sd, ctx.layer.n_edge_features, ctx.B, ctx.K, g_out, src_table=src, nbr_table=nbr, edge_table=edge,
-        mask=before.view(torch.uint8), src_time=st, nbr_time=nt)
-    return (None, None, None, d_src, d_st, d_nbr, d_nt, None, None) + tuple(grads[k] for k in ops.TGAT_KEYS)
-
-
 class TemporalAttentionLayer(nn.Module):
   """Same constructor, parameters (state_dict keys) and forward contract as the reference; forward runs the
-  fused HIP kernel and, under autograd, backward runs orca_tgat_backward (gradients of all twelve parameters
-  and of the node / time feature inputs; edge features are data upstream and get none).  Dropout is not applied
-  (module.eval() semantics)."""
+  fused HIP kernel (the custom op orca::tgat_dense, orca_amd/torch_ops.py) and, under autograd, backward runs
+  orca_tgat_backward (gradients of all twelve parameters and of the node / time feature inputs; edge features are
+  data upstream and get none).  Dropout is not applied (module.eval() semantics)."""
 
   def __init__(self, n_node_features, n_neighbors_features, n_edge_features, time_dim, output_dimension, n_head=2,
                dropout=0.1):
@@ -92,8 +69,8 @@ class TemporalAttentionLayer(nn.Module):
     edge = f(edge_features, self.n_edge_features)
     named = dict(self.named_parameters())
     params = [named[k] for k in ops.TGAT_KEYS]
-    if torch.is_grad_enabled() and any(t.requires_grad for t in params + [src, st, nbr, nt]):
-      return _AttentionFn.apply(self, B, K, src, st, nbr, nt, edge, mask, *params)
-    with torch.no_grad():
-      return ops.tgat_forward(self.packed(), self.n_edge_features, B, K, want_weights=True, src_table=src,
-                              nbr_table=nbr, edge_table=edge, mask=mask.view(torch.uint8), src_time=st, nbr_time=nt)
+    from .. import torch_ops  # noqa: F401  (registers the orca:: ops)
+    out, wts, after = torch.ops.orca.tgat_dense(params, self.packed(), self.n_edge_features, src, st, nbr, nt, edge,
+                                                mask.clone())     # (the op keeps this copy for its backward)
+    mask.copy_(after.detach())          # temporal_attention.py:46-47 mutates the caller's mask
+    return out, wts.detach()            # the weights are unused upstream (embedding_module.py:326): no gradient through them

@@ -1,7 +1,9 @@
 """model/tgn_model.py:13-195 -- the caller of the hot path, kept thin: it wires the mirrored modules in
 the reference's order (train: embed -> persist memory -> store raw messages; eval: embed -> store ->
 persist) so that a reference state_dict loads by key and the parity tests read like the reference's
-own flow.  Forward only."""
+own flow.  It trains: loss.backward() on compute_edge_probabilities' outputs reaches the attention layers, the GRU
+and the link decoder exactly where the reference's autograd graph does (the state writes -- memory persist, raw
+message store, history push -- are detached, as upstream)."""
 import numpy as np
 import torch
 
@@ -56,7 +58,6 @@ class TGN(torch.nn.Module):
     self._epoch = 1
     self.to(device)
 
-  @torch.no_grad()
   def compute_temporal_embeddings(self, source_nodes, destination_nodes, negative_nodes, edge_times, edge_idxs,
                                   n_neighbors, reuse, train, cache_plan):
     """tgn_model.py:95-147"""
@@ -87,13 +88,14 @@ class TGN(torch.nn.Module):
     else:
       emb = em.compute_embedding(memory=memory, source_nodes=nodes, timestamps=timestamps, n_layers=self.n_layers,
                                  n_neighbors=n_neighbors, memory_updater=self.memory_updater, train=train)
-    if train:                                                              # :127-129
-      self.memory_updater.update_memory(self.memory, positives)
-      self.memory.clear_messages(positives)
-    self.get_raw_messages_and_store(source_nodes, destination_nodes, edge_times, edge_idxs)   # :131-141
-    if not train:                                                          # :143-145
-      self.memory_updater.update_memory(self.memory, positives)
-      self.memory.clear_messages(positives)
+    with torch.no_grad():
+      if train:                                                            # :127-129
+        self.memory_updater.update_memory(self.memory, positives)
+        self.memory.clear_messages(positives)
+      self.get_raw_messages_and_store(source_nodes, destination_nodes, edge_times, edge_idxs)   # :131-141
+      if not train:                                                        # :143-145
+        self.memory_updater.update_memory(self.memory, positives)
+        self.memory.clear_messages(positives)
     return emb[:n_samples], emb[n_samples:2 * n_samples], emb[2 * n_samples:]
 
   def get_raw_messages_and_store(self, source_nodes, destination_nodes, edge_times, edge_idxs):
@@ -102,13 +104,13 @@ class TGN(torch.nn.Module):
     dev = self.device
     f = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x)).to(device=dev, dtype=dt)
     m, te = self.memory, self.time_encoder.w
-    ops.message_store(f(source_nodes, torch.int64), f(destination_nodes, torch.int64), f(edge_idxs, torch.int64),
-                      f(edge_times, torch.float64), m.memory, m.last_update, self.edge_raw_features,
-                      te.weight.reshape(-1).contiguous(), te.bias.contiguous(), self._slot, self._epoch, m.messages,
-                      m.timestamps, m.pending)
+    from .. import torch_ops  # noqa: F401  (registers the orca:: ops)
+    torch.ops.orca.message_store(f(source_nodes, torch.int64), f(destination_nodes, torch.int64), f(edge_idxs, torch.int64),
+                                 f(edge_times, torch.float64), m.memory, m.last_update, self.edge_raw_features,
+                                 te.weight.detach().reshape(-1).contiguous(), te.bias.detach().contiguous(), self._slot,
+                                 self._epoch, m.messages, m.timestamps, m.pending)
     self._epoch += 2 * len(source_nodes) + 1
 
-  @torch.no_grad()
   def compute_edge_probabilities(self, source_nodes, destination_nodes, negative_nodes, edge_times, edge_idxs,
                                  n_neighbors, reuse, train, cache_plan):
     """tgn_model.py:150-157"""

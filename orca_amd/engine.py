@@ -61,6 +61,9 @@ class OrcaEngine:
     self.sampling, self.seed = sampling, int(seed)
     self.exchange_cap = exchange_cap
     self._sharded = False    # True: memory / last_update / messages / msg_ts rows are current only on their owner
+    # the reference freezes its time encoder (model/time_encoding.py:20-23: requires_grad False, forward under no_grad):
+    # train_step returns no gradient for it unless this is set (the kernels can produce one: tests)
+    self.train_time_encoder = False
     dev = self.device
     ef = edge_feats if isinstance(edge_feats, torch.Tensor) else torch.as_tensor(np.asarray(edge_feats))
     self.edge_feats = ef.to(device=dev, dtype=torch.float32).contiguous()
@@ -749,9 +752,10 @@ class OrcaEngine:
     else:
       for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
         grads[p + k] = torch.zeros_like(self.params[p + k])
-    grads["time_encoder.w.weight"] = d_tw.view(D, 1)
-    if "time_encoder.w.bias" in self.params:
-      grads["time_encoder.w.bias"] = d_tb
+    if self.train_time_encoder:
+      grads["time_encoder.w.weight"] = d_tw.view(D, 1)
+      if "time_encoder.w.bias" in self.params:
+        grads["time_encoder.w.bias"] = d_tb
     if self.world > 1:                     # every rank holds the decoder's full gradient already
       keys = sorted(k for k in grads if not k.startswith("affinity_score."))
       flat = torch.cat([grads[k].reshape(-1) for k in keys])
@@ -771,7 +775,8 @@ class OrcaEngine:
   def optimizer(self, lr=1e-4):
     """torch.optim.Adam over the raw parameter tensors (train.py:180): the optimizer updates self.params in place;
     step_optimizer() feeds it train_step's gradients and re-packs the kernels' blobs."""
-    self._opt_params = {k: torch.nn.Parameter(v) for k, v in self.params.items() if v.is_floating_point()}
+    self._opt_params = {k: torch.nn.Parameter(v) for k, v in self.params.items() if v.is_floating_point() and
+                        (self.train_time_encoder or not k.startswith("time_encoder."))}
     self._opt = torch.optim.Adam(self._opt_params.values(), lr=lr)
     return self._opt
 

@@ -100,3 +100,24 @@ def test_mrd_planner_edge_cases():
   _, plans, _, _ = _plan(np.array([1, 2, 3, 1], np.int64), np.array([2, 3, 1, 3], np.int64), np.array([1.0, 2.0, 3.0, 4.0]),
                          np.array([1, 2, 3, 4], np.int64), 5, 2, 3, 0)
   assert all(len(p) == 0 for p in plans)
+
+
+def test_torch_custom_ops_are_registered():
+  """orca_amd/torch_ops.py registers the entry points as torch.library custom ops (namespace orca) with autograd
+  formulas for the attention and GRU ops; without a HIP device a call must fail loudly (no CPU fallback)."""
+  import torch
+  from orca_amd import torch_ops
+  from orca_amd._lib import OrcaError
+  for name in torch_ops.OPS:
+    assert hasattr(torch.ops.orca, name), name
+  schema = str(torch.ops.orca.tgat_gather.default._schema)
+  assert "Tensor[] params" in schema and "Tensor? upd_rows" in schema
+  assert "Tensor(a" not in str(torch.ops.orca.gru_cell.default._schema)      # functional: it carries an autograd formula
+  x, h = torch.zeros(3, 472), torch.zeros(3, 100)
+  w = [torch.zeros(300, 472), torch.zeros(300, 100), torch.zeros(300), torch.zeros(300)]
+  try:
+    torch.ops.orca.gru_cell(*w, torch.zeros(8), x, h)
+  except (OrcaError, RuntimeError, OSError, AssertionError):
+    pass
+  else:
+    raise AssertionError("a CPU call of orca::gru_cell must not succeed")

@@ -146,7 +146,7 @@ def test_memory_and_updater(api):
   hit = index[np.isin(index, ids)]
   exp = m0.clone()
   exp[hit] = O.gru_cell(P, msgs[np.searchsorted(ids, hit)], m0[hit])
-  assert_close_fp32(view[torch.from_numpy(np.arange(N))].cpu().numpy(), exp.numpy(), 1e-5, "get_updated_memory")
+  assert_close_fp32(view[torch.from_numpy(np.arange(N))].detach().cpu().numpy(), exp.numpy(), 1e-5, "get_updated_memory")
   assert np.array_equal(mem.memory.cpu().numpy(), m0.numpy())               # persistent table untouched
   exp_last = np.zeros(N, np.float32)
   exp_last[hit] = ts.numpy()[np.searchsorted(ids, hit)]
@@ -197,11 +197,13 @@ def test_tgn_flow_like_the_reference(api, golden, tag, graph):
     for _ in range(nb):
       s, e = b * bs, min(n_edges, (b + 1) * bs)
       plan = g[f"{tag}_plan{b}"] if (budget and phase == "train") else None
-      pos, neg = tgn.compute_edge_probabilities(src[s:e], dst[s:e], negs[s:e], ts[s:e], eidx[s:e], K, bool(reuse),
-                                                phase == "train", plan)
+      with torch.set_grad_enabled(phase == "train"):       # evaluation/evaluation.py:18 runs under no_grad
+        pos, neg = tgn.compute_edge_probabilities(src[s:e], dst[s:e], negs[s:e], ts[s:e], eidx[s:e], K, bool(reuse),
+                                                  phase == "train", plan)
       what = f"{tag} batch {b} ({phase})"
-      assert_close_fp32(pos.cpu().numpy(), g[f"{tag}_b{b}_pos"], 1e-5, what + " pos")
-      assert_close_fp32(neg.cpu().numpy(), g[f"{tag}_b{b}_neg"], 1e-5, what + " neg")
+      assert pos.requires_grad == (phase == "train")        # the train phase builds the autograd graph, as upstream
+      assert_close_fp32(pos.detach().cpu().numpy(), g[f"{tag}_b{b}_pos"], 1e-5, what + " pos")
+      assert_close_fp32(neg.detach().cpu().numpy(), g[f"{tag}_b{b}_neg"], 1e-5, what + " neg")
       assert_close_fp32(tgn.memory.memory.cpu().numpy(), g[f"{tag}_b{b}_memory"], 1e-5, what + " memory")
       assert np.array_equal(tgn.memory.last_update.cpu().numpy(), g[f"{tag}_b{b}_last_update"])
       assert np.array_equal(tgn.memory.nodes, g[f"{tag}_b{b}_pending"])
@@ -273,6 +275,73 @@ def test_eval_edge_prediction_drives_the_hip_model(api, golden):
     _, neg = smp.sample(len(data.sources[r]))
     p, n = m2.compute_edge_probabilities(data.sources[r], data.destinations[r], neg, data.timestamps[r], data.edge_idxs[r],
                                          K, True, False, None)
-    p, n = p.cpu().numpy(), n.cpu().numpy()
+    p, n = p.detach().cpu().numpy(), n.detach().cpu().numpy()
     aps.append(average_precision_score(np.concatenate([np.ones(len(p)), np.zeros(len(n))]), np.concatenate([p, n])))
   assert ap == np.mean(aps) and 0.0 <= auc <= 1.0 and 0.0 <= acc <= 1.0
+
+
+@pytest.mark.parametrize("reuse,L", [(True, 2), (False, 2), (False, 1)])
+def test_training_loop_through_the_drop_in(api, reuse, L):
+  """The reference's training loop shape (train.py:206-264: compute_edge_probabilities -> BCE on pos / neg ->
+  loss.backward() -> Adam step) on orca_amd.api.TGN: the loss back-propagates through the custom ops
+  (orca::tgat_gather, orca::gru_cell; orca_amd/torch_ops.py) into the attention layers, the GRU and the link decoder.
+  Gradients and the parameters after each Adam step must match OrcaEngine.train_step / step_optimizer (whose
+  gradients tests/test_gpu_backward.py checks against torch autograd of the oracle) at 1e-5; the time encoder stays
+  frozen as upstream (model/time_encoding.py:20-23).  Dropout 0 (the mirror applies none)."""
+  from orca_amd import ops, synth
+  from orca_amd.engine import OrcaEngine
+  N, E, K, d_e, bs = 1500, 30000, 10, 172, 150
+  src, dst, eidx, ts = synth.powerlaw_graph(N, E, "cuda:0", seed=5)
+  ef = synth.edge_features(E, d_e, "cuda:0")
+  sd = synth.tgn_state_dict(d_e, L, seed=2)
+  csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
+  args = argparse.Namespace(n_nodes=N + 1, n_edges=E + 1, reuse=reuse, budget=0, gradient=False, bs=bs, n_degree=K)
+  nf = api.NeighborFinder(None, None, None, device=DEV, _csr=csr)
+  tgn = api.TGN(neighbor_finder=nf, node_features=None, edge_features=ef, device=DEV, n_layers=L, n_heads=2, dropout=0.0,
+                n_neighbors=K, args=args)
+  missing = tgn.load_state_dict({k: v for k, v in sd.items() if k in tgn.state_dict()}, strict=False)
+  # (embedding_module.time_encoder is the same module as time_encoder, as upstream: its keys alias the loaded ones)
+  assert not [k for k in missing.missing_keys if not k.startswith("embedding_module.time_encoder.")], missing
+  tgn.train()
+  eng = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=0, device="cuda:0")
+  eng.set_neighbor_finder(csr)
+  opt = torch.optim.Adam(tgn.parameters(), lr=1e-3)               # train.py:180
+  eng.optimizer(lr=1e-3)
+  crit = torch.nn.BCELoss()                                        # train.py:179
+  rs = np.random.RandomState(0)
+  h = lambda x: x.cpu().numpy()
+  for b in range(4):
+    s, e = 20000 + b * bs, 20000 + (b + 1) * bs
+    neg = rs.randint(1, N + 1, bs).astype(np.int64)
+    opt.zero_grad()
+    pos_p, neg_p = tgn.compute_edge_probabilities(h(src[s:e]), h(dst[s:e]), neg, h(ts[s:e]), h(eidx[s:e]), K, reuse, True, None)
+    loss = crit(pos_p.squeeze(), torch.ones(bs, device=DEV)) + crit(neg_p.squeeze(), torch.zeros(bs, device=DEV))   # train.py:231-233
+    loss.backward()
+    ref_loss, grads = eng.train_step(src[s:e], dst[s:e], torch.from_numpy(neg).to(DEV), ts[s:e], eidx[s:e])
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-5 * max(1.0, abs(float(ref_loss))), f"batch {b} loss"
+    named = dict(tgn.named_parameters())
+    checked = 0
+    for k, gref in grads.items():
+      p = named[k]
+      if k.endswith("in_proj_bias") and p.grad is not None:
+        pass
+      assert p.grad is not None, f"batch {b}: no gradient reached {k}"
+      assert_close_fp32(p.grad.cpu().numpy().reshape(-1), gref.cpu().numpy().reshape(-1), 1e-5, f"batch {b} grad {k}")
+      checked += 1
+    assert checked >= L * 12 + 4 + 4
+    assert named["time_encoder.w.weight"].grad is None and named["time_encoder.w.bias"].grad is None
+    opt.step()
+    eng.step_optimizer(grads)
+    # Adam's first steps move every element by about lr * g / (|g| + 1e-8): where a gradient is at round-off level
+    # (|g| ~ 1e-8) the two 1e-5-close gradients give visibly different steps, so the parameters are compared at the
+    # size of a step and then made identical again -- the next batch's loss and gradients (1e-5) start from equal weights
+    with torch.no_grad():
+      for k in grads:
+        assert_close_fp32(named[k].detach().cpu().numpy().reshape(-1), eng.params[k].cpu().numpy().reshape(-1), 2e-3,
+                          f"batch {b} parameter {k} after the Adam step")
+        eng.params[k].copy_(named[k].detach().reshape(eng.params[k].shape))
+    eng.refresh()
+    assert_close_fp32(tgn.memory.memory.cpu().numpy(), eng.memory.cpu().numpy(), 1e-5, f"batch {b} memory")
+    assert_close_fp32(tgn.memory.messages.cpu().numpy(), eng.messages.cpu().numpy(), 1e-5, f"batch {b} messages")
+  for k in grads:        # every parameter the loss reaches has been trained (the GRU from the second batch on)
+    assert not torch.equal(named[k].detach().reshape(-1), sd[k].to(DEV).reshape(-1)), f"{k} did not move"

@@ -181,6 +181,7 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs):
   for _ in range(2):
     e = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=0, device="cuda:0")
     e.set_neighbor_finder(csr)
+    e.train_time_encoder = True     # the kernels' time-encoder gradient is checked too (frozen upstream: off by default)
     engs.append(e)
   A, B = engs
   rs = np.random.RandomState(0)
