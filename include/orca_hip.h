@@ -438,6 +438,18 @@ int orca_mrd_plan_host(int64_t n_interactions, int64_t bs, int K, const int64_t*
                        int64_t* plan_out_host, int64_t* plan_len_host, int64_t* stats_host,
                        double* avg_reuse_distance_host);
 
+/* The same plan computed ON THE DEVICE (csrc/plan_dev.hip): src, dst, nbr_src, nbr_dst, plan_out [num_batch * budget] and
+ * plan_len [num_batch] are DEVICE arrays (the neighbours can stay where orca_sample_recent wrote them); stats_host [2]
+ * and avg_reuse_distance_host are host scalars filled before the call returns (it synchronises the stream and
+ * allocates its temporaries with hipMalloc).  Pass 1 is radix sorts over all batches at once, pass 2 one workgroup
+ * walking the batches with an LDS sort of each batch's candidates; budget and the candidates of one batch
+ * (budget + uncached out-of-batch neighbours + targets) are limited to 16384 (ORCA_EINVAL beyond: use the host
+ * planner).  Entry for entry the plan of orca_mrd_plan_host. */
+int orca_mrd_plan_device(int64_t n_interactions, int64_t bs, int K, const int64_t* src, const int64_t* dst,
+                         const int32_t* nbr_src, const int32_t* nbr_dst, int64_t n_nodes, int64_t budget,
+                         int64_t* plan_out, int64_t* plan_len, int64_t* stats_host, double* avg_reuse_distance_host,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

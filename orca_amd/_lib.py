@@ -109,6 +109,7 @@ SIGNATURES = {
     "orca_engine_get_overlay_complete": (i32, [vp]),
     "orca_engine_drain": (i32, [vp, vp]),
     "orca_mrd_plan_host": (i32, [i64, i64, i32, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]),
+    "orca_mrd_plan_device": (i32, [i64, i64, i32, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp]),
 }
 
 _lib = None

@@ -219,30 +219,60 @@ def test_tgn_flow_like_the_reference(api, golden, tag, graph):
     api.get_embedding_module("graph_sum", None, None, None, None, None, 1, 100, 172, 100, 100, DEV)
 
 
+@pytest.mark.parametrize("planner", ["device", "host"])
 @pytest.mark.parametrize("tag", ["tight", "loose", "mid"])
-def test_get_cache_plan(api, golden, tag, capsys):
+def test_get_cache_plan(api, golden, tag, planner, capsys):
+  """utils/cache.py:407-428 through the mirror, planned on the device (csrc/plan_dev.hip) and on the host
+  (csrc/plan.hip): plan sizes and the tie-free trace against the reference's golden plans, every plan against the
+  oracle under the defined (distance, node id) order."""
   g = golden("mrd.npz")
   n_nodes, n_edges, bs, K, budget, num_batch = [int(x) for x in g[f"{tag}_meta"]]
   src, dst, ts, eidx = (g[f"{tag}_{k}"] for k in ("src", "dst", "ts", "eidx"))
   data = Data(src, dst, ts, eidx)
   nf = api.get_neighbor_finder(data, max_node_idx=n_nodes, device=DEV)
-  args = argparse.Namespace(n_nodes=n_nodes + 1, bs=bs, n_degree=K, budget=budget)
+  args = argparse.Namespace(n_nodes=n_nodes + 1, bs=bs, n_degree=K, budget=budget, planner=planner)
   plans = api.get_cache_plan(args, data, nf, args.n_nodes, "MRD")
-  assert "n_reuse" in capsys.readouterr().out
+  out = capsys.readouterr().out
+  assert "n_reuse" in out and "planning on the host" not in out
   assert len(plans) == num_batch
   assert np.array_equal(np.array([len(p) for p in plans]), g[f"{tag}_plan_len"])
   # exact plans under the defined (distance, node id) order == the oracle in stable mode
   onf = O.OracleNeighborFinder(src, dst, eidx, ts, max_node_idx=n_nodes)
   nb, tl, nl, occ = O.read_batches(src, dst, ts, onf, bs, K, n_nodes + 1)
-  ref, _, _, _ = O.mrd_plan(n_nodes + 1, nb, budget, tl, nl, occ, stable=True)
+  ref, n_reuse, n_recompute, avg_rd = O.mrd_plan(n_nodes + 1, nb, budget, tl, nl, occ, stable=True)
   for a, b in zip(plans, ref):
     assert np.array_equal(a, b)
+  assert f"n_reuse {n_reuse}, n_recompute {n_recompute}," in out             # cache.py:115,119,427
+  assert abs(float(out.split("average_reuse_distance")[1].split()[0]) - avg_rd) <= 1e-9 * max(1.0, abs(avg_rd))
   if tag == "loose":   # no tie group straddles the budget cut: same sets as the reference's own plan
     off = np.concatenate([[0], np.cumsum(g[f"{tag}_plan_len"])])
     for i, p in enumerate(plans):
       assert np.array_equal(np.sort(p), np.sort(g[f"{tag}_plan_flat"][off[i]:off[i + 1]]))
   with pytest.raises(SystemExit):
     api.get_cache_plan(args, data, nf, args.n_nodes, "LRU")
+
+
+def test_device_planner_equals_host_planner_on_a_long_trace(api, capsys):
+  """The two MRD planners (device: csrc/plan_dev.hip, host: csrc/plan.hip) on 1,500 batches of a power-law graph
+  with hubs (many ties at the maximum distance, cached ids that are targets again, budget smaller and larger than
+  a batch's candidates): identical plans, entry for entry, and identical reuse statistics."""
+  from orca_amd import synth
+  N, E, bs, K = 4000, 300000, 200, 10
+  src, dst, eidx, ts = (x.cpu().numpy() for x in synth.powerlaw_graph(N, E, "cuda:0", seed=17))
+  data = Data(src, dst, ts, eidx)
+  nf = api.get_neighbor_finder(data, max_node_idx=N, device=DEV)
+  for budget in (50, 1000, 6000):
+    res = {}
+    for planner in ("device", "host"):
+      args = argparse.Namespace(n_nodes=N + 1, bs=bs, n_degree=K, budget=budget, planner=planner)
+      plans = api.get_cache_plan(args, data, nf, args.n_nodes, "MRD")
+      out = capsys.readouterr().out
+      assert "planning on the host" not in out
+      res[planner] = (plans, out.split("n_reuse")[1])
+    assert len(res["device"][0]) == len(res["host"][0]) == E // bs
+    for a, b in zip(res["device"][0], res["host"][0]):
+      assert np.array_equal(a, b)
+    assert res["device"][1] == res["host"][1]
 
 
 def test_eval_edge_prediction_drives_the_hip_model(api, golden):

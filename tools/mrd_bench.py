@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Times get_cache_plan (device sampling of every interaction's neighbours + the host MRD planner) on a trace
-of BASELINE config 3's size: Wiki-Talk-like 7.8 M interactions, bs = 200 -> 39 k batches, budget 1000."""
+"""Times get_cache_plan (device sampling of every interaction's neighbours + the MRD planner, on the device and on
+the host) on a trace of BASELINE config 3's size: Wiki-Talk-like 7.8 M interactions, 70 % of them training
+interactions, bs = 200 -> 27 k batches, budget 1000."""
 import argparse
 import os
 import sys
@@ -29,12 +30,16 @@ def main():
   nf = api.get_neighbor_finder(data, max_node_idx=a.nodes, device=dev)
   torch.cuda.synchronize()
   t_csr = time.time() - t0
-  args = argparse.Namespace(bs=a.bs, n_degree=a.k, budget=a.budget)
-  t0 = time.time()
-  plan = api.get_cache_plan(args, data, nf, a.nodes + 1, "MRD")
-  t_plan = time.time() - t0
-  print(f"interactions {n_train}, batches {len(plan)}, budget {a.budget}: CSR build {t_csr:.2f} s, "
-        f"get_cache_plan {t_plan:.2f} s, mean plan size {np.mean([len(p) for p in plan]):.1f}")
+  plans = {}
+  for planner in ("device", "host"):
+    args = argparse.Namespace(bs=a.bs, n_degree=a.k, budget=a.budget, planner=planner)
+    t0 = time.time()
+    plan = plans[planner] = api.get_cache_plan(args, data, nf, a.nodes + 1, "MRD")
+    t_plan = time.time() - t0
+    print(f"[{planner} planner] interactions {n_train}, batches {len(plan)}, budget {a.budget}: CSR build {t_csr:.2f} s, "
+          f"get_cache_plan {t_plan:.2f} s, mean plan size {np.mean([len(p) for p in plan]):.1f}", flush=True)
+  same = all(np.array_equal(x, y) for x, y in zip(plans["device"], plans["host"]))
+  print("device plan == host plan, entry for entry:", same)
 
 
 if __name__ == "__main__":
