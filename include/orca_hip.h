@@ -297,6 +297,14 @@ int orca_gather_rows(const float* table, int64_t width, const int64_t* idx64, co
 int orca_index_positions(const int32_t* list, int64_t n, const int32_t* n_dev, int32_t* pos, void* stream);
 int orca_scatter_add_flagged(const float* rows, const int64_t* idx64, const int32_t* idx32, int64_t n,
                              const uint8_t* flags, const int32_t* pos, int64_t n_nodes, float* dst, void* stream);
+/* find_uncached_out_of_batch_neighbors (modules/embedding_module.py:200-212): the distinct ids of nbr [n_nbr] (int32,
+ * the sampled neighbours) that are not among batch_nodes [n_batch] and have cache_flag[id] == 0, ascending, WITHOUT
+ * the first of them (the reference's `[1:]`, which assumes it is the padding id 0: SURVEY H8) -> out[0 .. *count),
+ * at most cap entries written (*count is the full number).  slot / epoch as in orca_segment_last (one epoch);
+ * bitmap: caller-owned uint32 [ceil(n_nodes / 32)], all zero on entry and left all zero. */
+int orca_find_uncached(const int32_t* nbr, int64_t n_nbr, const int64_t* batch_nodes, int64_t n_batch,
+                       const uint8_t* cache_flag, int64_t* slot, int64_t epoch, int64_t n_nodes, uint32_t* bitmap,
+                       int64_t* out, int64_t cap, int32_t* count, void* stream);
 /* out_table[ids[p]] = x[p] (ids unique; Memory.set_memory modules/memory.py:33-34) */
 int orca_scatter_rows(float* table, int64_t width, const int64_t* ids, int64_t n, const float* x,
                       void* stream);

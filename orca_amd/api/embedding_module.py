@@ -154,10 +154,16 @@ class GraphAttentionEmbedding(nn.Module):
     """:200-212 (device tensors in, device tensor out)"""
     if n_layers == 1:
       return torch.zeros(0, dtype=torch.int64, device=self.device)
-    u = torch.unique(self._dev(neighbors, torch.int64).flatten())
-    u = u[~torch.isin(u, self._dev(source, torch.int64))]
-    u = u[self.histories[0].flag[u] == 0]
-    return u[1:]                                                    # :212 drops the first id (the dummy node 0)
+    h = self.histories[0]
+    if getattr(self, "_bitmap", None) is None or self._bitmap.device != h.flag.device:
+      self._bitmap = torch.zeros((h.flag.numel() + 31) // 32, dtype=torch.int32, device=h.flag.device)
+      self._fu_slot = torch.zeros(h.flag.numel(), dtype=torch.int64, device=h.flag.device)
+      self._fu_epoch = 1
+    self._fu_epoch += 1
+    # one device pass (orca_find_uncached): sorted unique, minus the batch, minus the cached ids, minus the first
+    # id (:212 drops it, assuming it is the dummy node 0)
+    return ops.find_uncached(self._dev(neighbors, torch.int32).flatten(), self._dev(source, torch.int64), h.flag,
+                             self._fu_slot, self._fu_epoch, self._bitmap)
 
   def compute_embedding_budget_reuse(self, memory, source_nodes, timestamps, n_layers, n_neighbors, batch_id,
                                      cache_plan, memory_updater=None, train=True):

@@ -115,7 +115,7 @@ static inline bool orca_first_use_on_device(bool (&seen)[64]) {
   return true;
 }
 
-static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

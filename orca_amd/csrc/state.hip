@@ -215,8 +215,75 @@ __global__ __launch_bounds__(256) void k_scatter_rows(float* __restrict__ table,
   for (int64_t c = lane; c < width; c += 64) table[r * width + c] = x[p * width + c];
 }
 
+// ---- find_uncached_out_of_batch_neighbors (modules/embedding_module.py:200-212) on the device -------------------
+// np.unique(neighbors) minus the batch's own nodes minus the cached ids, ascending, then WITHOUT its first element
+// (the reference drops it on the assumption that it is the padding id 0: SURVEY H8).  Three small kernels: the
+// batch's nodes stamp slot[id] = epoch; every neighbour that is not stamped and not flagged sets its bit in a
+// [n_nodes] bitmap; one workgroup scans the bitmap in ascending order (popcount prefix over its words), writes the
+// ids past the first, clears the words it read and leaves the count.
+__global__ void k_stamp_ids(const int64_t* __restrict__ ids, int64_t n, int64_t* __restrict__ slot, int64_t epoch,
+                            int64_t n_nodes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = ids[i];
+  if (v >= 0 && v < n_nodes) slot[v] = epoch;
+}
+__global__ void k_mark_uncached(const int32_t* __restrict__ nbr, int64_t n, const int64_t* __restrict__ slot, int64_t epoch,
+                                const uint8_t* __restrict__ cache_flag, int64_t n_nodes, uint32_t* __restrict__ bitmap) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = nbr[i];
+  if (v < 0 || v >= n_nodes || slot[v] == epoch || cache_flag[v]) return;
+  atomicOr(&bitmap[v >> 5], 1u << (v & 31));
+}
+__global__ __launch_bounds__(1024) void k_scan_bitmap(uint32_t* __restrict__ bitmap, int64_t n_words, int64_t* __restrict__ out,
+                                                      int64_t cap, int32_t* __restrict__ count) {
+  __shared__ int64_t wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t per = ceil_div64(n_words, 1024);          // consecutive words per thread: thread order = id order
+  const int64_t w0 = tid * per, w1 = w0 + per < n_words ? w0 + per : n_words;
+  int64_t mine = 0;
+  for (int64_t w = w0; w < w1; ++w) mine += __popc(bitmap[w]);
+  int64_t incl = mine;                                     // inclusive prefix over the wave
+  for (int o = 1; o < 64; o <<= 1) {
+    const int64_t up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int64_t base = 0, total = 0;
+  for (int w = 0; w < 16; ++w) { if (w < wave) base += wave_tot[w]; total += wave_tot[w]; }
+  int64_t k = base + incl - mine;                          // rank of this thread's first id
+  for (int64_t w = w0; w < w1; ++w) {
+    uint32_t bits = bitmap[w];
+    if (!bits) continue;
+    bitmap[w] = 0;                                         // the bitmap is clean again for the next call
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      if (k >= 1 && k - 1 < cap) out[k - 1] = w * 32 + b;  // [1:] drops the smallest id
+      ++k;
+    }
+  }
+  if (tid == 0) *count = (int32_t)(total > 0 ? total - 1 : 0);
+}
+
 inline unsigned blocks(int64_t n, int per) { return (unsigned)ceil_div64(n, per); }
 }  // namespace
+
+ORCA_API int orca_find_uncached(const int32_t* nbr, int64_t n_nbr, const int64_t* batch_nodes, int64_t n_batch,
+                                const uint8_t* cache_flag, int64_t* slot, int64_t epoch, int64_t n_nodes, uint32_t* bitmap,
+                                int64_t* out, int64_t cap, int32_t* count, void* stream) {
+  ORCA_REQUIRE(n_nbr >= 0 && n_batch >= 0 && n_nodes > 0 && cap >= 0 && cache_flag && slot && bitmap && count && (cap == 0 || out),
+               "orca_find_uncached: bad arguments");
+  ORCA_REQUIRE((n_nbr == 0 || nbr) && (n_batch == 0 || batch_nodes), "orca_find_uncached: null id array");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_batch) k_stamp_ids<<<blocks(n_batch, 256), 256, 0, st>>>(batch_nodes, n_batch, slot, epoch, n_nodes);
+  if (n_nbr) k_mark_uncached<<<blocks(n_nbr, 256), 256, 0, st>>>(nbr, n_nbr, slot, epoch, cache_flag, n_nodes, bitmap);
+  k_scan_bitmap<<<1, 1024, 0, st>>>(bitmap, ceil_div64(n_nodes, 32), out, cap, count);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
 
 ORCA_API int orca_time_encode(const float* t, int64_t n, const float* w, const float* b, float* out, void* stream) {
   ORCA_REQUIRE(n >= 0 && (n == 0 || (t && w && b && out)), "orca_time_encode: null pointer");

@@ -524,10 +524,9 @@ class OrcaEngine:
 
   # embedding_module.py:200-212
   def _find_uncached(self, nodes, nbr):
-    u = torch.unique(nbr.flatten().to(torch.int64))
-    u = u[~torch.isin(u, nodes)]
-    u = u[self.cache_flag[0][u] == 0]
-    return u[1:]
+    if getattr(self, "_bitmap", None) is None:
+      self._bitmap = torch.zeros((self.N + 31) // 32, dtype=torch.int32, device=self.device)
+    return ops.find_uncached(nbr, nodes, self.cache_flag[0], self.slot, self._slot_epoch(1), self._bitmap)
 
   def _attend_partitioned(self, layer, n, nbr, eid, dt, train, src_table, src_idx, nbr_table, from_memory):
     """_attend over this rank's contiguous share of the n queries, rows all-gathered back to [n, D]"""

@@ -411,3 +411,16 @@ def gather_rows(table, idx, out=None):
 def scatter_rows(table, ids, x):
   check(_lib.load().orca_scatter_rows(ptr(table), table.shape[1], ptr(ids), ids.numel(), ptr(x), stream()),
         "orca_scatter_rows")
+
+
+def find_uncached(nbr, batch_nodes, cache_flag, slot, epoch, bitmap):
+  """orca_find_uncached (embedding_module.py:200-212): sorted distinct out-of-batch neighbours that are not cached,
+  minus the first.  Returns an int64 tensor (one host read of the count: the caller concatenates it to the batch)."""
+  n_nbr = nbr.numel()
+  cap = min(n_nbr, slot.numel())
+  out = torch.empty(max(cap, 1), dtype=torch.int64, device=nbr.device)
+  count = torch.zeros(1, dtype=torch.int32, device=nbr.device)
+  check(_lib.load().orca_find_uncached(ptr(nbr), n_nbr, ptr(batch_nodes), batch_nodes.numel(), ptr(cache_flag), ptr(slot),
+                                       int(epoch), slot.numel(), ptr(bitmap), ptr(out), cap, ptr(count), stream()),
+        "orca_find_uncached")
+  return out[:int(count.item())]
