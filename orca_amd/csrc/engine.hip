@@ -11,10 +11,12 @@
 //   orca_engine_finish : persist memory update + raw-message build/store (train or eval order)
 // On one rank in train order the row writes of layer / finish ride inside the attention kernels (orca_tgat_side):
 // 4 launches per step.  DESIGN.md section 3 has the table.
+#include <stdlib.h>
 #include <new>
 #include <vector>
 #include "common.h"
 #include "sampler.h"
+#include "gru_split.h"
 
 struct orca_engine {
   orca_engine_desc d;
@@ -30,6 +32,7 @@ struct orca_engine {
   bool sharded;                // owner-computes step (several ranks, train order): see orca_engine_begin
   int64_t per;                 // owner-computes step: interactions per rank of the current batch = ceil(bs / world)
   int64_t epoch_push, epoch_msg;   // owner-computes step: the election values begin() claimed on slot / slot_m
+  int fuse_gru;                // 1: the eager GRU rides in the first kernel (env ORCA_FUSE_GRU=0 keeps it a launch of its own)
   int sampling;                // ORCA_SAMPLE_*
   uint64_t seed;               // uniform sampling: seed of the next step
   bool store_done;             // the raw-message store of the batch was fused into the last attention layer
@@ -198,23 +201,47 @@ struct begin_sample {
   int mode;                     // ORCA_SAMPLE_*
   uint64_t seed;
 };
+// The eager GRU as a role of the first kernel (blocks 0 .. n_blocks-1, ahead of every other role: theirs is the
+// longest chain of the launch): GRU(message, memory) -> overlay for the ids the previous step stored.  It shares no
+// data with the other roles (they touch the batch, the CSR and the other half of the list buffers), and both are
+// latency-bound launches that leave most of the chip idle: side by side they cost the longer of the two.
+constexpr int GRU_SUBS = ELECT_THREADS / (GRU_KW * 64);       // 4-wave GRU groups per block
+struct begin_gru {
+  int n_blocks, n_wg;
+  const float* blob;
+  const int32_t* ids;
+  int64_t n_max;
+  const int32_t* n_dev;
+  const float *x, *h;
+  float* out;
+};
+template <bool WITH_GRU>     // the GRU role raises the register count of the whole kernel: the plain variant keeps its occupancy
 __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
-    int32_t* __restrict__ nodes32, begin_elect el, int nbs, int64_t n_nodes,
+    int32_t* __restrict__ nodes32, begin_gru gru, begin_elect el, int nbs, int64_t n_nodes,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ c_nbr, const int32_t* __restrict__ c_eid,
     const double* __restrict__ c_ts, int64_t n_rows, int64_t lo, int64_t hi, int by_e, int K, begin_sample smp,
     int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt,
     orca_claim claim) {
-  __shared__ int32_t keys[ELECT_SLOTS], vals[ELECT_SLOTS];
+  __shared__ __align__(16) int32_t tab[2 * ELECT_SLOTS];
+  int32_t *keys = tab, *vals = tab + ELECT_SLOTS;
   auto root = [&](int64_t i) {   // one load through a selected pointer: no branch around it
     const int64_t* a = i < bs ? src : (i < 2 * bs ? dst - bs : neg - 2 * bs);
     return a[i];
   };
-  // the election workgroups (the longest dependent chains of this launch) take the first block indices so that
-  // they are dispatched first
-  if ((int)blockIdx.x < el.ne) {
-    const int b = (int)blockIdx.x;
+  if (WITH_GRU && (int)blockIdx.x < gru.n_blocks) {
+    static_assert(sizeof(tab) >= sizeof(f32x4) * GRU_SUBS * (GRU_KW - 1) * 3 * 64, "GRU partial sums must fit the election tables");
+    gru_split_workgroup<3 * ORCA_D + 172, 2, 1, GRU_SUBS>(gru.blob, gru.ids, gru.n_max, gru.n_dev, gru.x, gru.h, gru.out, nullptr,
+                                                          nullptr, (int)blockIdx.x * GRU_SUBS, gru.n_wg,
+                                                          reinterpret_cast<f32x4 (*)[1][3][64]>(tab), nullptr);
+    return;
+  }
+  // the election workgroups (the longest dependent chains after the GRU's) take the next block indices so that
+  // they are dispatched early
+  const int blk = (int)blockIdx.x - gru.n_blocks;
+  if (blk < el.ne) {
+    const int b = blk;
     if (el.seg) {
       if (b < el.ne_m) elect_segment(keys, vals, (int64_t)b * ELECT_SEG, 2 * bs, n_nodes, root, el.slot_msg, el.epoch_msg, el.own_world, el.own_rank);
       else elect_segment(keys, vals, (int64_t)(b - el.ne_m) * ELECT_SEG, 3 * bs, n_nodes, root, el.slot_push, el.epoch_push, 1, 0);
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int64_t bq = (int64_t)((int)blockIdx.x - el.ne);
+  const int64_t bq = (int64_t)(blk - el.ne);
   // this rank's roots: the contiguous slice [lo, hi) of the 3*bs roots, or (by_e, the owner-computes step) the src,
   // dst and neg roots of the INTERACTIONS [lo, hi) -- local query ql = k * (hi - lo) + (e - lo), root i = k * bs + e
   if (bq >= nbs) {   // query rows of the roots outside this rank's slice: one per thread (a wave each would be 8x the
@@ -459,6 +486,10 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   e->epoch_push = e->epoch_msg = 0;
   e->sampling = ORCA_SAMPLE_RECENT;
   e->seed = 0;
+  {
+    const char* v = getenv("ORCA_FUSE_GRU");
+    e->fuse_gru = !(v && v[0] == '0');
+  }
   e->eidx = nullptr;
   e->overlay_complete = false;
   e->have_list = false;
@@ -591,13 +622,24 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   int32_t* my_list = lists ? d.eager_ids + (int64_t)e->cur * d.q_max : nullptr;
   int32_t* my_count = lists ? d.eager_count + e->cur : nullptr;
   e->list_written = lists;
+  begin_gru gru{};
   if (e->have_list) {
     e->have_list = false;
     if (e->overlay_complete) {
-      Timed t(e, ORCA_PROF_GRU, stream);
-      rc = orca_gru_update(d.gru_blob, 3 * ORCA_D + d.d_e, d.eager_ids + (int64_t)(e->cur ^ 1) * d.q_max, e->list_bound,
-                           d.eager_count + (e->cur ^ 1), d.messages, d.memory, d.overlay, nullptr, nullptr, stream_);
-      if (rc != ORCA_OK) return rc;
+      const int32_t* ids = d.eager_ids + (int64_t)(e->cur ^ 1) * d.q_max;
+      const int64_t tiles = ceil_div64(e->list_bound, 16);
+      if (d.d_e == 172 && e->fuse_gru && !e->timed_step && tiles <= GRU_SPLIT_TILES) {
+        // a role of the first kernel (begin_gru): every tile has its GRU_NWG groups, so a group loops at most once
+        gru.n_wg = (int)tiles * GRU_NWG;
+        gru.n_blocks = (int)ceil_div64(gru.n_wg, GRU_SUBS);
+        gru.blob = d.gru_blob; gru.ids = ids; gru.n_max = e->list_bound; gru.n_dev = d.eager_count + (e->cur ^ 1);
+        gru.x = d.messages; gru.h = d.memory; gru.out = d.overlay;
+      } else {
+        Timed t(e, ORCA_PROF_GRU, stream);
+        rc = orca_gru_update(d.gru_blob, 3 * ORCA_D + d.d_e, ids, e->list_bound, d.eager_count + (e->cur ^ 1), d.messages,
+                             d.memory, d.overlay, nullptr, nullptr, stream_);
+        if (rc != ORCA_OK) return rc;
+      }
     }
   }
   const bool full = !e->sharded && lo == 0 && hi == Q;
@@ -630,9 +672,14 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     }
     const begin_sample smp{e->sampling, e->seed};
     Timed t(e, ORCA_PROF_SAMPLE, stream);
-    ORCA_LAUNCH_TIMED(k_begin_queries, (unsigned)(nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
-                      bs, d.nodes, d.qts, d.nodes32, el, nbs, d.n_nodes,
-                      indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
+    if (gru.n_blocks)
+      ORCA_LAUNCH_TIMED(k_begin_queries<true>, (unsigned)(gru.n_blocks + nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
+                        bs, d.nodes, d.qts, d.nodes32, gru, el, nbs, d.n_nodes,
+                        indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
+    else
+      ORCA_LAUNCH_TIMED(k_begin_queries<false>, (unsigned)(nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
+                        bs, d.nodes, d.qts, d.nodes32, gru, el, nbs, d.n_nodes,
+                        indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
     ORCA_LAUNCH_CHECK();
   }
   // the other half of the list buffers (consumed above) is the next step's: its counter restarts at zero

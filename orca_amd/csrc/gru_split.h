@@ -74,13 +74,23 @@ __device__ __forceinline__ void gru_chain(const float* const (&arow)[MT], const 
 // launch bound far above the device-side row count does not pay for thousands of empty workgroups.
 // `wg` of `n_wg` is this workgroup's place among those doing GRU work (a kernel of its own, or a role inside the
 // step driver's first kernel); `part` is GRU_KW-1 x MT x 3 x 64 float4 of LDS.
-template <int MSG, int GS, int MT>
+// SUBS > 1: the block holds SUBS such 4-wave groups (wg = the FIRST group's index, groups wg .. wg+SUBS-1, each with
+// its own `part`): the groups run their tile loops in lockstep -- the barriers are the block's -- so the trip count
+// is that of the first group (the lowest tile index) and a group whose tile lies past the rows skips the work of an
+// iteration but not its barriers.
+template <int MSG, int GS, int MT, int SUBS = 1>
 __device__ __forceinline__ void gru_split_workgroup(const float* __restrict__ blob, const int32_t* __restrict__ ids,
                                                     int64_t n_max, const int32_t* __restrict__ n_dev,
                                                     const float* __restrict__ x, const float* __restrict__ h,
                                                     float* __restrict__ out, float* last_update,
                                                     const float* __restrict__ msg_ts, int wg, int n_wg,
                                                     f32x4 (*part)[MT][3][64], long long* __restrict__ phase_clock) {
+  const int wg_first = wg;
+  if constexpr (SUBS > 1) {
+    const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    wg += sub;
+    part += sub * (GRU_KW - 1);
+  }
   const long long clk0 = phase_clock ? wall_clock64() : 0;
   static_assert(MSG % 4 == 0 && ORCA_D % 4 == 0, "a float4 A fragment must not straddle the end of a row");
   constexpr int KBx = (MSG + 15) / 16, KBh = (ORCA_D + 15) / 16, SPW = KBx / (GRU_KW - 1), TR = 16 * MT;
@@ -89,7 +99,7 @@ __device__ __forceinline__ void gru_split_workgroup(const float* __restrict__ bl
   constexpr int64_t PW_X = 0, PW_H = 3 * (int64_t)GRU_NWG * KBx * 256, BIAS = PW_H + 3 * (int64_t)GRU_NWG * KBh * 256;
   const int t = wg % GRU_NWG;                           // hidden-unit tile
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // everything derived from it stays in scalar registers
+  const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & (GRU_KW - 1));   // everything derived from it stays in scalar registers
   const int kq = 4 * (lane >> 4);
   const bool hw = wave == GRU_KW - 1;                       // this wave walks the memory columns
   const int kb0 = hw ? 0 : wave * SPW;
@@ -108,8 +118,9 @@ __device__ __forceinline__ void gru_split_workgroup(const float* __restrict__ bl
   }
   long long clk1 = 0, clk2 = 0;
   const int64_t tstride = n_wg / GRU_NWG, last = n_max - 1;   // ids[] is valid memory up to n_max
-  for (int64_t tile = wg / GRU_NWG; tile * TR < n; tile += tstride) {
-    const int64_t r0 = tile * TR;
+  for (int64_t tile = wg / GRU_NWG, lead = wg_first / GRU_NWG; (SUBS > 1 ? lead : tile) * TR < n; tile += tstride, lead += tstride) {
+    const bool act = SUBS == 1 || (tile * TR < n && wg < n_wg);
+    const int64_t r0 = act ? tile * TR : 0;
     // the weights do not depend on the tile: the lane offset is made opaque per iteration, or the compiler hoists
     // every fragment out of the loop into registers and halves the waves a SIMD can hold
     int lane_off = lane;
@@ -144,18 +155,20 @@ __device__ __forceinline__ void gru_split_workgroup(const float* __restrict__ bl
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[m][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (hw) gru_chain<KBh, (GS < KBh ? GS : KBh), MT>(arow, bgate, kq, std::integral_constant<int, D>{}, acc);
-    else    gru_chain<SPW, GS, MT>(arow, bgate, kq, MSG - kb0 * 16, acc);
+    if (act) {
+      if (hw) gru_chain<KBh, (GS < KBh ? GS : KBh), MT>(arow, bgate, kq, std::integral_constant<int, D>{}, acc);
+      else    gru_chain<SPW, GS, MT>(arow, bgate, kq, MSG - kb0 * 16, acc);
+    }
     if (phase_clock) clk2 = wall_clock64();
 
-    if (wave != 0) {
+    if (act && wave != 0) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int g = 0; g < 3; ++g) part[wave - 1][m][g][lane] = acc[m][g];
     }
     __syncthreads();
-    if (wave == 0) {
+    if (act && wave == 0) {
       // fused gate epilogue (torch.nn.GRUCell, gate order r, z, n)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
