@@ -149,7 +149,18 @@ typedef struct {
   /* nonzero (gather mode only): the caller states that `blob` was completed by orca_tgat_pack_gather with these
    * time_b values; the kernel then takes q~ straight from the source rows.  0 = the general path. */
   int32_t q_folded;
+  /* Attention-weight dropout of nn.MultiheadAttention (model/temporal_attention.py:17-21; train.py:30 default 0.4):
+   * weight (query q, head h, slot j) is kept with probability 1 - dropout_p and scaled by 1 / (1 - dropout_p).  The
+   * keep decision is a counter RNG keyed (dropout_seed, q0 + q, h, j) -- orca_tgat_dropout_mask writes the same
+   * multipliers out; the RNG STREAM is not torch's (parity unpinned), the masked arithmetic is pinned by feeding
+   * that mask to the oracle.  0 = off (module.eval()).  dropout_q0: index of query 0 in the caller's numbering. */
+  float dropout_p;
+  uint64_t dropout_seed;
+  int64_t dropout_q0;
 } orca_tgat_inputs;
+/* mult[q][h][j] (float [Q, ORCA_HEADS, K]) = 0 or 1 / (1 - p): the dropout multipliers orca_tgat_forward /
+ * orca_tgat_backward apply for (seed, q0) */
+int orca_tgat_dropout_mask(uint64_t seed, int64_t q0, int64_t Q, int K, float p, float* mult, void* stream);
 
 /* out [Q, ORCA_D]; out_weights [Q, K] (head-averaged attention, may be NULL).  1 <= K <= ORCA_MAX_K. */
 int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,

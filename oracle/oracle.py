@@ -203,9 +203,12 @@ def time_encode(t, w, b=None):
 # ------------------------------------------------------------------------------------------
 # TGAT attention layer  (model/temporal_attention.py:24-56, utils/util.py:12-24)
 # ------------------------------------------------------------------------------------------
-def attention_forward(P, src, src_t, nbr, nbr_t, edge, mask, n_head=2):
+def attention_forward(P, src, src_t, nbr, nbr_t, edge, mask, n_head=2, drop_mult=None):
   """P: dict of the layer's state_dict tensors (keys as in SURVEY §8b).  mask is mutated in place
-  exactly as temporal_attention.py:46-47 does.  Returns (out [B,D], weights [B,K])."""
+  exactly as temporal_attention.py:46-47 does.  Returns (out [B,D], weights [B,K]).
+  drop_mult [B, n_head, K] (0 or 1/(1-p)): nn.MultiheadAttention's dropout on the softmax output
+  (temporal_attention.py:17-21) with the keep decisions given explicitly -- torch's own dropout RNG stream cannot be
+  reproduced by another implementation, so dropout parity is pinned on the masked arithmetic, not on the stream."""
   B, K = mask.shape
   query = torch.cat([src.unsqueeze(1), src_t], dim=2).reshape(B, -1)            # :41-42
   key = torch.cat([nbr, edge, nbr_t], dim=2)                                    # :43
@@ -223,6 +226,8 @@ def attention_forward(P, src, src_t, nbr, nbr_t, edge, mask, n_head=2):
   s = q @ k.transpose(-1, -2)                                                   # [B,H,1,K]
   s = s.masked_fill(mask.view(B, 1, 1, K), float("-inf"))
   a = torch.softmax(s, dim=-1)
+  if drop_mult is not None:
+    a = a * drop_mult.view(B, n_head, 1, K)
   o = (a @ v).reshape(B, E)
   o = o @ P["multi_head_target.out_proj.weight"].t() + P["multi_head_target.out_proj.bias"]
   w = a.mean(dim=1).reshape(B, K)

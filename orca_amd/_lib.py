@@ -23,7 +23,8 @@ class TgatInputs(ctypes.Structure):
       "src_table", "src_idx", "src_overlay", "src_flags",
       "nbr_table", "nbr_idx", "nbr_overlay", "nbr_flags",
       "nbr_ids", "mask", "edge_table", "edge_idx",
-      "dt", "time_w", "time_b", "src_time", "nbr_time")] + [("q_folded", ctypes.c_int32)]
+      "dt", "time_w", "time_b", "src_time", "nbr_time")] + [("q_folded", ctypes.c_int32), ("dropout_p", ctypes.c_float),
+                                                                     ("dropout_seed", ctypes.c_uint64), ("dropout_q0", ctypes.c_int64)]
 
 
 class TgatParams(ctypes.Structure):
@@ -74,6 +75,7 @@ SIGNATURES = {
     "orca_gru_backward": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 11),
     "orca_tgat_backward_workspace_floats": (i64, [i32, i64, i32]),
     "orca_tgat_backward": (i32, [vp, i32, vp, i64, i32] + [vp] * 10),
+    "orca_tgat_dropout_mask": (i32, [u64, i64, i64, i32, ctypes.c_float, vp, vp]),
     "orca_tgat_forward": (i32, [vp, i32, ctypes.POINTER(TgatInputs), i64, i32, vp, vp, vp]),
     "orca_debug_tgat_phase_clock": (i32, [vp]),
     "orca_debug_gru_phase_clock": (i32, [vp]),

@@ -92,17 +92,20 @@ class GraphAttentionEmbedding(nn.Module):
       from .. import torch_ops  # noqa: F401
       named = dict(att.named_parameters())
       m = src if src.get("flags") is not None else nb
+      p, seed = att.dropout_args()
       return torch.ops.orca.tgat_gather([named[k] for k in ops.TGAT_KEYS], att.packed(), self.n_edge_features, Q, K,
                                         src["table"], src_idx, nb["table"], nbr_idx, nbr, self._edge_table(), eid, dt,
-                                        tw, tb, m.get("overlay"), m.get("flags"), m.get("upd_rows"), m.get("pos"), False)
+                                        tw, tb, m.get("overlay"), m.get("flags"), m.get("upd_rows"), m.get("pos"), False,
+                                        p, seed)
     kw = dict(src_table=src["table"], src_idx=src_idx, nbr_table=nb["table"], nbr_idx=nbr_idx, nbr_ids=nbr,
               edge_table=self._edge_table(), edge_idx=eid, dt=dt, time_w=tw, time_b=tb)
     if src.get("flags") is not None:
       kw.update(src_overlay=src["overlay"], src_flags=src["flags"])
     if nb.get("flags") is not None:
       kw.update(nbr_overlay=nb["overlay"], nbr_flags=nb["flags"])
+    p, seed = att.dropout_args()
     with torch.no_grad():
-      out, _ = ops.tgat_forward(att.packed(), self.n_edge_features, Q, K, **kw)
+      out, _ = ops.tgat_forward(att.packed(), self.n_edge_features, Q, K, dropout_p=p, dropout_seed=seed, **kw)
     return out
 
   # ---- Path A: :116-147 --------------------------------------------------------------------------

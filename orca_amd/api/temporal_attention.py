@@ -24,7 +24,8 @@ class TemporalAttentionLayer(nn.Module):
   """Same constructor, parameters (state_dict keys) and forward contract as the reference; forward runs the
   fused HIP kernel (the custom op orca::tgat_dense, orca_amd/torch_ops.py) and, under autograd, backward runs
   orca_tgat_backward (gradients of all twelve parameters and of the node / time feature inputs; edge features are
-  data upstream and get none).  Dropout is not applied (module.eval() semantics)."""
+  data upstream and get none).  In train() mode the attention weights are dropped out with probability `dropout` like
+  nn.MultiheadAttention's (counter RNG in the kernel: torch's own dropout stream is not reproduced)."""
 
   def __init__(self, n_node_features, n_neighbors_features, n_edge_features, time_dim, output_dimension, n_head=2,
                dropout=0.1):
@@ -41,6 +42,7 @@ class TemporalAttentionLayer(nn.Module):
     self.multi_head_target = nn.MultiheadAttention(embed_dim=self.query_dim, kdim=self.key_dim, vdim=self.key_dim,
                                                    num_heads=n_head, dropout=dropout)
     self.norm = nn.LayerNorm(output_dimension)
+    self.dropout = float(dropout)
     self._blob = None
     self._blob_key = None
 
@@ -54,6 +56,13 @@ class TemporalAttentionLayer(nn.Module):
       self._blob = ops.tgat_pack(sd, self.n_edge_features, dev, None)
       self._blob_key = key
     return self._blob
+
+  def dropout_args(self):
+    """(p, seed) of this call: attention-weight dropout is on in train() mode, as nn.MultiheadAttention's; the seed
+    of the kernel's counter RNG is drawn from torch's CPU generator (torch.manual_seed makes a run repeatable)."""
+    if not self.training or self.dropout <= 0.0:
+      return 0.0, 0
+    return self.dropout, int(torch.randint(0, 1 << 62, (1,)).item())
 
   def forward(self, src_node_features, src_time_features, neighbors_features, neighbors_time_features, edge_features,
               neighbors_padding_mask):
@@ -70,7 +79,8 @@ class TemporalAttentionLayer(nn.Module):
     named = dict(self.named_parameters())
     params = [named[k] for k in ops.TGAT_KEYS]
     from .. import torch_ops  # noqa: F401  (registers the orca:: ops)
+    p, seed = self.dropout_args()
     out, wts, after = torch.ops.orca.tgat_dense(params, self.packed(), self.n_edge_features, src, st, nbr, nt, edge,
-                                                mask.clone())     # (the op keeps this copy for its backward)
+                                                mask.clone(), p, seed)     # (the op keeps the mask copy for its backward)
     mask.copy_(after.detach())          # temporal_attention.py:46-47 mutates the caller's mask
     return out, wts.detach()            # the weights are unused upstream (embedding_module.py:326): no gradient through them

@@ -173,6 +173,17 @@ __device__ __forceinline__ float orca_sinf(float x) {
   p = __builtin_fmaf(u * rf, p, rf);
   return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p) ^ sign);
 }
+// Attention-weight dropout multiplier of (query, head, slot): counter RNG (splitmix64 finaliser), 24 uniform bits
+__host__ __device__ static inline uint64_t orca_mix64_(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__host__ __device__ static inline float orca_dropout_mult(uint64_t seed, int64_t q, int h, int j, float p, float scale) {
+  const uint64_t r = orca_mix64_(seed ^ orca_mix64_((uint64_t)q * 64u + (uint64_t)(h * 32 + j)));
+  return (float)(r >> 40) * (1.0f / 16777216.0f) >= p ? scale : 0.0f;
+}
 // t·ω + φ of nn.Linear(1, D) (time_encoding.py:26) with TWO roundings: the product, then the bias add.  With
 // φ = 0 (the reference's initial value and every fixture it holds) the rounding order cannot matter; with a
 // trained φ != 0 torch's own CPU linear rounds once or twice depending on the MKL code path of the host (measured:

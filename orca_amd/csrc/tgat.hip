@@ -65,7 +65,7 @@ __host__ __device__ constexpr Blob blob_layout(int d_e) {
   L.qk_flag = o; o += 16;
   // scratch of the pack routines (the fp64 products of the folds), kept inside the blob so that packing neither
   // allocates nor synchronises; the kernel never reads it.  Offsets are even: the fp64 parts stay 8-byte aligned.
-  L.scr_u = o; o += 2 * (2 * D * D + QD);                          // double [2*D*D + QD]
+  L.scr_u = o; o += 2 * (2 * D * D + 3 * QD);                      // double [2*D*D + 3*QD]
   L.scr_f = o; o += (int64_t)D * L.KBT * 16;                        // float  [D, KBT*16]
   L.scr_t = o; o += 2 * QD;                                         // double [QD]
   L.scr_a = o; o += 2 * (int64_t)(L.kdim + 1) * D + ((L.kdim + 1) * D & 1);   // float [2, kdim+1, D]
@@ -75,16 +75,20 @@ __host__ __device__ constexpr Blob blob_layout(int d_e) {
 
 // ---- folding the linear tail (setup time, fp64 accumulation) ---------------------------------------------
 // U[h][n][d] = sum_j W1[n][j] Wo[j][h*100 + d]            (fc1_w [100, 300], o_w [200, 200], row-major)
-// U[2*D*D + j] = bo[j] + sum_k Wo[j][k] bv[k]              (the out-projection of the value bias)
+// U[2*D*D + h*QD + j] = sum_{k in head h} Wo[j][k] bv[k]  (the out-projection of head h's value bias: it reaches the
+//                        output scaled by the sum of that head's attention weights -- 1 unless dropout is on)
+// U[2*D*D + 2*QD + j] = bo[j]
 __global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restrict__ o_w, const float* __restrict__ o_b,
                          const float* __restrict__ bv, double* __restrict__ U) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * D * D) {
-    const int j = i - 2 * D * D;
-    if (j < QD) {
-      double t = (double)o_b[j];
-      for (int k = 0; k < QD; ++k) t += (double)o_w[j * QD + k] * (double)bv[k];
+    const int r = i - 2 * D * D, part = r / QD, j = r % QD;
+    if (part < 2) {
+      double t = 0.0;
+      for (int k = 0; k < D; ++k) t += (double)o_w[j * QD + part * D + k] * (double)bv[part * D + k];
       U[i] = t;
+    } else if (part == 2) {
+      U[i] = (double)o_b[j];
     }
     return;
   }
@@ -93,8 +97,9 @@ __global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restric
   for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * (double)o_w[j * QD + h * D + d];
   U[i] = acc;
 }
-// F [100, KBT*16]: columns h*KP + c (c < kdim) = sum_d U[h][n][d] Wv[h*100 + d][c];  column kdim (head 0) = the
-// constant W1a (Wo bv + bo);  columns 2*KP + k (k < 100) = W1[n][200 + k];  zero elsewhere.
+// F [100, KBT*16]: columns h*KP + c (c < kdim) = sum_d U[h][n][d] Wv[h*100 + d][c];  column h*KP + kdim = the
+// constant W1a Wo_h bv_h of head h (multiplied by that head's weight sum);  columns 2*KP + k (k < 100) =
+// W1[n][200 + k];  column 2*KP + 100 = W1a bo (multiplied by 1 for a valid query);  zero elsewhere.
 __global__ void k_fold_f(const double* __restrict__ U, const float* __restrict__ v_w, const float* __restrict__ in_b,
                          const float* __restrict__ o_w, const float* __restrict__ o_b, const float* __restrict__ fc1_w,
                          int kdim, int KP, int width, float* __restrict__ F) {
@@ -106,11 +111,13 @@ __global__ void k_fold_f(const double* __restrict__ U, const float* __restrict__
     const int h = col / KP, c = col - h * KP;
     if (c < kdim) {
       for (int d = 0; d < D; ++d) acc += U[(h * D + n) * D + d] * (double)v_w[(int64_t)(h * D + d) * kdim + c];
-    } else if (h == 0 && c == kdim) {
-      for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * U[2 * D * D + j];
+    } else if (c == kdim) {
+      for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * U[2 * D * D + h * QD + j];
     }
   } else if (col < 2 * KP + D) {
     acc = (double)fc1_w[n * 3 * D + QD + (col - 2 * KP)];
+  } else if (col == 2 * KP + D) {
+    for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * U[2 * D * D + 2 * QD + j];
   }
   F[i] = (float)acc;
 }
@@ -221,7 +228,7 @@ ORCA_API int orca_tgat_pack(int d_e, const float* q_w, const float* k_w, const f
     const int width = L.KBT * 16;
     double* U = reinterpret_cast<double*>(blob + L.scr_u);
     float* F = blob + L.scr_f;
-    k_fold_u<<<(2 * D * D + QD + 255) / 256, 256, 0, s>>>(fc1_w, o_w, o_b, in_b + 2 * QD, U);
+    k_fold_u<<<(2 * D * D + 3 * QD + 255) / 256, 256, 0, s>>>(fc1_w, o_w, o_b, in_b + 2 * QD, U);
     k_fold_f<<<(D * width + 255) / 256, 256, 0, s>>>(U, v_w, in_b, o_w, o_b, fc1_w, kdim, L.KP, width, F);
     rc |= orca_pack_matrix(blob + L.pw_t, pw_tiles(D), L.KBT, 0, D, width, F, width, 1, s);
   }
@@ -722,7 +729,15 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       const float e0 = lv0 ? expf(sc[0] - mx) : 0.f, e1 = lv1 ? expf(sc[1] - mx) : 0.f;
       // an all-padded neighbourhood has attn = 0 (:52): its weights, hence x-bar, are zeroed (out_w too, below)
       const float inv = invalid ? 0.f : 1.0f / (half_sum(e0 + e1) * 0.5f);
-      const float a_c0 = e0 * inv, a_c1 = e1 * inv;      // attention weight of (head = lane>>5, slot hs [+KC])
+      float a_c0 = e0 * inv, a_c1 = e1 * inv;            // attention weight of (head = lane>>5, slot hs [+KC])
+      float wsum = invalid ? 0.f : 1.f;                  // sum of this head's weights: 1 without dropout
+      if (in.dropout_p > 0.f) {                          // nn.MultiheadAttention's dropout on the softmax output
+        const float sc_ = 1.0f / (1.0f - in.dropout_p);
+        const int hh = hs < 0 ? 0 : hs;
+        a_c0 *= orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, lane >> 5, hh, in.dropout_p, sc_);
+        a_c1 *= orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, lane >> 5, hh + KC, in.dropout_p, sc_);
+        wsum = half_sum(a_c0 + a_c1) * 0.5f;             // (a_c* are zero outside the real slots)
+      }
       if (out_w) {                                                       // :51-53 (head average); wave-uniform
         const int jj = lane < K ? (lane < KC ? lane : lane - KC) : 0;
         int hl = 0;
@@ -767,7 +782,9 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       }
       xb0[tb + lane] = at0; xb1[tb + lane] = at1;
       if (c1 < D) { xb0[tb + c1] = bt0; xb1[tb + c1] = bt1; }
-      if (lane == 0) { xb0[kdim] = invalid ? 0.f : 1.f; xb1[kdim] = 0.f; }   // indicator column of the tail's constant
+      // constant columns of the tail: each head's value-bias term times its weight sum, the out-projection bias once
+      const float ws1 = __shfl(wsum, 32, 64);
+      if (lane == 0) { xb0[kdim] = wsum; xb1[kdim] = ws1; xb0[2 * KPS + D] = invalid ? 0.f : 1.f; }
     }
   }
   // ---- P4: h1 = relu(F [x-bar_0 | x-bar_1 | src] + b1), F = the folded value map / out-proj / fc1 ----------
@@ -843,6 +860,23 @@ ORCA_API int orca_debug_tgat_phase_clock(void* buf) {
   return ORCA_OK;
 }
 
+namespace {
+__global__ void k_dropout_mask(uint64_t seed, int64_t q0, int64_t Q, int K, float p, float* __restrict__ mult) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q * ORCA_HEADS * K) return;
+  const int j = (int)(i % K), h = (int)((i / K) % ORCA_HEADS);
+  mult[i] = orca_dropout_mult(seed, q0 + i / (K * ORCA_HEADS), h, j, p, 1.0f / (1.0f - p));
+}
+}  // namespace
+
+ORCA_API int orca_tgat_dropout_mask(uint64_t seed, int64_t q0, int64_t Q, int K, float p, float* mult, void* stream) {
+  ORCA_REQUIRE(Q >= 0 && K >= 1 && K <= ORCA_MAX_K && p >= 0.f && p < 1.f && (Q == 0 || mult), "orca_tgat_dropout_mask: bad arguments");
+  if (Q == 0) return ORCA_OK;
+  k_dropout_mask<<<(unsigned)ceil_div64(Q * ORCA_HEADS * K, 256), 256, 0, (hipStream_t)stream>>>(seed, q0, Q, K, p, mult);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
 ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
                                float* out_weights, void* stream) {
   return orca_tgat_forward_side(blob, d_e, in, Q, K, out, out_weights, nullptr, stream);
@@ -875,6 +909,7 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
   }
   ORCA_REQUIRE(lds_bytes <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds_bytes);
   ORCA_REQUIRE(!in->q_folded || in->dt, "orca_tgat_forward: q_folded needs gather-mode time inputs (dt)");
+  ORCA_REQUIRE(in->dropout_p >= 0.f && in->dropout_p < 1.f, "orca_tgat_forward: dropout_p=%g outside [0,1)", (double)in->dropout_p);
   const unsigned grid = (unsigned)ceil_div64(Q, TQ);
   hipStream_t st = (hipStream_t)stream;
 #define ORCA_TGAT_LAUNCH(KT_, DE_)                                                                              \

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void k_bwd_prep(orca_tgat_inputs in, int64_t Q
 // xbar[q][h] = sum_j a_hj x_j;  invalid[q] = 1 for an all-padded query (temporal_attention.py:46-47,52)
 __global__ __launch_bounds__(256) void k_bwd_attn_fwd(orca_tgat_inputs in, int64_t Q, int K, int d_e,
                                                       const float* __restrict__ qt, float* __restrict__ a_out,
-                                                      float* __restrict__ xbar, float* __restrict__ invalid) {
+                                                      float* __restrict__ xbar, float* __restrict__ invalid,
+                                                      float* __restrict__ wsum) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= Q) return;
@@ -312,10 +313,18 @@ __global__ __launch_bounds__(256) void k_bwd_attn_fwd(orca_tgat_inputs in, int64
   const float m0 = wave_max_f(s0), m1 = wave_max_f(s1);
   float e0 = (lane < K && ((live >> lane) & 1ull)) ? expf(s0 - m0) : 0.f;
   float e1 = (lane < K && ((live >> lane) & 1ull)) ? expf(s1 - m1) : 0.f;
-  const float a0 = e0 / wave_sum(e0), a1 = e1 / wave_sum(e1);
-  if (lane < K) {
+  float a0 = e0 / wave_sum(e0), a1 = e1 / wave_sum(e1);
+  if (lane < K) {     // the softmax output itself (its backward needs it); dropout acts on what is summed below
     a_out[(q * 2 + 0) * K + lane] = a0;
     a_out[(q * 2 + 1) * K + lane] = a1;
+  }
+  if (in.dropout_p > 0.f) {
+    const float sc = 1.0f / (1.0f - in.dropout_p);
+    const int j = lane < K ? lane : 0;
+    a0 *= orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, 0, j, in.dropout_p, sc);
+    a1 *= orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, 1, j, in.dropout_p, sc);
+    const float s0 = wave_sum(a0), s1 = wave_sum(a1);
+    if (lane == 0) { wsum[q * 2] = s0; wsum[q * 2 + 1] = s1; }
   }
   float b0[MAXC], b1[MAXC];
 #pragma unroll
@@ -339,6 +348,33 @@ __global__ __launch_bounds__(256) void k_bwd_attn_fwd(orca_tgat_inputs in, int64
   if (lane == 0) invalid[q] = inv ? 1.f : 0.f;
 }
 
+// dropout: ocat[q][h*100 + c] += wsum[q][h] * bv[h*100 + c]  (the value bias reaches the output times the weight sum)
+__global__ void k_add_scaled_bias(float* __restrict__ ocat, int64_t Q, const float* __restrict__ wsum,
+                                  const float* __restrict__ bv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q * QD) return;
+  const int64_t q = i / QD;
+  const int c = (int)(i % QD);
+  ocat[i] += wsum[q * 2 + c / D] * bv[c];
+}
+// dropout: scaled[q][c] = docat[q][c] * wsum[q][h] (for the bv gradient); dsum[q][h] = docat[q][h] . bv_h
+__global__ __launch_bounds__(256) void k_bias_scale_bwd(const float* __restrict__ docat, int64_t Q, const float* __restrict__ wsum,
+                                                        const float* __restrict__ bv, float* __restrict__ scaled,
+                                                        float* __restrict__ dsum) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  for (int h = 0; h < 2; ++h) {
+    float acc = 0.f;
+    for (int c = lane; c < D; c += 64) {
+      const float g = docat[q * QD + h * D + c];
+      scaled[q * QD + h * D + c] = g * wsum[q * 2 + h];
+      acc += g * bv[h * D + c];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dsum[q * 2 + h] = acc;
+  }
+}
 // rows of an invalid query are zeroed in X[q*ld .. +n)
 __global__ void k_zero_invalid(float* __restrict__ X, int64_t Q, int64_t ld, int n, const float* __restrict__ invalid) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -386,7 +422,7 @@ __global__ __launch_bounds__(256) void k_bwd_attn_bwd(orca_tgat_inputs in, int64
                                                       const float* __restrict__ qt, const float* __restrict__ a_in,
                                                       const float* __restrict__ dxbar, float* __restrict__ dqt,
                                                       float* __restrict__ d_nbr, float* __restrict__ d_nbr_time,
-                                                      float* __restrict__ tgrad) {
+                                                      float* __restrict__ tgrad, const float* __restrict__ dsum) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= Q) return;
@@ -416,11 +452,22 @@ __global__ __launch_bounds__(256) void k_bwd_attn_bwd(orca_tgat_inputs in, int64
     p1 = wave_sum(p1);
     if (lane == j) { da0 = p0; da1 = p1; }
   }
+  // dropout: the key sums (and each head's weight sum, whose gradient is dsum) were taken with a' = a * mult
+  float m0 = 1.f, m1 = 1.f;
+  if (in.dropout_p > 0.f) {
+    const float sc = 1.0f / (1.0f - in.dropout_p);
+    const int j = lane < K ? lane : 0;
+    m0 = orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, 0, j, in.dropout_p, sc);
+    m1 = orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, 1, j, in.dropout_p, sc);
+    da0 = (da0 + dsum[q * 2]) * m0;
+    da1 = (da1 + dsum[q * 2 + 1]) * m1;
+  }
   const float ds0 = a0 * (da0 - wave_sum(a0 * da0)), ds1 = a1 * (da1 - wave_sum(a1 * da1));
+  const float aw0 = a0 * m0, aw1 = a1 * m1;
   for (int j = 0; j < K; ++j) {
     float x[MAXC];
     key_row(x, in, S, q, j, K, d_e, lane);
-    const float w0 = __shfl(a0, j, 64), w1 = __shfl(a1, j, 64), e0 = __shfl(ds0, j, 64), e1 = __shfl(ds1, j, 64);
+    const float w0 = __shfl(aw0, j, 64), w1 = __shfl(aw1, j, 64), e0 = __shfl(ds0, j, 64), e1 = __shfl(ds1, j, 64);
     const float dt = __shfl(S.dt, j, 64);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
@@ -478,7 +525,7 @@ __global__ void k_bwd_finish(orca_tgat_inputs in, int64_t Q, const float* __rest
 }
 
 struct Ws {   // float offsets of the per-query rows inside the workspace
-  int64_t xq, qs, qt, a, xbar, ocat, x1, h1, y, dy, gx, dh1, dx1, docat, dxbar, dqt, dq, dxq, tgrad, invalid, part, total;
+  int64_t xq, qs, qt, a, xbar, ocat, x1, h1, y, dy, gx, dh1, dx1, docat, dxbar, dqt, dq, dxq, tgrad, invalid, wsum, dsum, part, total;
 };
 constexpr int SPLITS = ORCA_GEMM_SPLITS;
 Ws ws_layout(int d_e, int64_t Q, int K) {
@@ -489,7 +536,7 @@ Ws ws_layout(int d_e, int64_t Q, int K) {
   w.xq = take(QD); w.qs = take(QD); w.qt = take(2 * kdim); w.a = take(2 * K); w.xbar = take(2 * kdim);
   w.ocat = take(QD); w.x1 = take(3 * D); w.h1 = take(D); w.y = take(D); w.dy = take(D); w.gx = take(D);
   w.dh1 = take(D); w.dx1 = take(3 * D); w.docat = take(QD); w.dxbar = take(2 * kdim); w.dqt = take(2 * kdim);
-  w.dq = take(QD); w.dxq = take(QD); w.tgrad = take(QD); w.invalid = take(1);
+  w.dq = take(QD); w.dxq = take(QD); w.tgrad = take(QD); w.invalid = take(1); w.wsum = take(2); w.dsum = take(2);
   w.part = o;
   o += (int64_t)SPLITS * QD * (kdim > 3 * D ? kdim : 3 * D);
   w.total = o;
@@ -533,7 +580,9 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
   float *xq = W + w.xq, *qs = W + w.qs, *qt = W + w.qt, *a = W + w.a, *xbar = W + w.xbar, *ocat = W + w.ocat,
         *x1 = W + w.x1, *h1 = W + w.h1, *y = W + w.y, *dy = W + w.dy, *gx = W + w.gx, *dh1 = W + w.dh1,
         *dx1 = W + w.dx1, *docat = W + w.docat, *dxbar = W + w.dxbar, *dqt = W + w.dqt, *dq = W + w.dq,
-        *dxq = W + w.dxq, *tgrad = W + w.tgrad, *invalid = W + w.invalid, *part = W + w.part;
+        *dxq = W + w.dxq, *tgrad = W + w.tgrad, *invalid = W + w.invalid, *wsum = W + w.wsum, *dsum = W + w.dsum, *part = W + w.part;
+  const bool drop = in->dropout_p > 0.f;
+  ORCA_REQUIRE(in->dropout_p >= 0.f && in->dropout_p < 1.f, "orca_tgat_backward: dropout_p=%g outside [0,1)", (double)in->dropout_p);
   const unsigned qb = (unsigned)ceil_div64(Q, 4);
   int rc = ORCA_OK;
   auto ew = [&](int64_t n) { return (unsigned)ceil_div64(n, 256); };
@@ -545,10 +594,11 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
   for (int h = 0; h < 2; ++h)   // q~_h = qs_h Wk_h   [Q,100] x [100,kdim]
     rc |= sgemm(s, M, kdim, D, qs + h * D, QD, 1, P->k_w + (int64_t)h * D * kdim, kdim, 1, qt + h * kdim, 2 * kdim, 1,
                 nullptr, 1.f, false, false);
-  k_bwd_attn_fwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid);
-  for (int h = 0; h < 2; ++h)   // ocat_h = xbar_h Wv_h^T + bv_h
+  k_bwd_attn_fwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
+  for (int h = 0; h < 2; ++h)   // ocat_h = xbar_h Wv_h^T + bv_h  (dropout: + (sum of the head's kept weights) bv_h)
     rc |= sgemm(s, M, D, kdim, xbar + h * kdim, 2 * kdim, 1, P->v_w + (int64_t)h * D * kdim, 1, kdim, ocat + h * D, QD, 1,
-                P->in_b + 2 * QD + h * D, 1.f, false, false);
+                drop ? nullptr : P->in_b + 2 * QD + h * D, 1.f, false, false);
+  if (drop) k_add_scaled_bias<<<ew(Q * QD), 256, 0, s>>>(ocat, Q, wsum, P->in_b + 2 * QD);
   // o = ocat Wo^T + bo -> x1[:, 0:200], zero for invalid queries                 (temporal_attention.py:52)
   rc |= sgemm(s, M, QD, QD, ocat, QD, 1, P->o_w, 1, QD, x1, 3 * D, 1, P->o_b, 1.f, false, false);
   k_zero_invalid<<<ew(Q * QD), 256, 0, s>>>(x1, Q, 3 * D, QD, invalid);
@@ -575,7 +625,12 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
   rc |= colsum(s, dx1, Q, 3 * D, QD, G->o_b, 1.f, true, part);
   rc |= sgemm(s, M, QD, QD, dx1, 3 * D, 1, P->o_w, QD, 1, docat, QD, 1, nullptr, 1.f, false, false);
   // value map: dWv_h += docat_h^T xbar_h, dbv += sum docat, dxbar_h = docat_h Wv_h
-  rc |= colsum(s, docat, Q, QD, QD, G->in_b + 2 * QD, 1.f, true, part);
+  if (drop) {     // ocat is dead from here on: it takes docat scaled by the weight sums
+    k_bias_scale_bwd<<<qb, 256, 0, s>>>(docat, Q, wsum, P->in_b + 2 * QD, ocat, dsum);
+    rc |= colsum(s, ocat, Q, QD, QD, G->in_b + 2 * QD, 1.f, true, part);
+  } else {
+    rc |= colsum(s, docat, Q, QD, QD, G->in_b + 2 * QD, 1.f, true, part);
+  }
   for (int h = 0; h < 2; ++h) {
     rc |= sgemm(s, D, kdim, M, docat + h * D, 1, QD, xbar + h * kdim, 2 * kdim, 1, G->v_w + (int64_t)h * D * kdim, kdim, 1,
                 nullptr, 1.f, true, false, part, SPLITS);
@@ -583,7 +638,7 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
                 nullptr, 1.f, false, false);
   }
   const bool want_t = in->dt && d_time_w;
-  k_bwd_attn_bwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr);
+  k_bwd_attn_bwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
   // key fold: dWk_h += qs_h^T dq~_h, dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs   (the bk gradient is zero: softmax is shift-invariant)
   for (int h = 0; h < 2; ++h) {
     rc |= sgemm(s, D, kdim, M, qs + h * D, 1, QD, dqt + h * kdim, 2 * kdim, 1, G->k_w + (int64_t)h * D * kdim, kdim, 1,

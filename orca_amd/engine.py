@@ -34,7 +34,7 @@ D = ORCA_D
 
 class OrcaEngine:
   def __init__(self, state_dict, edge_feats, n_nodes, n_layers, n_neighbors, reuse=False, budget=0,
-               device="cuda:0", group=None, sampling="recent", seed=0, exchange_cap=None, pretend=None):
+               device="cuda:0", group=None, sampling="recent", seed=0, exchange_cap=None, pretend=None, dropout=0.0):
     """state_dict: the TGN state_dict of the reference (key names of SURVEY §8b); edge_feats
     [n_edges+1, d_e] (row 0 = padding); n_nodes = number of table rows (args.n_nodes, train.py:129).
     sampling: "recent" (the reference's NeighborFinder) or "uniform" (seeded, not in the reference: BASELINE
@@ -59,6 +59,9 @@ class OrcaEngine:
     if sampling not in ("recent", "uniform"):
       raise ValueError(f"OrcaEngine: unknown sampling mode {sampling!r}")
     self.sampling, self.seed = sampling, int(seed)
+    # attention-weight dropout of train_step (train.py:30 --drop_out, nn.MultiheadAttention's); the forward-only
+    # entry points never drop (module.eval()).  Counter RNG keyed (seed, batch, layer, query, head, slot).
+    self.dropout = float(dropout)
     self.exchange_cap = exchange_cap
     self._sharded = False    # True: memory / last_update / messages / msg_ts rows are current only on their owner
     # the reference freezes its time encoder (model/time_encoding.py:20-23: requires_grad False, forward under no_grad):
@@ -458,7 +461,14 @@ class OrcaEngine:
       nbr, eid, _, dt = self._timed("sample_recent", ops.sample_recent, self.csr, nodes, ts, self.K)
     return nbr, eid, dt
 
-  def _attend(self, layer, Q, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr_idx, from_memory):
+  def _dropout_kw(self, layer, q0):
+    """dropout inputs of this batch's attention call of `layer` (train_step), {} when off"""
+    if self.dropout <= 0.0:
+      return {}
+    return dict(dropout_p=self.dropout, dropout_q0=int(q0),
+                dropout_seed=(self.seed * 0x2545F4914F6CDD1D + self.batch_counter * 0x9E3779B97F4A7C15 + layer) & 0xFFFFFFFFFFFFFFFF)
+
+  def _attend(self, layer, Q, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr_idx, from_memory, drop=None):
     """embedding_module.py:318-329 (aggregate) fused with the gathers of :123,133,172-174 and the
     time encodings of :126,132."""
     kw = dict(src_table=src_table, src_idx=src_idx, nbr_table=nbr_table, nbr_idx=nbr_idx, nbr_ids=nbr,
@@ -466,6 +476,8 @@ class OrcaEngine:
               q_folded=True)
     if from_memory and train:
       kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
+    if drop:
+      kw.update(drop)
     out, _ = self._timed("tgat_forward", ops.tgat_forward, self.att_blobs[layer - 1], self.d_e, Q, self.K, **kw)
     return out
 
@@ -630,7 +642,8 @@ class OrcaEngine:
   def train_step(self, src, dst, neg, ts, eidx):
     """One training batch of train.py:200-246 up to (not including) optimizer.step(): the train-ordered forward
     of compute_edge_probabilities (tgn_model.py:95-157), the loss BCE(pos, 1) + BCE(neg, 0) (train.py:231-233) and
-    its backward.  Path A (exact recursion) and Path B (`reuse`); no budgeted reuse; dropout off.  Returns
+    its backward.  Path A (exact recursion) and Path B (`reuse`); no budgeted reuse; attention-weight dropout as the engine was built
+    (dropout=..., train.py:30; counter RNG, see include/orca_hip.h).  Returns
     (loss, grads) with grads keyed like the state_dict (parameters the loss does not reach are absent); the state
     advances exactly as in compute_temporal_embeddings(train=True).  Gradients flow as upstream: through the
     attention layers (Path A: also through the inner-layer embeddings of the sampled neighbours) into the
@@ -666,15 +679,17 @@ class OrcaEngine:
       nbr, eid, dt = self._sample(my_nodes, t3[lo:hi], q0=lo)
       self._overlay_updated_memory(nbr, my_nodes)
       my32 = my_nodes.to(torch.int32)
-      emb = self._attend(1, n, nbr, eid, dt, True, self.memory, my32, self.memory, nbr, True)
-      steps.append((1, n, (nbr, eid, dt), dict(src_table=self.memory, src_idx=my32, nbr_table=self.memory, nbr_idx=nbr),
+      dk = self._dropout_kw(1, lo)
+      emb = self._attend(1, n, nbr, eid, dt, True, self.memory, my32, self.memory, nbr, True, drop=dk)
+      steps.append((1, n, (nbr, eid, dt), dict(src_table=self.memory, src_idx=my32, nbr_table=self.memory, nbr_idx=nbr, **dk),
                     (my_nodes, nbr.view(-1))))
       for layer in range(2, self.L + 1):
         full = self._all_gather_rows(emb, Q, per)
         ops.history_push(self.hist[layer - 2], full, nodes, self.slot, self._slot_epoch(Q))
         prev = emb
-        emb = self._attend(layer, n, nbr, eid, dt, True, prev, None, self.hist[layer - 2], nbr, False)
-        steps.append((layer, n, (nbr, eid, dt), dict(src_table=prev, nbr_table=self.hist[layer - 2], nbr_idx=nbr), None))
+        dk = self._dropout_kw(layer, lo)
+        emb = self._attend(layer, n, nbr, eid, dt, True, prev, None, self.hist[layer - 2], nbr, False, drop=dk)
+        steps.append((layer, n, (nbr, eid, dt), dict(src_table=prev, nbr_table=self.hist[layer - 2], nbr_idx=nbr, **dk), None))
     else:                                                # embedding_module.py:116-147
       f_nodes, f_ts, samples = [my_nodes], [t3[lo:hi]], []
       for _ in range(self.L):
@@ -690,13 +705,15 @@ class OrcaEngine:
         m = f_nodes[lvl].numel()
         if layer == 1:
           i32 = f_nodes[lvl].to(torch.int32)
-          emb = self._attend(1, m, nbr, eid, dt, True, self.memory, i32, self.memory, nbr, True)
-          steps.append((1, m, samples[lvl], dict(src_table=self.memory, src_idx=i32, nbr_table=self.memory, nbr_idx=nbr),
+          dk = self._dropout_kw(1, 0)      # (the exact recursion numbers its frontier per rank)
+          emb = self._attend(1, m, nbr, eid, dt, True, self.memory, i32, self.memory, nbr, True, drop=dk)
+          steps.append((1, m, samples[lvl], dict(src_table=self.memory, src_idx=i32, nbr_table=self.memory, nbr_idx=nbr, **dk),
                         (f_nodes[lvl], nbr.view(-1))))
         else:
           prev = emb
-          emb = self._attend(layer, m, nbr, eid, dt, True, prev, None, prev[m:], None, False)
-          steps.append((layer, m, samples[lvl], dict(src_table=prev, nbr_table=prev[m:]), "cat"))
+          dk = self._dropout_kw(layer, 0)
+          emb = self._attend(layer, m, nbr, eid, dt, True, prev, None, prev[m:], None, False, drop=dk)
+          steps.append((layer, m, samples[lvl], dict(src_table=prev, nbr_table=prev[m:], **dk), "cat"))
     out = self._all_gather_rows(emb, Q, per)
     # ---- link decoder + loss (tgn_model.py:150-157, train.py:231-233) ----
     leaf = out.detach().requires_grad_()

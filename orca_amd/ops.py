@@ -200,22 +200,9 @@ def tgat_pack(sd, d_e, device, blob=None, time_b=None):
 
 
 def tgat_forward(blob, d_e, Q, K, out=None, want_weights=False, **kw):
-  """orca_tgat_forward.  kw: the fields of orca_tgat_inputs (tensors or None; q_folded: bool)."""
-  inp = _lib.TgatInputs()
-  inp.q_folded = int(bool(kw.pop("q_folded", False)))
-  keep = []
-  for name, ty in _lib.TgatInputs._fields_:
-    if ty is not _lib.vp:
-      continue
-    t = kw.pop(name, None)
-    if t is not None:
-      if not t.is_cuda:
-        raise _lib.OrcaError(f"tgat_forward: {name} is not on the HIP device")
-      t = t.contiguous()
-      keep.append(t)
-    setattr(inp, name, ptr(t))
-  if kw:
-    raise TypeError(f"tgat_forward: unknown inputs {sorted(kw)}")
+  """orca_tgat_forward.  kw: the fields of orca_tgat_inputs (tensors or None; q_folded: bool; dropout_p, dropout_seed,
+  dropout_q0: attention-weight dropout, off by default)."""
+  inp, keep = _tgat_inputs(kw, "tgat_forward")
   dev = blob.device
   if out is None:
     out = torch.empty((Q, D), dtype=torch.float32, device=dev)
@@ -225,9 +212,21 @@ def tgat_forward(blob, d_e, Q, K, out=None, want_weights=False, **kw):
   return out, w
 
 
+def tgat_dropout_mask(seed, q0, Q, K, p, device):
+  """the multipliers (0 or 1/(1-p)) [Q, 2, K] the attention kernels apply for (seed, q0): what a checker feeds its
+  own softmax in place of torch's dropout"""
+  m = torch.empty((Q, 2, K), dtype=torch.float32, device=device)
+  check(_lib.load().orca_tgat_dropout_mask(int(seed) & 0xFFFFFFFFFFFFFFFF, int(q0), int(Q), int(K), float(p), ptr(m), stream()),
+        "orca_tgat_dropout_mask")
+  return m
+
+
 def _tgat_inputs(kw, who):
   inp = _lib.TgatInputs()
   inp.q_folded = int(bool(kw.pop("q_folded", False)))
+  inp.dropout_p = float(kw.pop("dropout_p", 0.0) or 0.0)
+  inp.dropout_seed = int(kw.pop("dropout_seed", 0) or 0) & 0xFFFFFFFFFFFFFFFF
+  inp.dropout_q0 = int(kw.pop("dropout_q0", 0) or 0)
   keep = []
   for name, ty in _lib.TgatInputs._fields_:
     if ty is not _lib.vp:

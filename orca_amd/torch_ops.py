@@ -55,20 +55,21 @@ def sample_uniform(csr: int, nodes: Tensor, ts: Tensor, K: int, seed: int, q0: i
 # ---- attention, dense boundary ------------------------------------------------------------------------------
 @_lib.custom_op("orca::tgat_dense", mutates_args=())
 def tgat_dense(params: List[Tensor], blob: Tensor, d_e: int, src: Tensor, src_time: Tensor, nbr: Tensor,
-               nbr_time: Tensor, edge: Tensor, mask: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+               nbr_time: Tensor, edge: Tensor, mask: Tensor, dropout_p: float, dropout_seed: int) -> Tuple[Tensor, Tensor, Tensor]:
   """-> (out [B,100], weights [B,K], mask_after): the reference un-masks slot 0 of all-padded rows in the caller's
   mask (temporal_attention.py:46-47); an op with an autograd formula has to be functional, so the mutated mask
   comes back as an output and the layer copies it into the caller's tensor."""
   B, K = mask.shape
   after = mask.clone()
   out, w = ops.tgat_forward(blob, d_e, B, K, want_weights=True, src_table=src, nbr_table=nbr, edge_table=edge,
-                            mask=after.view(torch.uint8), src_time=src_time, nbr_time=nbr_time)
+                            mask=after.view(torch.uint8), src_time=src_time, nbr_time=nbr_time, dropout_p=dropout_p,
+                            dropout_seed=dropout_seed)
   return out, w, after
 
 
 def _tgat_dense_setup(ctx, inputs, output):
-  params, blob, d_e, src, st, nbr, nt, edge, mask = inputs
-  ctx.d_e = d_e
+  params, blob, d_e, src, st, nbr, nt, edge, mask, dropout_p, dropout_seed = inputs
+  ctx.d_e, ctx.drop = d_e, (dropout_p, dropout_seed)
   ctx.save_for_backward(src, st, nbr, nt, edge, mask, *params)     # the mask as it was BEFORE the forward
 
 
@@ -77,8 +78,8 @@ def _tgat_dense_backward(ctx, g_out, _g_w, _g_m):
   B, K = before.shape
   grads, d_src, d_nbr, d_st, d_nt, _, _ = ops.tgat_backward(
       dict(zip(ops.TGAT_KEYS, params)), ctx.d_e, B, K, g_out.contiguous(), src_table=src, nbr_table=nbr, edge_table=edge,
-      mask=before.view(torch.uint8), src_time=st, nbr_time=nt)
-  return [grads[k] for k in ops.TGAT_KEYS], None, None, d_src, d_st, d_nbr, d_nt, None, None
+      mask=before.view(torch.uint8), src_time=st, nbr_time=nt, dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1])
+  return [grads[k] for k in ops.TGAT_KEYS], None, None, d_src, d_st, d_nbr, d_nt, None, None, None, None
 
 
 _lib.register_autograd("orca::tgat_dense", _tgat_dense_backward, setup_context=_tgat_dense_setup)
@@ -90,11 +91,12 @@ def tgat_gather(params: List[Tensor], blob: Tensor, d_e: int, Q: int, K: int, sr
                 src_idx: Optional[Tensor], nbr_table: Tensor, nbr_idx: Optional[Tensor], nbr_ids: Tensor,
                 edge_table: Tensor, edge_idx: Tensor, dt: Tensor, time_w: Tensor, time_b: Tensor,
                 overlay: Optional[Tensor], flags: Optional[Tensor], upd_rows: Optional[Tensor],
-                upd_pos: Optional[Tensor], q_folded: bool) -> Tensor:
+                upd_pos: Optional[Tensor], q_folded: bool, dropout_p: float, dropout_seed: int) -> Tensor:
   """upd_rows / upd_pos carry no data the forward reads (it reads `overlay`, the table the GRU op filled): they tie
   the overlay rows into the autograd graph -- upd_rows[upd_pos[id]] is overlay[id] for the flagged ids."""
   kw = dict(src_table=src_table, src_idx=src_idx, nbr_table=nbr_table, nbr_idx=nbr_idx, nbr_ids=nbr_ids,
-            edge_table=edge_table, edge_idx=edge_idx, dt=dt, time_w=time_w, time_b=time_b, q_folded=q_folded)
+            edge_table=edge_table, edge_idx=edge_idx, dt=dt, time_w=time_w, time_b=time_b, q_folded=q_folded,
+            dropout_p=dropout_p, dropout_seed=dropout_seed)
   if flags is not None:
     kw.update(src_overlay=overlay, src_flags=flags, nbr_overlay=overlay, nbr_flags=flags)
   return ops.tgat_forward(blob, d_e, Q, K, **kw)[0]
@@ -102,8 +104,9 @@ def tgat_gather(params: List[Tensor], blob: Tensor, d_e: int, Q: int, K: int, sr
 
 def _tgat_gather_setup(ctx, inputs, output):
   (params, blob, d_e, Q, K, src_table, src_idx, nbr_table, nbr_idx, nbr_ids, edge_table, edge_idx, dt, time_w, time_b,
-   overlay, flags, upd_rows, upd_pos, q_folded) = inputs
+   overlay, flags, upd_rows, upd_pos, q_folded, dropout_p, dropout_seed) = inputs
   ctx.d_e, ctx.Q, ctx.K = d_e, Q, K
+  ctx.drop = (dropout_p, dropout_seed)
   ctx.src_rows, ctx.nbr_rows = src_table.shape[0], nbr_table.shape[0]
   ctx.upd_n = upd_rows.shape[0] if upd_rows is not None else 0
   ctx.opt = [t is not None for t in (src_idx, nbr_idx, overlay, flags, upd_pos)]
@@ -122,7 +125,8 @@ def _tgat_gather_backward(ctx, g_out):
   src_idx, nbr_idx, overlay, flags, upd_pos = (next(it) if has else None for has in ctx.opt)
   Q, K = ctx.Q, ctx.K
   kw = dict(src_table=src_table, src_idx=src_idx, nbr_table=nbr_table, nbr_idx=nbr_idx, nbr_ids=nbr_ids,
-            edge_table=edge_table, edge_idx=edge_idx, dt=dt, time_w=time_w, time_b=time_b)
+            edge_table=edge_table, edge_idx=edge_idx, dt=dt, time_w=time_w, time_b=time_b, dropout_p=ctx.drop[0],
+            dropout_seed=ctx.drop[1])
   if flags is not None:
     kw.update(src_overlay=overlay, src_flags=flags, nbr_overlay=overlay, nbr_flags=flags)
   grads, d_src, d_nbr, _, _, _, _ = ops.tgat_backward(dict(zip(ops.TGAT_KEYS, params)), ctx.d_e, Q, K, g_out.contiguous(), **kw)
@@ -138,7 +142,7 @@ def _tgat_gather_backward(ctx, g_out):
     if nbr_idx is not None and ctx.upd_n:
       ops.scatter_add_flagged(d_nbr, nbr_idx.reshape(-1), flags, upd_pos, g_upd)
   return ([grads[k] for k in ops.TGAT_KEYS], None, None, None, None, g_src_table, None, g_nbr_table, None, None, None,
-          None, None, None, None, None, None, g_upd, None, None)
+          None, None, None, None, None, None, g_upd, None, None, None, None)
 
 
 _lib.register_autograd("orca::tgat_gather", _tgat_gather_backward, setup_context=_tgat_gather_setup)

@@ -162,13 +162,16 @@ def test_gru_backward(ops, msg_dim, n, gather):
   assert_close_fp32(got[5].cpu().numpy(), hr.grad.numpy(), TOL, "gru d_h")
 
 
-@pytest.mark.parametrize("reuse,L,bs", [(True, 2, 150), (False, 2, 150), (False, 1, 150), (True, 2, 1365)])
-def test_engine_train_step_vs_autograd(ops, reuse, L, bs):
+@pytest.mark.parametrize("reuse,L,bs,drop", [(True, 2, 150, 0.0), (False, 2, 150, 0.0), (False, 1, 150, 0.0), (True, 2, 1365, 0.0),
+                                              (True, 2, 150, 0.4), (False, 2, 150, 0.4)])
+def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop):
   """OrcaEngine.train_step (Path B with 2 layers; Path A, the exact recursion, with 2 layers and with 1 layer = the
   reference's default configuration): loss and every parameter gradient against torch autograd of the oracle's
   pieces composed as tgn_model.py:95-157 / embedding_module.py:116-182 compose them, on a warmed-up state (pending
   messages, pushed history); and the state after the step equals the forward-only step's.  bs = 1365 is the bench's
-  batch shape (4095 roots: every split-K and tile variant of the backward GEMM is in play)."""
+  batch shape (4095 roots: every split-K and tile variant of the backward GEMM is in play).  drop > 0: the
+  attention-weight dropout of train.py:30 -- the checker multiplies its softmax by the keep masks the kernels used
+  (orca_tgat_dropout_mask; RNG stream unpinned, masked arithmetic pinned)."""
   from orca_amd import synth
   from orca_amd.engine import OrcaEngine
   N, E, K, d_e = 1500, 30000, 10, 172
@@ -179,7 +182,7 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs):
   csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
   engs = []
   for _ in range(2):
-    e = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=0, device="cuda:0")
+    e = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=0, device="cuda:0", dropout=drop, seed=11)
     e.set_neighbor_finder(csr)
     e.train_time_encoder = True     # the kernels' time-encoder gradient is checked too (frozen upstream: off by default)
     engs.append(e)
@@ -200,7 +203,7 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs):
   torch.cuda.synchronize()
   for name in ("memory", "last_update", "messages", "msg_ts", "pending"):
     assert_close_fp32(getattr(A, name).float().cpu().numpy(), getattr(B, name).float().cpu().numpy(), 1e-6, "state " + name)
-  if reuse:
+  if reuse and not drop:
     assert_close_fp32(A.hist[0].cpu().numpy(), B.hist[0].cpu().numpy(), 1e-6, "state hist")
   # ---- the checker: torch autograd on the CPU ----
   nodes = torch.cat([bt[0], bt[1], bt[2]])
@@ -220,9 +223,14 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs):
     nbr, eid, dt = smp
     n = s_rows.shape[0]
     p = f"embedding_module.attention_models.{i}."
+    mult = None
+    if drop:
+      dk = A._dropout_kw(i + 1, 0)
+      assert dk["dropout_p"] == drop
+      mult = ops.tgat_dropout_mask(dk["dropout_seed"], 0, n, K, drop, DEV).cpu()
     return O.attention_forward({k[len(p):]: v for k, v in P.items() if k.startswith(p)}, s_rows,
                                O.time_encode(torch.zeros(n, 1), wt, bt_), n_rows, O.time_encode(dt, wt, bt_), efc[eid],
-                               nbr == 0)[0]
+                               nbr == 0, drop_mult=mult)[0]
   s0 = sample(nodes, t3)
   nc = nodes.cpu()
   if reuse:
@@ -298,3 +306,99 @@ def test_optimizer_step_and_refresh(ops):
   a = eng.compute_temporal_embeddings(*nb, True)
   c = fresh.compute_temporal_embeddings(*nb, True)
   assert torch.equal(a, c) and torch.equal(eng.memory, fresh.memory) and torch.equal(eng.messages, fresh.messages)
+
+
+@pytest.mark.parametrize("tag", ["de172_K10_", "de4_K20_"])
+def test_attention_dropout_forward_and_backward_vs_oracle(ops, golden, tag):
+  """Attention-weight dropout (nn.MultiheadAttention(dropout=p), model/temporal_attention.py:17-21; train.py:30
+  default 0.4).  torch's dropout RNG stream cannot be reproduced by another implementation -- "RNG stream unpinned":
+  the kernel draws its keep decisions from a counter RNG and orca_tgat_dropout_mask writes them out; the MASKED
+  ARITHMETIC is pinned: the oracle's softmax is multiplied by the same mask (F.dropout replaced by an explicit mask
+  multiply) and output, parameter and input gradients must agree at 1e-5.  The inputs are the reference's golden
+  attention cases (all-padded rows included)."""
+  g = golden("attention.npz")
+  sd = _sd(g, tag)
+  d_e = g[tag + "edge"].shape[2]
+  B, K = g[tag + "mask_in"].shape
+  p, seed, q0 = 0.4, 0xC0FFEE1234, 77
+  mult = ops.tgat_dropout_mask(seed, q0, B, K, p, DEV)
+  mh = mult.cpu()
+  assert set(np.unique(mh.numpy()).tolist()) <= {0.0, np.float32(1.0 / (1.0 - p))}
+  assert 0.25 < float((mh == 0).float().mean()) < 0.55                      # about p of the weights are dropped
+  R = torch.from_numpy(np.random.RandomState(B + K).randn(B, 100).astype(np.float32))
+  names = ["src", "src_t", "nbr", "nbr_t"]
+  P = {k: v.clone().requires_grad_() for k, v in sd.items()}
+  xin = {k: torch.from_numpy(g[tag + k]).clone().requires_grad_() for k in names}
+  out, _ = O.attention_forward(P, xin["src"], xin["src_t"], xin["nbr"], xin["nbr_t"], torch.from_numpy(g[tag + "edge"]),
+                               torch.from_numpy(g[tag + "mask_in"].copy()), drop_mult=mh)
+  (out * R).sum().backward()
+  blob = ops.tgat_pack(sd, d_e, DEV)
+  dsd = {k: v.to(DEV) for k, v in sd.items()}
+  t = lambda k: torch.from_numpy(g[tag + k]).to(DEV).contiguous()
+  f = lambda x, w: x.reshape(-1, w).contiguous()
+  kw = dict(src_table=f(t("src"), 100), nbr_table=f(t("nbr"), 100), edge_table=f(t("edge"), d_e),
+            src_time=f(t("src_t"), 100), nbr_time=f(t("nbr_t"), 100), dropout_p=p, dropout_seed=seed, dropout_q0=q0)
+  mask = torch.from_numpy(g[tag + "mask_in"].copy()).to(DEV)
+  got, _ = ops.tgat_forward(blob, d_e, B, K, mask=mask.clone().view(torch.uint8), **kw)
+  assert_close_fp32(got.cpu().numpy(), out.detach().numpy(), TOL, tag + "dropout forward")
+  plain, _ = ops.tgat_forward(blob, d_e, B, K, mask=mask.clone().view(torch.uint8), **{k: v for k, v in kw.items() if not k.startswith("dropout")})
+  assert_close_fp32(plain.cpu().numpy(), g[tag + "out"], TOL, tag + "forward without dropout")
+  assert float((got - plain).abs().max()) > 1e-3                             # and dropout does change the output
+  grads, d_src, d_nbr, d_st, d_nt, _, _ = ops.tgat_backward(dsd, d_e, B, K, R.to(DEV), mask=mask.view(torch.uint8), **kw)
+  for k, v in P.items():
+    r = v.grad.numpy().copy()
+    if k.endswith("in_proj_bias"):
+      r[200:400] = 0.0           # softmax is shift-invariant: the key bias has no gradient (autograd leaves round-off)
+    assert_close_fp32(grads[k].cpu().numpy().reshape(r.shape), r, TOL, tag + "dropout grad " + k)
+  for nm, got_g in zip(names, (d_src, d_st, d_nbr, d_nt)):
+    assert_close_fp32(got_g.cpu().numpy().reshape(-1), xin[nm].grad.numpy().reshape(-1), TOL, tag + "dropout d_" + nm)
+
+
+def test_api_layer_train_mode_dropout(ops, golden):
+  """The drop-in TemporalAttentionLayer in train() mode: the call draws its dropout seed from torch's CPU generator
+  (torch.manual_seed makes a run repeatable, as it does upstream), eval() switches dropout off; output and gradients
+  against the oracle under the same keep mask."""
+  import orca_amd.api as api
+  tag = "de172_K10_"
+  g = golden("attention.npz")
+  sd = _sd(g, tag)
+  d_e = g[tag + "edge"].shape[2]
+  B, K = g[tag + "mask_in"].shape
+  p = 0.4
+  layer = api.TemporalAttentionLayer(100, 100, d_e, 100, 100, n_head=2, dropout=p)
+  layer.load_state_dict(sd, strict=True)
+  layer = layer.to(DEV).train()
+  names = ["src", "src_t", "nbr", "nbr_t"]
+  yin = {k: torch.from_numpy(g[tag + k]).to(DEV).requires_grad_() for k in names}
+  edge = torch.from_numpy(g[tag + "edge"]).to(DEV)
+  call = lambda: layer(yin["src"], yin["src_t"], yin["nbr"], yin["nbr_t"], edge, torch.from_numpy(g[tag + "mask_in"].copy()).to(DEV))
+  torch.manual_seed(123)
+  seed = int(torch.randint(0, 1 << 62, (1,)).item())
+  torch.manual_seed(123)
+  got, w = call()
+  torch.manual_seed(123)
+  again, _ = call()
+  assert torch.equal(got, again)
+  other, _ = call()                                    # the generator moved on: another mask
+  assert not torch.equal(got, other)
+  mh = ops.tgat_dropout_mask(seed, 0, B, K, p, DEV).cpu()
+  P = {k: v.clone().requires_grad_() for k, v in sd.items()}
+  xin = {k: torch.from_numpy(g[tag + k]).clone().requires_grad_() for k in names}
+  out, wr = O.attention_forward(P, xin["src"], xin["src_t"], xin["nbr"], xin["nbr_t"], torch.from_numpy(g[tag + "edge"]),
+                                torch.from_numpy(g[tag + "mask_in"].copy()), drop_mult=mh)
+  assert_close_fp32(got.detach().cpu().numpy(), out.detach().numpy(), TOL, "train-mode layer output")
+  assert_close_fp32(w.cpu().numpy(), wr.detach().numpy(), TOL, "train-mode layer weights (after dropout, as nn.MultiheadAttention)")
+  R = torch.from_numpy(np.random.RandomState(3).randn(B, 100).astype(np.float32))
+  (out * R).sum().backward()
+  (got * R.to(DEV)).sum().backward()
+  named = dict(layer.named_parameters())
+  for k in sd:
+    r = P[k].grad.numpy().copy()
+    if k.endswith("in_proj_bias"):
+      r[200:400] = 0.0
+    assert_close_fp32(named[k].grad.cpu().numpy(), r, TOL, "train-mode grad " + k)
+  for k in names:
+    assert_close_fp32(yin[k].grad.cpu().numpy(), xin[k].grad.numpy(), TOL, "train-mode grad input " + k)
+  layer.eval()
+  plain, _ = call()
+  assert_close_fp32(plain.detach().cpu().numpy(), g[tag + "out"], TOL, "eval() switches dropout off")
