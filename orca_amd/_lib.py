@@ -161,6 +161,16 @@ def ptr(t):
   return t.ctypes.data
 
 
+_raw_stream = None
+
+
 def stream():
+  """the current HIP stream of the current device, as a raw handle (the fast accessor: the Stream object route costs
+  10 us a call, and a training step makes twenty)"""
+  global _raw_stream
   import torch
+  if _raw_stream is None:
+    _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+  if _raw_stream:
+    return _raw_stream(torch.cuda.current_device())
   return torch.cuda.current_stream().cuda_stream

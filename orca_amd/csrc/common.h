@@ -232,11 +232,52 @@ constexpr int ORCA_GEMM_SPLITS = 32;
 int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
                int64_t sbn, float* C, int64_t scm, int64_t scn, const float* bias, float alpha, bool accumulate, bool relu,
                float* part = nullptr, int splits = 1);
+// Several independent problems in ONE launch (and one more for the split-K sums of those that ask for splits): the
+// backward's GEMMs are short (10-15 us each), so what is launched together overlaps instead of queueing.
+struct OrcaGemm {
+  int M, N, K;
+  const float* A; int64_t sam, sak;
+  const float* B; int64_t sbk, sbn;
+  float* C; int64_t scm, scn;
+  const float* bias;        // [N] or NULL
+  float alpha;
+  int accumulate, relu;
+  const float* gate;        // strides of C, or NULL: the result is zeroed where gate(m,n) <= 0 (ReLU backward)
+  const float* rowzero;     // [M] or NULL: rows with rowzero[m] != 0 are zeroed in the columns n < rowzero_n
+  int rowzero_n;
+  float* ones_out;          // [M] or NULL: B gets a virtual column N of ones, whose result alpha * sum_k A(m,k)
+                            // (+ old value when accumulate) goes here -- the bias gradient of a weight-gradient GEMM
+  int splits;               // > 1: split-K through `part` (no bias / relu / gate / rowzero then)
+};
+constexpr int ORCA_GEMM_GROUP_MAX = 8;
+// floats of `part` a group needs
+int64_t orca_sgemm_group_part_floats(const OrcaGemm* g, int n);
+int orca_sgemm_group(hipStream_t s, const OrcaGemm* g, int n, float* part);
 // out[n] (+)= alpha * sum_q X[q*ld + n], n < ncols
 // (part: scratch of 64 * ncols floats)
 int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate,
                 float* part);
 
-// generic strided pack kernel launcher (pack.hip)
+// generic strided pack kernel launcher (tgat.hip)
 int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd, const float* src,
                      int64_t sn, int64_t sk, hipStream_t stream, bool tail1 = false);
+// Several pack jobs in ONE launch: a re-pack after every optimizer step is two dozen tiny kernels otherwise.
+struct OrcaPackJob {
+  int kind;                 // 0: matrix into MFMA-fragment order (orca_pack_matrix); 1: dst[i < n_pad] = i < n ? src[i] : 0;
+                            // 2: *dst = 1
+  float* dst;
+  const float* src;
+  int KB, n0, n_cnt, Kd, tail1;     // kind 0
+  int64_t sn, sk;                   // kind 0
+  int n, n_pad;                     // kind 1
+};
+constexpr int ORCA_PACK_GROUP_MAX = 16;
+inline OrcaPackJob orca_pack_job(float* dst, int KB, int n0, int n_cnt, int Kd, const float* src, int64_t sn, int64_t sk,
+                                 bool tail1 = false) {
+  return OrcaPackJob{0, dst, src, KB, n0, n_cnt, Kd, tail1 ? 1 : 0, sn, sk, 0, 0};
+}
+inline OrcaPackJob orca_copy_pad_job(float* dst, const float* src, int n, int n_pad) {
+  return OrcaPackJob{1, dst, src, 0, 0, 0, 0, 0, 0, 0, n, n_pad};
+}
+inline OrcaPackJob orca_flag_job(float* dst) { return OrcaPackJob{2, dst, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+int orca_pack_group(const OrcaPackJob* jobs, int n, hipStream_t stream);

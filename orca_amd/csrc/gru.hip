@@ -360,12 +360,14 @@ ORCA_API int orca_gru_pack(int msg_dim, const float* w_ih, const float* w_hh, co
   GBlob L = gru_layout(msg_dim);
   ORCA_HIP_TRY(hipMemsetAsync(blob, 0, (size_t)L.total * sizeof(float), s));
   int rc = ORCA_OK;
+  OrcaPackJob jobs[6];
   for (int g = 0; g < 3; ++g) {
-    rc |= orca_pack_matrix(blob + L.pw_x + (int64_t)g * NWG * L.KBx * 256, NWG, L.KBx, 0, D, msg_dim,
-                           w_ih + (int64_t)g * D * msg_dim, msg_dim, 1, s);
-    rc |= orca_pack_matrix(blob + L.pw_h + (int64_t)g * NWG * L.KBh * 256, NWG, L.KBh, 0, D, D,
-                           w_hh + (int64_t)g * D * D, D, 1, s);
+    jobs[2 * g] = orca_pack_job(blob + L.pw_x + (int64_t)g * NWG * L.KBx * 256, L.KBx, 0, D, msg_dim,
+                                w_ih + (int64_t)g * D * msg_dim, msg_dim, 1);
+    jobs[2 * g + 1] = orca_pack_job(blob + L.pw_h + (int64_t)g * NWG * L.KBh * 256, L.KBh, 0, D, D,
+                                    w_hh + (int64_t)g * D * D, D, 1);
   }
+  rc |= orca_pack_group(jobs, 6, s);
   k_gru_bias<<<1, 128, 0, s>>>(blob + L.bias, b_ih, b_hh);
   if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
     orca_set_error("orca_gru_pack: kernel launch failed");

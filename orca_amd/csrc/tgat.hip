@@ -85,6 +85,7 @@ __global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restric
     const int r = i - 2 * D * D, part = r / QD, j = r % QD;
     if (part < 2) {
       double t = 0.0;
+#pragma unroll 10
       for (int k = 0; k < D; ++k) t += (double)o_w[j * QD + part * D + k] * (double)bv[part * D + k];
       U[i] = t;
     } else if (part == 2) {
@@ -94,6 +95,7 @@ __global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restric
   }
   const int h = i / (D * D), n = (i / D) % D, d = i % D;
   double acc = 0.0;
+#pragma unroll 10
   for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * (double)o_w[j * QD + h * D + d];
   U[i] = acc;
 }
@@ -110,6 +112,7 @@ __global__ void k_fold_f(const double* __restrict__ U, const float* __restrict__
   if (col < 2 * KP) {
     const int h = col / KP, c = col - h * KP;
     if (c < kdim) {
+#pragma unroll 10
       for (int d = 0; d < D; ++d) acc += U[(h * D + n) * D + d] * (double)v_w[(int64_t)(h * D + d) * kdim + c];
     } else if (c == kdim) {
       for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * U[2 * D * D + h * QD + j];
@@ -130,6 +133,7 @@ __global__ void k_fold_qt(const float* __restrict__ q_w, const float* __restrict
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= QD) return;
   double acc = (double)in_b[j];
+#pragma unroll 4
   for (int i = 0; i < D; ++i)
     acc += (double)q_w[j * QD + D + i] * (double)orca_cosf(orca_time_arg(0.0f, 0.0f, time_b[i]));
   t[j] = acc;
@@ -145,6 +149,7 @@ __global__ void k_fold_qk(const float* __restrict__ q_w, const float* __restrict
   const int h = i / per, c = (i % per) / (D + 1), s = i % (D + 1);
   const double scale = (double)0.1f;
   double acc = 0.0;
+#pragma unroll 10
   for (int d = 0; d < D; ++d) {
     const int j = h * D + d;
     const double wk = c < kdim ? (double)k_w[(int64_t)j * kdim + c] : (double)in_b[QD + j];
@@ -153,8 +158,6 @@ __global__ void k_fold_qk(const float* __restrict__ q_w, const float* __restrict
   if (s < D) A[((int64_t)h * (kdim + 1) + c) * D + s] = (float)(scale * acc);
   else a[h * KP + c] = (float)(scale * acc);
 }
-__global__ void k_set_flag(float* p) { *p = 1.0f; }
-
 __global__ void k_pack(float* __restrict__ dst, int KB, int n0, int n_cnt, int Kd, const float* __restrict__ src,
                        int64_t sn, int64_t sk, int tail1) {
   // one thread per destination float of the n-tiles that intersect [n0, n0+n_cnt)
@@ -175,12 +178,63 @@ __global__ void k_pack(float* __restrict__ dst, int KB, int n0, int n_cnt, int K
   dst[((int64_t)nt * KB + kb) * 256 + lane * 4 + s] = v;
 }
 
-__global__ void k_copy_pad(float* dst, const float* src, int n, int n_pad) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_pad) dst[i] = (i < n) ? src[i] : 0.0f;
+struct PackGroup {
+  int n;
+  int first[ORCA_PACK_GROUP_MAX + 1];     // first block of each job
+  OrcaPackJob j[ORCA_PACK_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void k_pack_group(PackGroup grp) {
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < ORCA_PACK_GROUP_MAX; ++i) p += (i < grp.n && (int)blockIdx.x >= grp.first[i]) ? 1 : 0;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const OrcaPackJob j = grp.j[p];
+  const int64_t idx = (int64_t)((int)blockIdx.x - grp.first[p]) * 256 + threadIdx.x;
+  if (j.kind == 1) {
+    if (idx < j.n_pad) j.dst[idx] = idx < j.n ? j.src[idx] : 0.0f;
+    return;
+  }
+  if (j.kind == 2) {
+    if (idx == 0) *j.dst = 1.0f;
+    return;
+  }
+  // one thread per destination float of the n-tiles that intersect [n0, n0+n_cnt)   (k_pack)
+  const int nt0 = j.n0 / 16;
+  const int nt_cnt = (j.n0 + j.n_cnt + 15) / 16 - nt0;
+  if (idx >= (int64_t)nt_cnt * j.KB * 256) return;
+  const int s = idx & 3;
+  const int lane = (idx >> 2) & 63;
+  const int64_t blk = idx >> 8;
+  const int kb = (int)(blk % j.KB);
+  const int nt = nt0 + (int)(blk / j.KB);
+  const int n = nt * 16 + (lane & 15);
+  int k = kb * 16 + 4 * (lane >> 4) + s;
+  if (j.tail1 && kb == j.KB - 1) k = s == 0 ? kb * 16 + (lane >> 4) : j.Kd;
+  if (n < j.n0 || n >= j.n0 + j.n_cnt) return;
+  const float v = (k < j.Kd) ? j.src[(int64_t)(n - j.n0) * j.sn + (int64_t)k * j.sk] : 0.0f;
+  j.dst[((int64_t)nt * j.KB + kb) * 256 + lane * 4 + s] = v;
 }
 
 }  // namespace
+
+int orca_pack_group(const OrcaPackJob* jobs, int n, hipStream_t stream) {
+  if (n <= 0) return ORCA_OK;
+  if (n > ORCA_PACK_GROUP_MAX) return ORCA_EINVAL;
+  PackGroup grp{};
+  grp.n = n;
+  int first = 0;
+  for (int i = 0; i < n; ++i) {
+    grp.first[i] = first;
+    grp.j[i] = jobs[i];
+    int64_t total = 1;
+    if (jobs[i].kind == 0) total = (int64_t)((jobs[i].n0 + jobs[i].n_cnt + 15) / 16 - jobs[i].n0 / 16) * jobs[i].KB * 256;
+    else if (jobs[i].kind == 1) total = jobs[i].n_pad;
+    first += (int)ceil_div64(total > 0 ? total : 1, 256);
+  }
+  grp.first[n] = first;
+  k_pack_group<<<(unsigned)first, 256, 0, stream>>>(grp);
+  return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
+}
 
 int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd, const float* src, int64_t sn,
                      int64_t sk, hipStream_t stream, bool tail1) {
@@ -188,11 +242,6 @@ int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd
   int nt_cnt = (n0 + n_cnt + 15) / 16 - n0 / 16;
   int64_t total = (int64_t)nt_cnt * KB * 256;
   k_pack<<<(unsigned)ceil_div64(total, 256), 256, 0, stream>>>(dst, KB, n0, n_cnt, Kd, src, sn, sk, tail1 ? 1 : 0);
-  return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
-}
-
-static int copy_pad(float* dst, const float* src, int n, int n_pad, hipStream_t s) {
-  k_copy_pad<<<(n_pad + 255) / 256, 256, 0, s>>>(dst, src, n, n_pad);
   return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
 }
 
@@ -213,30 +262,33 @@ ORCA_API int orca_tgat_pack(int d_e, const float* q_w, const float* k_w, const f
   const int kdim = L.kdim;
   ORCA_HIP_TRY(hipMemsetAsync(blob, 0, (size_t)L.total * sizeof(float), s));
   int rc = ORCA_OK;
-  // q projection: out n = row of q_proj_weight [200,200]
-  rc |= orca_pack_matrix(blob + L.pw_q, pw_tiles(QD), pw_tiles(QD), 0, QD, QD, q_w, QD, 1, s);
-  rc |= copy_pad(blob + L.b_q, in_b, QD, 208, s);
+  // the folded tail (see the head of this file): multiplied out in fp64 in scratch memory first
+  const int width = L.KBT * 16;
+  double* U = reinterpret_cast<double*>(blob + L.scr_u);
+  float* F = blob + L.scr_f;
+  k_fold_u<<<(2 * D * D + 3 * QD + 255) / 256, 256, 0, s>>>(fc1_w, o_w, o_b, in_b + 2 * QD, U);
+  k_fold_f<<<(D * width + 255) / 256, 256, 0, s>>>(U, v_w, in_b, o_w, o_b, fc1_w, kdim, L.KP, width, F);
+  if (hipGetLastError() != hipSuccess) rc = ORCA_EHIP;
   const int KB100 = pw_tiles(D);
+  OrcaPackJob jobs[ORCA_PACK_GROUP_MAX];
+  int nj = 0;
+  // q projection: out n = row of q_proj_weight [200,200]
+  jobs[nj++] = orca_pack_job(blob + L.pw_q, pw_tiles(QD), 0, QD, QD, q_w, QD, 1);
+  jobs[nj++] = orca_copy_pad_job(blob + L.b_q, in_b, QD, 208);
   for (int h = 0; h < 2; ++h) {
     // folded key map of head h: out n = key column c (< kdim), reduction k = d (< 100):  Wk[h*100+d][c]
     float* kt = blob + L.pw_kt + (int64_t)h * pw_floats(kdim + 1, D);
-    rc |= orca_pack_matrix(kt, L.NTk, KB100, 0, kdim, D, k_w + (int64_t)h * D * kdim, 1, kdim, s, true);
+    jobs[nj++] = orca_pack_job(kt, KB100, 0, kdim, D, k_w + (int64_t)h * D * kdim, 1, kdim, true);
     // extra output column n = kdim: bk[h*100+d]  (gives the (0.1 q_h).bk_h score offset)
-    rc |= orca_pack_matrix(kt, L.NTk, KB100, kdim, 1, D, in_b + QD + h * D, 0, 1, s, true);
+    jobs[nj++] = orca_pack_job(kt, KB100, kdim, 1, D, in_b + QD + h * D, 0, 1, true);
   }
-  {   // the folded tail (see the head of this file): multiplied out in fp64 in scratch memory, then packed
-    const int width = L.KBT * 16;
-    double* U = reinterpret_cast<double*>(blob + L.scr_u);
-    float* F = blob + L.scr_f;
-    k_fold_u<<<(2 * D * D + 3 * QD + 255) / 256, 256, 0, s>>>(fc1_w, o_w, o_b, in_b + 2 * QD, U);
-    k_fold_f<<<(D * width + 255) / 256, 256, 0, s>>>(U, v_w, in_b, o_w, o_b, fc1_w, kdim, L.KP, width, F);
-    rc |= orca_pack_matrix(blob + L.pw_t, pw_tiles(D), L.KBT, 0, D, width, F, width, 1, s);
-  }
-  rc |= copy_pad(blob + L.b_1, fc1_b, D, 112, s);
-  rc |= orca_pack_matrix(blob + L.pw_2, pw_tiles(D), pw_tiles(D), 0, D, D, fc2_w, D, 1, s);
-  rc |= copy_pad(blob + L.b_2, fc2_b, D, 112, s);
-  rc |= copy_pad(blob + L.ln_w, ln_w, D, 112, s);
-  rc |= copy_pad(blob + L.ln_b, ln_b, D, 112, s);
+  jobs[nj++] = orca_pack_job(blob + L.pw_t, L.KBT, 0, D, width, F, width, 1);
+  jobs[nj++] = orca_copy_pad_job(blob + L.b_1, fc1_b, D, 112);
+  jobs[nj++] = orca_pack_job(blob + L.pw_2, pw_tiles(D), 0, D, D, fc2_w, D, 1);
+  jobs[nj++] = orca_copy_pad_job(blob + L.b_2, fc2_b, D, 112);
+  jobs[nj++] = orca_copy_pad_job(blob + L.ln_w, ln_w, D, 112);
+  jobs[nj++] = orca_copy_pad_job(blob + L.ln_b, ln_b, D, 112);
+  rc |= orca_pack_group(jobs, nj, s);
   if (rc != ORCA_OK) {
     orca_set_error("orca_tgat_pack: kernel launch failed");
     return ORCA_EHIP;
@@ -257,11 +309,13 @@ ORCA_API int orca_tgat_pack_gather(int d_e, const float* q_w, const float* k_w, 
   hipError_t e0 = hipMemsetAsync(blob + L.b_qk, 0, sizeof(float) * 2 * L.KP, s);
   k_fold_qt<<<1, 256, 0, s>>>(q_w, in_b, time_b, t);
   k_fold_qk<<<(2 * (kdim + 1) * (D + 1) + 255) / 256, 256, 0, s>>>(q_w, k_w, in_b, t, kdim, L.KP, A, blob + L.b_qk);
-  for (int h = 0; h < 2; ++h)
-    rc |= orca_pack_matrix(blob + L.pw_qk + (int64_t)h * pw_floats(kdim + 1, D), L.NTk, pw_tiles(D), 0, kdim + 1, D,
-                           A + (int64_t)h * (kdim + 1) * D, D, 1, s, true);
-  k_set_flag<<<1, 1, 0, s>>>(blob + L.qk_flag);
   if (hipGetLastError() != hipSuccess) rc = ORCA_EHIP;
+  OrcaPackJob jobs[3];
+  for (int h = 0; h < 2; ++h)
+    jobs[h] = orca_pack_job(blob + L.pw_qk + (int64_t)h * pw_floats(kdim + 1, D), pw_tiles(D), 0, kdim + 1, D,
+                            A + (int64_t)h * (kdim + 1) * D, D, 1, true);
+  jobs[2] = orca_flag_job(blob + L.qk_flag);
+  rc |= orca_pack_group(jobs, 3, s);
   ORCA_HIP_TRY(e0);
   if (rc != ORCA_OK) {
     orca_set_error("orca_tgat_pack_gather: kernel launch failed");

@@ -21,7 +21,7 @@ constexpr int MAXC = (QD + ORCA_MAX_DE + 63) / 64;   // key columns per lane
 // C(m,n) = alpha * (sum_k A(m,k) B(k,n) + bias[n]) [+ C(m,n)] [relu];  X(i,j) = X[i*s0 + j*s1].
 // With part != NULL block z writes its raw partial sums of k in [z*kchunk, (z+1)*kchunk) to part[z][m][n].
 struct GemmArgs {
-  int M, N, K;
+  int M, N, K;             // N counts the virtual ones column when ones_out is set
   const float* A; int64_t sam, sak;
   const float* B; int64_t sbk, sbn;
   float* C; int64_t scm, scn;
@@ -29,19 +29,53 @@ struct GemmArgs {
   float alpha;
   int accumulate, relu, kchunk;
   float* part;
+  const float* gate;
+  const float* rowzero;
+  int rowzero_n;
+  float* ones_out;
+  int gx, gy, gz;          // tiles along n, m and k
 };
+struct GemmGroup {
+  int n;
+  int first[ORCA_GEMM_GROUP_MAX + 1];   // first block of each problem (GEMM launch) / first 256-element block (sums)
+  GemmArgs g[ORCA_GEMM_GROUP_MAX];
+};
+
+__device__ __forceinline__ void gemm_store(const GemmArgs& g, int m, int n, float acc) {
+  const int Nr = g.ones_out ? g.N - 1 : g.N;      // real columns
+  if (n == Nr) {                                  // the ones column: a bias gradient
+    const float v = g.alpha * acc;
+    g.ones_out[m] = g.accumulate ? g.ones_out[m] + v : v;
+    return;
+  }
+  float v = g.alpha * (acc + (g.bias ? g.bias[n] : 0.f));
+  float* c = g.C + (int64_t)m * g.scm + (int64_t)n * g.scn;
+  if (g.accumulate) v += *c;
+  if (g.relu) v = fmaxf(v, 0.f);
+  if (g.gate && !(g.gate[(int64_t)m * g.scm + (int64_t)n * g.scn] > 0.f)) v = 0.f;
+  if (g.rowzero && n < g.rowzero_n && g.rowzero[m] != 0.f) v = 0.f;
+  *c = v;
+}
 
 // TM = rows of the block tile (64, or 32 when the grid would otherwise leave CUs idle); the tile is TM x 64, the
 // reduction advances 16 at a time and the next slab's global loads are in flight while the current one is multiplied.
 template <int TM>
-__global__ __launch_bounds__(256) void k_sgemm(GemmArgs g) {
+__global__ __launch_bounds__(256) void k_sgemm(GemmGroup grp) {
   constexpr int IM = TM / 32;          // 16-row MFMA tiles per wave along m
   constexpr int EA = TM / 16;          // A elements per thread and slab
   __shared__ float As[16][TM + 4], Bs[16][68];
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < ORCA_GEMM_GROUP_MAX; ++i) p += (i < grp.n && (int)blockIdx.x >= grp.first[i]) ? 1 : 0;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const GemmArgs g = grp.g[p];
+  const int local = (int)blockIdx.x - grp.first[p];
+  const int bx = local % g.gx, by = (local / g.gx) % g.gy, bz = local / (g.gx * g.gy);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 64;
-  const int kbeg = blockIdx.z * g.kchunk;
+  const int m0 = by * TM, n0 = bx * 64;
+  const int kbeg = bz * g.kchunk;
   const int kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
+  const int Nr = g.ones_out ? g.N - 1 : g.N;
   const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * 32;
   f32x4 acc[IM][2];
 #pragma unroll
@@ -63,7 +97,12 @@ __global__ __launch_bounds__(256) void k_sgemm(GemmArgs g) {
       const int idx = t + 256 * e;
       int n, kk;
       if (b_nfast) { n = idx & 63; kk = idx >> 6; } else { kk = idx & 15; n = idx >> 4; }
-      rb[e] = (n0 + n < g.N && k0 + kk < kend) ? g.B[(int64_t)(k0 + kk) * g.sbk + (int64_t)(n0 + n) * g.sbn] : 0.f;
+      float v = 0.f;
+      if (k0 + kk < kend) {
+        if (n0 + n < Nr) v = g.B[(int64_t)(k0 + kk) * g.sbk + (int64_t)(n0 + n) * g.sbn];
+        else if (n0 + n < g.N) v = 1.f;
+      }
+      rb[e] = v;
     }
   };
   if (kbeg < kend) fetch(kbeg);
@@ -107,32 +146,30 @@ __global__ __launch_bounds__(256) void k_sgemm(GemmArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + i * 16 + 4 * (lane >> 4) + r, n = n0 + wn + j * 16 + (lane & 15);
         if (m >= g.M || n >= g.N) continue;
-        if (g.part) {
-          g.part[((int64_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
-        } else {
-          float v = g.alpha * (acc[i][j][r] + (g.bias ? g.bias[n] : 0.f));
-          float* c = g.C + (int64_t)m * g.scm + (int64_t)n * g.scn;
-          if (g.accumulate) v += *c;
-          *c = g.relu ? fmaxf(v, 0.f) : v;
-        }
+        if (g.part) g.part[((int64_t)bz * g.M + m) * g.N + n] = acc[i][j][r];
+        else gemm_store(g, m, n, acc[i][j][r]);
       }
 }
 
-__global__ void k_splitk_reduce(const float* __restrict__ part, int S, int M, int N, float* C, int64_t scm, int64_t scn,
-                                float alpha, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)M * N) return;
-  // S <= ORCA_GEMM_SPLITS partials, clamped and masked instead of skipped: no control flow, so every load is in
+// the split-K sums of every problem of a group that has them
+__global__ __launch_bounds__(256) void k_splitk_reduce(GemmGroup grp) {
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < ORCA_GEMM_GROUP_MAX; ++i) p += (i < grp.n && (int)blockIdx.x >= grp.first[i]) ? 1 : 0;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const GemmArgs g = grp.g[p];
+  const int64_t i = (int64_t)((int)blockIdx.x - grp.first[p]) * 256 + threadIdx.x;
+  const int64_t MN = (int64_t)g.M * g.N;
+  if (i >= MN) return;
+  // at most ORCA_GEMM_SPLITS partials, clamped and masked instead of skipped: no control flow, so every load is in
   // flight before the first use (a loop pays one memory round trip per iteration); fixed order: deterministic
   float v = 0.f;
 #pragma unroll
   for (int z = 0; z < ORCA_GEMM_SPLITS; ++z) {
-    const float x = part[(int64_t)(z < S ? z : 0) * M * N + i];
-    v += z < S ? x : 0.f;
+    const float x = g.part[(int64_t)(z < g.gz ? z : 0) * MN + i];
+    v += z < g.gz ? x : 0.f;
   }
-  float* c = C + (i / N) * scm + (i % N) * scn;
-  v *= alpha;
-  *c = accumulate ? *c + v : v;
+  gemm_store(g, (int)(i / g.N), (int)(i % g.N), v);
 }
 
 // out[n] (+)= alpha * sum_q X[q*ld + n], n < ncols, in two branch-free passes (a loop over rows pays a full memory
@@ -175,32 +212,87 @@ __global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__
   if (z == 0) out[c] = accumulate ? out[c] + alpha * v : alpha * v;
 }
 
+int group_splits(const OrcaGemm& p) {
+  if (p.splits <= 1 || p.K <= 64) return 1;
+  const int sp = p.splits > ORCA_GEMM_SPLITS ? ORCA_GEMM_SPLITS : p.splits;
+  int kc = (p.K + sp - 1) / sp;
+  kc = (kc + 15) / 16 * 16;
+  return (p.K + kc - 1) / kc;
+}
+
 }  // namespace
+
+int64_t orca_sgemm_group_part_floats(const OrcaGemm* g, int n) {
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    const int gz = group_splits(g[i]);
+    if (gz > 1) total += ((int64_t)gz * g[i].M * (g[i].N + (g[i].ones_out ? 1 : 0)) + 63) / 64 * 64;
+  }
+  return total;
+}
+
+int orca_sgemm_group(hipStream_t s, const OrcaGemm* in, int n, float* part) {
+  if (n <= 0) return ORCA_OK;
+  if (n > ORCA_GEMM_GROUP_MAX) return ORCA_EINVAL;
+  GemmGroup grp{};
+  int64_t tiles64 = 0;
+  int np = 0;
+  bool any_split = false;
+  int64_t po = 0;
+  for (int i = 0; i < n; ++i) {
+    const OrcaGemm& p = in[i];
+    if (p.M <= 0 || p.N <= 0) continue;
+    GemmArgs& g = grp.g[np++];
+    g = GemmArgs{p.M, p.N + (p.ones_out ? 1 : 0), p.K, p.A, p.sam, p.sak, p.B, p.sbk, p.sbn, p.C, p.scm, p.scn, p.bias, p.alpha,
+                 p.accumulate, p.relu, p.K < 16 ? 16 : p.K, nullptr, p.gate, p.rowzero, p.rowzero_n, p.ones_out, 0, 0, 1};
+    g.gz = group_splits(p);
+    if (g.gz > 1) {
+      if (!part || p.bias || p.relu || p.gate || p.rowzero) return ORCA_EINVAL;
+      const int sp = p.splits > ORCA_GEMM_SPLITS ? ORCA_GEMM_SPLITS : p.splits;
+      int kc = (p.K + sp - 1) / sp;
+      g.kchunk = (kc + 15) / 16 * 16;
+      g.part = part + po;
+      po += ((int64_t)g.gz * g.M * g.N + 63) / 64 * 64;
+      any_split = true;
+    }
+    g.gx = (g.N + 63) / 64;
+    tiles64 += (int64_t)g.gx * ((g.M + 63) / 64) * g.gz;
+  }
+  if (np == 0) return ORCA_OK;
+  grp.n = np;
+  const bool small = tiles64 < 512;     // under two blocks per CU: halve the tile, double the blocks
+  const int TM = small ? 32 : 64;
+  int first = 0;
+  for (int i = 0; i < np; ++i) {
+    grp.first[i] = first;
+    grp.g[i].gy = (grp.g[i].M + TM - 1) / TM;
+    first += grp.g[i].gx * grp.g[i].gy * grp.g[i].gz;
+  }
+  grp.first[np] = first;
+  if (small) k_sgemm<32><<<(unsigned)first, 256, 0, s>>>(grp);
+  else k_sgemm<64><<<(unsigned)first, 256, 0, s>>>(grp);
+  if (any_split) {
+    GemmGroup red{};
+    int nr = 0, fb = 0;
+    for (int i = 0; i < np; ++i) {
+      if (grp.g[i].gz <= 1) continue;
+      red.g[nr] = grp.g[i];
+      red.first[nr++] = fb;
+      fb += (int)(((int64_t)grp.g[i].M * grp.g[i].N + 255) / 256);
+    }
+    red.n = nr;
+    red.first[nr] = fb;
+    k_splitk_reduce<<<(unsigned)fb, 256, 0, s>>>(red);
+  }
+  return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
+}
 
 int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
                int64_t sbn, float* C, int64_t scm, int64_t scn, const float* bias, float alpha, bool accumulate, bool relu,
                float* part, int splits) {
-  if (M <= 0 || N <= 0) return ORCA_OK;
-  GemmArgs g{M, N, K, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, alpha, accumulate ? 1 : 0, relu ? 1 : 0, K, nullptr};
-  unsigned gz = 1;
-  if (splits > ORCA_GEMM_SPLITS) splits = ORCA_GEMM_SPLITS;   // k_splitk_reduce sums at most that many
-  if (part && splits > 1 && K > 64) {
-    int kc = (K + splits - 1) / splits;
-    kc = (kc + 15) / 16 * 16;
-    g.kchunk = kc;
-    gz = (unsigned)((K + kc - 1) / kc);
-    g.part = part;
-  }
-  if (g.kchunk < 16) g.kchunk = 16;
-  const unsigned gx = (unsigned)((N + 63) / 64);
-  if ((int64_t)gx * ((M + 63) / 64) * gz < 512)      // under two blocks per CU: halve the tile, double the blocks
-    k_sgemm<32><<<dim3(gx, (unsigned)((M + 31) / 32), gz), 256, 0, s>>>(g);
-  else
-    k_sgemm<64><<<dim3(gx, (unsigned)((M + 63) / 64), gz), 256, 0, s>>>(g);
-  if (g.part)
-    k_splitk_reduce<<<(unsigned)ceil_div64((int64_t)M * N, 256), 256, 0, s>>>(part, (int)gz, M, N, C, scm, scn, alpha,
-                                                                            accumulate ? 1 : 0);
-  return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
+  OrcaGemm g{M, N, K, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, alpha, accumulate ? 1 : 0, relu ? 1 : 0, nullptr, nullptr, 0,
+             nullptr, part ? splits : 1};
+  return orca_sgemm_group(s, &g, 1, part);
 }
 
 int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate,
@@ -375,19 +467,6 @@ __global__ __launch_bounds__(256) void k_bias_scale_bwd(const float* __restrict_
     if (lane == 0) dsum[q * 2 + h] = acc;
   }
 }
-// rows of an invalid query are zeroed in X[q*ld .. +n)
-__global__ void k_zero_invalid(float* __restrict__ X, int64_t Q, int64_t ld, int n, const float* __restrict__ invalid) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Q * n) return;
-  const int64_t q = i / n;
-  if (invalid[q] != 0.f) X[q * ld + i % n] = 0.f;
-}
-// d[i] = h[i] > 0 ? d[i] : 0   (ReLU backward through the kept activation)
-__global__ void k_relu_bwd(float* __restrict__ d, const float* __restrict__ h, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && !(h[i] > 0.f)) d[i] = 0.f;
-}
-
 // LayerNorm backward (eps 1e-5, biased variance): dy from g = dL/dout, gx = g * xhat for the affine gradients
 __global__ __launch_bounds__(256) void k_bwd_ln(const float* __restrict__ y, const float* __restrict__ g,
                                                 const float* __restrict__ gamma, int64_t Q, float* __restrict__ dy,
@@ -525,9 +604,10 @@ __global__ void k_bwd_finish(orca_tgat_inputs in, int64_t Q, const float* __rest
 }
 
 struct Ws {   // float offsets of the per-query rows inside the workspace
-  int64_t xq, qs, qt, a, xbar, ocat, x1, h1, y, dy, gx, dh1, dx1, docat, dxbar, dqt, dq, dxq, tgrad, invalid, wsum, dsum, part, total;
+  int64_t xq, qs, qt, a, xbar, ocat, x1, h1, y, dy, gx, dh1, dx1, docat, dxbar, dqt, dq, dxq, tgrad, invalid, wsum, dsum, scaled,
+      part, total;
 };
-constexpr int SPLITS = ORCA_GEMM_SPLITS;
+constexpr int SPLITS = 16;      // split-K pieces of the weight-gradient GEMMs (all of a layer's in one launch)
 Ws ws_layout(int d_e, int64_t Q, int K) {
   const int64_t kdim = QD + d_e;
   Ws w{};
@@ -537,8 +617,11 @@ Ws ws_layout(int d_e, int64_t Q, int K) {
   w.ocat = take(QD); w.x1 = take(3 * D); w.h1 = take(D); w.y = take(D); w.dy = take(D); w.gx = take(D);
   w.dh1 = take(D); w.dx1 = take(3 * D); w.docat = take(QD); w.dxbar = take(2 * kdim); w.dqt = take(2 * kdim);
   w.dq = take(QD); w.dxq = take(QD); w.tgrad = take(QD); w.invalid = take(1); w.wsum = take(2); w.dsum = take(2);
+  w.scaled = take(QD);
   w.part = o;
-  o += (int64_t)SPLITS * QD * (kdim > 3 * D ? kdim : 3 * D);
+  // the eight weight-gradient problems with their bias columns (each rounded up to 64 floats), or a column sum's slices
+  o += (int64_t)SPLITS * ((int64_t)D * (D + 1) + (int64_t)D * (3 * D + 1) + 2 * (int64_t)QD * (QD + 1) + 4 * (int64_t)D * (kdim + 1)) + 64 * 8
+       + 64 * QD;
   w.total = o;
   return w;
 }
@@ -587,70 +670,100 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
   int rc = ORCA_OK;
   auto ew = [&](int64_t n) { return (unsigned)ceil_div64(n, 256); };
 
+  float* scaled = W + w.scaled;
+  auto G1 = [&](int M_, int N_, int K_, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                float* C, int64_t scm, int64_t scn, const float* bias, float alpha) {
+    return OrcaGemm{M_, N_, K_, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, alpha, 0, 0, nullptr, nullptr, 0, nullptr, 1};
+  };
   // ---- forward recompute -------------------------------------------------------------------------------
   k_bwd_prep<<<qb, 256, 0, s>>>(*in, Q, xq, x1);
   // qs = 0.1 (xq Wq^T + bq)                                                    (scaling: head_dim^-0.5)
   rc |= sgemm(s, M, QD, QD, xq, QD, 1, P->q_w, 1, QD, qs, QD, 1, P->in_b, 0.1f, false, false);
-  for (int h = 0; h < 2; ++h)   // q~_h = qs_h Wk_h   [Q,100] x [100,kdim]
-    rc |= sgemm(s, M, kdim, D, qs + h * D, QD, 1, P->k_w + (int64_t)h * D * kdim, kdim, 1, qt + h * kdim, 2 * kdim, 1,
-                nullptr, 1.f, false, false);
+  {   // q~_h = qs_h Wk_h   [Q,100] x [100,kdim], both heads in one launch
+    OrcaGemm g[2];
+    for (int h = 0; h < 2; ++h)
+      g[h] = G1(M, kdim, D, qs + h * D, QD, 1, P->k_w + (int64_t)h * D * kdim, kdim, 1, qt + h * kdim, 2 * kdim, 1, nullptr, 1.f);
+    rc |= orca_sgemm_group(s, g, 2, nullptr);
+  }
   k_bwd_attn_fwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
-  for (int h = 0; h < 2; ++h)   // ocat_h = xbar_h Wv_h^T + bv_h  (dropout: + (sum of the head's kept weights) bv_h)
-    rc |= sgemm(s, M, D, kdim, xbar + h * kdim, 2 * kdim, 1, P->v_w + (int64_t)h * D * kdim, 1, kdim, ocat + h * D, QD, 1,
-                drop ? nullptr : P->in_b + 2 * QD + h * D, 1.f, false, false);
+  {   // ocat_h = xbar_h Wv_h^T + bv_h  (dropout: + (sum of the head's kept weights) bv_h)
+    OrcaGemm g[2];
+    for (int h = 0; h < 2; ++h)
+      g[h] = G1(M, D, kdim, xbar + h * kdim, 2 * kdim, 1, P->v_w + (int64_t)h * D * kdim, 1, kdim, ocat + h * D, QD, 1,
+                drop ? nullptr : P->in_b + 2 * QD + h * D, 1.f);
+    rc |= orca_sgemm_group(s, g, 2, nullptr);
+  }
   if (drop) k_add_scaled_bias<<<ew(Q * QD), 256, 0, s>>>(ocat, Q, wsum, P->in_b + 2 * QD);
-  // o = ocat Wo^T + bo -> x1[:, 0:200], zero for invalid queries                 (temporal_attention.py:52)
-  rc |= sgemm(s, M, QD, QD, ocat, QD, 1, P->o_w, 1, QD, x1, 3 * D, 1, P->o_b, 1.f, false, false);
-  k_zero_invalid<<<ew(Q * QD), 256, 0, s>>>(x1, Q, 3 * D, QD, invalid);
+  {   // o = ocat Wo^T + bo -> x1[:, 0:200], zero for invalid queries                 (temporal_attention.py:52)
+    OrcaGemm g = G1(M, QD, QD, ocat, QD, 1, P->o_w, 1, QD, x1, 3 * D, 1, P->o_b, 1.f);
+    g.rowzero = invalid;
+    g.rowzero_n = QD;
+    rc |= orca_sgemm_group(s, &g, 1, nullptr);
+  }
   // h1 = relu(x1 W1^T + b1), y = h1 W2^T + b2                                     (utils/util.py:22-24)
   rc |= sgemm(s, M, D, 3 * D, x1, 3 * D, 1, P->fc1_w, 1, 3 * D, h1, D, 1, P->fc1_b, 1.f, false, true);
   rc |= sgemm(s, M, D, D, h1, D, 1, P->fc2_w, 1, D, y, D, 1, P->fc2_b, 1.f, false, false);
 
-  // ---- backward ----------------------------------------------------------------------------------------
+  // ---- backward: the data gradients, a chain ------------------------------------------------------------
   k_bwd_ln<<<qb, 256, 0, s>>>(y, grad_out, P->ln_w, Q, dy, gx);
   rc |= colsum(s, gx, Q, D, D, G->ln_w, 1.f, true, part);
   rc |= colsum(s, grad_out, Q, D, D, G->ln_b, 1.f, true, part);
-  // fc2: dW2 += dy^T h1, db2 += sum dy, dh1 = dy W2
-  rc |= sgemm(s, D, D, M, dy, 1, D, h1, D, 1, G->fc2_w, D, 1, nullptr, 1.f, true, false, part, SPLITS);
-  rc |= colsum(s, dy, Q, D, D, G->fc2_b, 1.f, true, part);
-  rc |= sgemm(s, M, D, D, dy, D, 1, P->fc2_w, D, 1, dh1, D, 1, nullptr, 1.f, false, false);
-  k_relu_bwd<<<ew(Q * D), 256, 0, s>>>(dh1, h1, Q * D);
-  // fc1: dW1 += dz1^T x1, db1 += sum dz1, dx1 = dz1 W1
-  rc |= sgemm(s, D, 3 * D, M, dh1, 1, D, x1, 3 * D, 1, G->fc1_w, 3 * D, 1, nullptr, 1.f, true, false, part, SPLITS);
-  rc |= colsum(s, dh1, Q, D, D, G->fc1_b, 1.f, true, part);
-  rc |= sgemm(s, M, 3 * D, D, dh1, D, 1, P->fc1_w, 3 * D, 1, dx1, 3 * D, 1, nullptr, 1.f, false, false);
-  k_zero_invalid<<<ew(Q * QD), 256, 0, s>>>(dx1, Q, 3 * D, QD, invalid);     // do = 0 where the output was zeroed
-  // out-proj: dWo += do^T ocat, dbo += sum do, docat = do Wo
-  rc |= sgemm(s, QD, QD, M, dx1, 1, 3 * D, ocat, QD, 1, G->o_w, QD, 1, nullptr, 1.f, true, false, part, SPLITS);
-  rc |= colsum(s, dx1, Q, 3 * D, QD, G->o_b, 1.f, true, part);
-  rc |= sgemm(s, M, QD, QD, dx1, 3 * D, 1, P->o_w, QD, 1, docat, QD, 1, nullptr, 1.f, false, false);
-  // value map: dWv_h += docat_h^T xbar_h, dbv += sum docat, dxbar_h = docat_h Wv_h
-  if (drop) {     // ocat is dead from here on: it takes docat scaled by the weight sums
-    k_bias_scale_bwd<<<qb, 256, 0, s>>>(docat, Q, wsum, P->in_b + 2 * QD, ocat, dsum);
-    rc |= colsum(s, ocat, Q, QD, QD, G->in_b + 2 * QD, 1.f, true, part);
-  } else {
-    rc |= colsum(s, docat, Q, QD, QD, G->in_b + 2 * QD, 1.f, true, part);
+  {   // fc2: dz1 = (dy W2) where h1 > 0
+    OrcaGemm g = G1(M, D, D, dy, D, 1, P->fc2_w, D, 1, dh1, D, 1, nullptr, 1.f);
+    g.gate = h1;
+    rc |= orca_sgemm_group(s, &g, 1, nullptr);
   }
-  for (int h = 0; h < 2; ++h) {
-    rc |= sgemm(s, D, kdim, M, docat + h * D, 1, QD, xbar + h * kdim, 2 * kdim, 1, G->v_w + (int64_t)h * D * kdim, kdim, 1,
-                nullptr, 1.f, true, false, part, SPLITS);
-    rc |= sgemm(s, M, kdim, D, docat + h * D, QD, 1, P->v_w + (int64_t)h * D * kdim, kdim, 1, dxbar + h * kdim, 2 * kdim, 1,
-                nullptr, 1.f, false, false);
+  {   // fc1: dx1 = dz1 W1; do = dx1[:, 0:200] = 0 where the output was zeroed
+    OrcaGemm g = G1(M, 3 * D, D, dh1, D, 1, P->fc1_w, 3 * D, 1, dx1, 3 * D, 1, nullptr, 1.f);
+    g.rowzero = invalid;
+    g.rowzero_n = QD;
+    rc |= orca_sgemm_group(s, &g, 1, nullptr);
+  }
+  // out-proj: docat = do Wo
+  rc |= sgemm(s, M, QD, QD, dx1, 3 * D, 1, P->o_w, QD, 1, docat, QD, 1, nullptr, 1.f, false, false);
+  if (drop)       // docat scaled by the weight sums (the bv gradient's summand), dsum = docat_h . bv_h
+    k_bias_scale_bwd<<<qb, 256, 0, s>>>(docat, Q, wsum, P->in_b + 2 * QD, scaled, dsum);
+  {   // value map: dxbar_h = docat_h Wv_h
+    OrcaGemm g[2];
+    for (int h = 0; h < 2; ++h)
+      g[h] = G1(M, kdim, D, docat + h * D, QD, 1, P->v_w + (int64_t)h * D * kdim, kdim, 1, dxbar + h * kdim, 2 * kdim, 1, nullptr, 1.f);
+    rc |= orca_sgemm_group(s, g, 2, nullptr);
   }
   const bool want_t = in->dt && d_time_w;
   k_bwd_attn_bwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
-  // key fold: dWk_h += qs_h^T dq~_h, dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs   (the bk gradient is zero: softmax is shift-invariant)
-  for (int h = 0; h < 2; ++h) {
-    rc |= sgemm(s, D, kdim, M, qs + h * D, 1, QD, dqt + h * kdim, 2 * kdim, 1, G->k_w + (int64_t)h * D * kdim, kdim, 1,
-                nullptr, 1.f, true, false, part, SPLITS);
-    rc |= sgemm(s, M, D, kdim, dqt + h * kdim, 2 * kdim, 1, P->k_w + (int64_t)h * D * kdim, 1, kdim, dq + h * D, QD, 1,
-                nullptr, 0.1f, false, false);
+  {   // key fold: dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs
+    OrcaGemm g[2];
+    for (int h = 0; h < 2; ++h)
+      g[h] = G1(M, D, kdim, dqt + h * kdim, 2 * kdim, 1, P->k_w + (int64_t)h * D * kdim, 1, kdim, dq + h * D, QD, 1, nullptr, 0.1f);
+    rc |= orca_sgemm_group(s, g, 2, nullptr);
   }
-  // q projection: dWq += dq^T xq, dbq += sum dq, dxq = dq Wq
-  rc |= sgemm(s, QD, QD, M, dq, 1, QD, xq, QD, 1, G->q_w, QD, 1, nullptr, 1.f, true, false, part, SPLITS);
-  rc |= colsum(s, dq, Q, QD, QD, G->in_b, 1.f, true, part);
+  // q projection: dxq = dq Wq
   rc |= sgemm(s, M, QD, QD, dq, QD, 1, P->q_w, QD, 1, dxq, QD, 1, nullptr, 1.f, false, false);
   k_bwd_finish<<<ew(Q * D), 256, 0, s>>>(*in, Q, dx1, dxq, d_src, d_src_time, want_t ? tgrad : nullptr);
+  // ---- backward: every weight gradient (a reduction over the queries) in ONE split-K launch, the bias gradients as a
+  // column of ones:  dW2 += dy^T h1, dW1 += dz1^T x1, dWo += do^T ocat, dWv_h += docat_h^T xbar_h, dWk_h += qs_h^T dq~_h
+  // (the bk gradient is zero: softmax is shift-invariant), dWq += dq^T xq
+  {
+    OrcaGemm g[8];
+    auto GW = [&](int M_, int N_, const float* A, int64_t sak, const float* B, int64_t sbk, float* C, float* bias_grad) {
+      OrcaGemm r = G1(M_, N_, M, A, 1, sak, B, sbk, 1, C, N_, 1, nullptr, 1.f);
+      r.accumulate = 1;
+      r.ones_out = bias_grad;
+      r.splits = SPLITS;
+      return r;
+    };
+    g[0] = GW(D, D, dy, D, h1, D, G->fc2_w, G->fc2_b);
+    g[1] = GW(D, 3 * D, dh1, D, x1, 3 * D, G->fc1_w, G->fc1_b);
+    g[2] = GW(QD, QD, dx1, 3 * D, ocat, QD, G->o_w, G->o_b);
+    for (int h = 0; h < 2; ++h) {
+      g[3 + h] = GW(D, kdim, docat + h * D, QD, xbar + h * kdim, 2 * kdim, G->v_w + (int64_t)h * D * kdim,
+                    drop ? nullptr : G->in_b + 2 * QD + h * D);
+      g[5 + h] = GW(D, kdim, qs + h * D, QD, dqt + h * kdim, 2 * kdim, G->k_w + (int64_t)h * D * kdim, nullptr);
+    }
+    g[7] = GW(QD, QD, dq, QD, xq, QD, G->q_w, G->in_b);
+    rc |= orca_sgemm_group(s, g, 8, part);
+  }
+  if (drop) rc |= colsum(s, scaled, Q, QD, QD, G->in_b + 2 * QD, 1.f, true, part);
   if (want_t) {
     rc |= colsum(s, tgrad, Q, QD, D, d_time_w, 1.f, true, part);
     rc |= colsum(s, tgrad + D, Q, QD, D, d_time_b, 1.f, true, part);

@@ -678,6 +678,7 @@ class OrcaEngine:
     if self.reuse:                                       # embedding_module.py:154-182
       nbr, eid, dt = self._sample(my_nodes, t3[lo:hi], q0=lo)
       self._overlay_updated_memory(nbr, my_nodes)
+      cnt_ready = self._fetch_count()
       my32 = my_nodes.to(torch.int32)
       dk = self._dropout_kw(1, lo)
       emb = self._attend(1, n, nbr, eid, dt, True, self.memory, my32, self.memory, nbr, True, drop=dk)
@@ -698,6 +699,7 @@ class OrcaEngine:
         f_nodes.append(torch.cat([f_nodes[-1], smp[0].flatten().to(torch.int64)]))
         f_ts.append(torch.cat([f_ts[-1], f_ts[-1].repeat_interleave(K)]))
       self._overlay_updated_memory(None, f_nodes[-1])
+      cnt_ready = self._fetch_count()
       emb = None
       for layer in range(1, self.L + 1):
         lvl = self.L - layer
@@ -751,7 +753,8 @@ class OrcaEngine:
         into_memory = (sink, d_src, d_nbr)
     # ---- into the updated-memory rows of the pending ids this slice read, then through the GRU ----
     p = "memory_updater.memory_updater."
-    cnt = int(self.count.item())           # distinct pending ids of the overlay work-list (set by the forward)
+    cnt_ready.synchronize()                # distinct pending ids of the overlay work-list: the copy was enqueued right
+    cnt = int(self._count_host[0])         # after the forward set it, so this wait does not drain the queue
     if cnt:
       if getattr(self, "_pos", None) is None:
         self._pos = torch.zeros(self.N, dtype=torch.int32, device=dev)
@@ -787,6 +790,15 @@ class OrcaEngine:
     ops.message_store(src, dst, eidx, ts, self.memory, self.last_update, self.edge_feats, self.time_w, self.time_b,
                       self.slot, self._slot_epoch(2 * bs), self.messages, self.msg_ts, self.pending)
     return loss.detach(), grads
+
+  def _fetch_count(self):
+    """starts the copy of the work-list count to pinned host memory; the returned event completes with it"""
+    if getattr(self, "_count_host", None) is None:
+      self._count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    self._count_host.copy_(self.count, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
 
   def optimizer(self, lr=1e-4):
     """torch.optim.Adam over the raw parameter tensors (train.py:180): the optimizer updates self.params in place;
