@@ -254,9 +254,12 @@ constexpr int ORCA_GEMM_GROUP_MAX = 8;
 int64_t orca_sgemm_group_part_floats(const OrcaGemm* g, int n);
 int orca_sgemm_group(hipStream_t s, const OrcaGemm* g, int n, float* part);
 // out[n] (+)= alpha * sum_q X[q*ld + n], n < ncols
-// (part: scratch of 64 * ncols floats)
+// (ncols <= 320; part: scratch of 64 * 320 floats)
 int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate,
                 float* part);
+// up to four such sums (each of at most 320 columns) over the same Q rows in one launch pair; part: 4 * 64 * 320 floats
+int orca_colsum_group(hipStream_t s, int n, const float* const* X, const int64_t* ld, const int* ncols, float* const* out,
+                      int64_t Q, float alpha, bool accumulate, float* part);
 
 // generic strided pack kernel launcher (tgat.hip)
 int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd, const float* src,

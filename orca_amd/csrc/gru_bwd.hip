@@ -42,9 +42,11 @@ __global__ void k_gru_gates_bwd(float* __restrict__ gi, float* __restrict__ gh, 
 }
 }  // namespace
 
+namespace { constexpr int GRU_SPLITS = 16; }   // split-K pieces of the two weight-gradient GEMMs (one launch)
+
 ORCA_API int64_t orca_gru_backward_workspace_floats(int msg_dim, int64_t n) {
   if (msg_dim < 1 || msg_dim > 3 * ORCA_D + ORCA_MAX_DE || n < 0) return -1;
-  return n * (msg_dim + D + 2 * G3) + 256 + (int64_t)ORCA_GEMM_SPLITS * G3 * (msg_dim > D ? msg_dim : D);
+  return n * (msg_dim + D + 2 * G3) + 256 + (int64_t)GRU_SPLITS * G3 * (msg_dim + 1 + D + 1) + 128;
 }
 
 ORCA_API int orca_gru_backward(int msg_dim, const float* weight_ih, const float* weight_hh, const float* bias_ih,
@@ -69,17 +71,31 @@ ORCA_API int orca_gru_backward(int msg_dim, const float* weight_ih, const float*
   k_gather_wide<<<ew(n * msg_dim), 256, 0, s>>>(x, ids, n, msg_dim, xg);
   k_gather_wide<<<ew(n * D), 256, 0, s>>>(h, ids, n, D, hg);
   int rc = ORCA_OK;
-  rc |= orca_sgemm(s, M, G3, msg_dim, xg, msg_dim, 1, weight_ih, 1, msg_dim, gi, G3, 1, bias_ih, 1.f, false, false);
-  rc |= orca_sgemm(s, M, G3, D, hg, D, 1, weight_hh, 1, D, gh, G3, 1, bias_hh, 1.f, false, false);
+  auto G1 = [&](int M_, int N_, int K_, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                float* C, int64_t scm, int64_t scn, const float* bias, int accumulate) {
+    return OrcaGemm{M_, N_, K_, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, 1.f, accumulate, 0, nullptr, nullptr, 0, nullptr, 1};
+  };
+  {   // gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh: one launch
+    OrcaGemm g[2] = {G1(M, G3, msg_dim, xg, msg_dim, 1, weight_ih, 1, msg_dim, gi, G3, 1, bias_ih, 0),
+                     G1(M, G3, D, hg, D, 1, weight_hh, 1, D, gh, G3, 1, bias_hh, 0)};
+    rc |= orca_sgemm_group(s, g, 2, nullptr);
+  }
   k_gru_gates_bwd<<<ew(n * D), 256, 0, s>>>(gi, gh, hg, d_out, n, d_h);
-  // weight_ih [300,msg] += dgi^T x;  weight_hh [300,100] += dgh^T h;  the biases: column sums
-  rc |= orca_sgemm(s, G3, msg_dim, M, gi, 1, G3, xg, msg_dim, 1, g_weight_ih, msg_dim, 1, nullptr, 1.f, true, false, part,
-                   ORCA_GEMM_SPLITS);
-  rc |= orca_sgemm(s, G3, D, M, gh, 1, G3, hg, D, 1, g_weight_hh, D, 1, nullptr, 1.f, true, false, part, ORCA_GEMM_SPLITS);
-  rc |= orca_colsum(s, gi, n, G3, G3, g_bias_ih, 1.f, true, part);
-  rc |= orca_colsum(s, gh, n, G3, G3, g_bias_hh, 1.f, true, part);
-  if (d_x) rc |= orca_sgemm(s, M, msg_dim, G3, gi, G3, 1, weight_ih, msg_dim, 1, d_x, msg_dim, 1, nullptr, 1.f, false, false);
-  if (d_h) rc |= orca_sgemm(s, M, D, G3, gh, G3, 1, weight_hh, D, 1, d_h, D, 1, nullptr, 1.f, true, false);
+  {   // weight_ih [300,msg] += dgi^T x;  weight_hh [300,100] += dgh^T h;  the biases as a column of ones: one launch
+    OrcaGemm g[2] = {G1(G3, msg_dim, M, gi, 1, G3, xg, msg_dim, 1, g_weight_ih, msg_dim, 1, nullptr, 1),
+                     G1(G3, D, M, gh, 1, G3, hg, D, 1, g_weight_hh, D, 1, nullptr, 1)};
+    g[0].ones_out = g_bias_ih;
+    g[1].ones_out = g_bias_hh;
+    g[0].splits = g[1].splits = GRU_SPLITS;
+    rc |= orca_sgemm_group(s, g, 2, part);
+  }
+  if (d_x || d_h) {
+    OrcaGemm g[2];
+    int ng = 0;
+    if (d_x) g[ng++] = G1(M, msg_dim, G3, gi, G3, 1, weight_ih, msg_dim, 1, d_x, msg_dim, 1, nullptr, 0);
+    if (d_h) g[ng++] = G1(M, D, G3, gh, G3, 1, weight_hh, D, 1, d_h, D, 1, nullptr, 1);
+    rc |= orca_sgemm_group(s, g, ng, nullptr);
+  }
   if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
     orca_set_error("orca_gru_backward: kernel launch failed");
     return ORCA_EHIP;

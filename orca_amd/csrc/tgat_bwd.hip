@@ -57,13 +57,17 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, int m, int n, floa
   *c = v;
 }
 
-// TM = rows of the block tile (64, or 32 when the grid would otherwise leave CUs idle); the tile is TM x 64, the
-// reduction advances 16 at a time and the next slab's global loads are in flight while the current one is multiplied.
+// TM = rows of the block tile (64, or 32 when the grid would otherwise leave CUs idle); the tile is TM x 64 and the
+// reduction advances GEMM_BK = 64 at a time, the next slab's global loads in flight while the current one is
+// multiplied.  These problems are small (a few hundred blocks of a few slabs): a block's time is its chain of
+// load -> LDS -> barrier round trips, so the slab is deep (16-deep slabs: 15 us per launch, 64-deep: see DESIGN).
+constexpr int GEMM_BK = 32;
 template <int TM>
 __global__ __launch_bounds__(256) void k_sgemm(GemmGroup grp) {
-  constexpr int IM = TM / 32;          // 16-row MFMA tiles per wave along m
-  constexpr int EA = TM / 16;          // A elements per thread and slab
-  __shared__ float As[16][TM + 4], Bs[16][68];
+  constexpr int IM = TM / 32;                  // 16-row MFMA tiles per wave along m
+  constexpr int EA = TM * GEMM_BK / 256;       // A elements per thread and slab
+  constexpr int EB = 64 * GEMM_BK / 256;       // B elements per thread and slab
+  __shared__ float As[GEMM_BK][TM + 4], Bs[GEMM_BK][68];
   int p = 0;
 #pragma unroll
   for (int i = 1; i < ORCA_GEMM_GROUP_MAX; ++i) p += (i < grp.n && (int)blockIdx.x >= grp.first[i]) ? 1 : 0;
@@ -83,48 +87,67 @@ __global__ __launch_bounds__(256) void k_sgemm(GemmGroup grp) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
-  float ra[EA], rb[4];
+  float ra[EA], rb[EB];
+  auto a_index = [&](int e, int& m, int& k) {
+    const int idx = t + 256 * e;
+    if (a_kfast) { m = idx / GEMM_BK; k = idx % GEMM_BK; } else { m = idx % TM; k = idx / TM; }
+  };
+  auto b_index = [&](int e, int& n, int& kk) {
+    const int idx = t + 256 * e;
+    if (b_nfast) { n = idx & 63; kk = idx >> 6; } else { kk = idx % GEMM_BK; n = idx / GEMM_BK; }
+  };
+  // running pointers and row / column masks: the 64-bit strided address of every element is computed once, not per slab
+  const float* pa[EA];
+  const float* pb[EB];
+  int ka[EA], kb[EB];        // k offset inside the slab; -1: the row / column is out of range (loads nothing)
+  int onesb = 0;             // bit e: element e of B lies in the virtual ones column
+#pragma unroll
+  for (int e = 0; e < EA; ++e) {
+    int m, k;
+    a_index(e, m, k);
+    ka[e] = m0 + m < g.M ? k : -1;
+    pa[e] = g.A + (int64_t)(m0 + m < g.M ? m0 + m : 0) * g.sam + (int64_t)(kbeg + k) * g.sak;
+  }
+#pragma unroll
+  for (int e = 0; e < EB; ++e) {
+    int n, kk;
+    b_index(e, n, kk);
+    kb[e] = n0 + n < g.N ? kk : -1;
+    if (n0 + n >= Nr && n0 + n < g.N) onesb |= 1 << e;
+    pb[e] = g.B + (int64_t)(kbeg + kk) * g.sbk + (int64_t)(n0 + n < Nr ? n0 + n : 0) * g.sbn;
+  }
+  const int64_t step_a = (int64_t)GEMM_BK * g.sak, step_b = (int64_t)GEMM_BK * g.sbk;
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
-      const int idx = t + 256 * e;
-      int m, k;
-      if (a_kfast) { m = idx >> 4; k = idx & 15; } else { m = idx % TM; k = idx / TM; }
-      ra[e] = (m0 + m < g.M && k0 + k < kend) ? g.A[(int64_t)(m0 + m) * g.sam + (int64_t)(k0 + k) * g.sak] : 0.f;
+      ra[e] = (ka[e] >= 0 && k0 + ka[e] < kend) ? *pa[e] : 0.f;
+      pa[e] += step_a;
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = t + 256 * e;
-      int n, kk;
-      if (b_nfast) { n = idx & 63; kk = idx >> 6; } else { kk = idx & 15; n = idx >> 4; }
-      float v = 0.f;
-      if (k0 + kk < kend) {
-        if (n0 + n < Nr) v = g.B[(int64_t)(k0 + kk) * g.sbk + (int64_t)(n0 + n) * g.sbn];
-        else if (n0 + n < g.N) v = 1.f;
-      }
-      rb[e] = v;
+    for (int e = 0; e < EB; ++e) {
+      const bool in = kb[e] >= 0 && k0 + kb[e] < kend;
+      rb[e] = in ? (((onesb >> e) & 1) ? 1.f : *pb[e]) : 0.f;
+      pb[e] += step_b;
     }
   };
   if (kbeg < kend) fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+  for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
-      const int idx = t + 256 * e;
       int m, k;
-      if (a_kfast) { m = idx >> 4; k = idx & 15; } else { m = idx % TM; k = idx / TM; }
+      a_index(e, m, k);
       As[k][m] = ra[e];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = t + 256 * e;
+    for (int e = 0; e < EB; ++e) {
       int n, kk;
-      if (b_nfast) { n = idx & 63; kk = idx >> 6; } else { kk = idx & 15; n = idx >> 4; }
+      b_index(e, n, kk);
       Bs[kk][n] = rb[e];
     }
     __syncthreads();
-    if (k0 + 16 < kend) fetch(k0 + 16);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    if (k0 + GEMM_BK < kend) fetch(k0 + GEMM_BK);
+    const int ksteps = (kend - k0 < GEMM_BK ? kend - k0 + 3 : GEMM_BK) / 4;     // rows past kend hold zeros: skip them
+    for (int kk = 0; kk < ksteps; ++kk) {
       const int kr = kk * 4 + (lane >> 4);
       float a[IM], b[2];
 #pragma unroll
@@ -176,9 +199,21 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmGroup grp) {
 // round trip per iteration): block (x, y) of k_colsum sums the rows q = y + 64 * (r + 16 u) of 64 columns, 16 row
 // lanes r with COLSUM_U loads each in flight, into part[y][n]; k_colsum_finish adds the 64 slices in a fixed order.
 constexpr int COLSUM_SLICES = 64, COLSUM_U = 8;     // one pass covers 64 * 16 * 8 = 8192 rows
-__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ X, int64_t Q, int64_t ld, int ncols,
-                                                 float* __restrict__ part) {
+constexpr int COLSUM_JOBS = 4, COLSUM_MAXC = 320;   // up to four sums of at most 320 columns in one launch pair
+struct ColsumJobs {
+  const float* X[COLSUM_JOBS];
+  int64_t ld[COLSUM_JOBS];
+  int ncols[COLSUM_JOBS];
+  float* out[COLSUM_JOBS];
+};
+__global__ __launch_bounds__(1024) void k_colsum(ColsumJobs jobs, int64_t Q, float* __restrict__ part_all) {
   __shared__ float red[16][64];
+  const int job = blockIdx.z;
+  const float* __restrict__ X = jobs.X[job];
+  const int64_t ld = jobs.ld[job];
+  const int ncols = jobs.ncols[job];
+  float* __restrict__ part = part_all + (int64_t)job * COLSUM_SLICES * COLSUM_MAXC;
+  if ((int)blockIdx.x * 64 >= ncols) return;
   const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, r = threadIdx.x >> 6;
   const int cc = c < ncols ? c : 0;
   float v = 0.f;
@@ -203,9 +238,13 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ X, in
   }
 }
 // one wave per column: lane z holds slice z, summed by a fixed butterfly (deterministic)
-__global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ part, int ncols, float* out, float alpha,
+__global__ __launch_bounds__(256) void k_colsum_finish(ColsumJobs jobs, const float* __restrict__ part_all, float alpha,
                                                        int accumulate) {
   static_assert(COLSUM_SLICES == 64, "one slice per lane");
+  const int job = blockIdx.y;
+  const int ncols = jobs.ncols[job];
+  float* out = jobs.out[job];
+  const float* __restrict__ part = part_all + (int64_t)job * COLSUM_SLICES * COLSUM_MAXC;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), z = threadIdx.x & 63;
   if (c >= ncols) return;
   const float v = wave_sum(part[(int64_t)z * ncols + c]);
@@ -295,12 +334,28 @@ int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, 
   return orca_sgemm_group(s, &g, 1, part);
 }
 
+// up to COLSUM_JOBS column sums over the same Q rows in one launch pair; part: COLSUM_JOBS * 64 * COLSUM_MAXC floats
+int orca_colsum_group(hipStream_t s, int n, const float* const* X, const int64_t* ld, const int* ncols, float* const* out,
+                      int64_t Q, float alpha, bool accumulate, float* part) {
+  if (n <= 0) return ORCA_OK;
+  if (n > COLSUM_JOBS) return ORCA_EINVAL;
+  ColsumJobs jobs{};
+  int maxc = 0;
+  for (int i = 0; i < n; ++i) {
+    if (ncols[i] <= 0 || ncols[i] > COLSUM_MAXC) return ORCA_EINVAL;
+    jobs.X[i] = X[i]; jobs.ld[i] = ld[i]; jobs.ncols[i] = ncols[i]; jobs.out[i] = out[i];
+    maxc = ncols[i] > maxc ? ncols[i] : maxc;
+  }
+  k_colsum<<<dim3((unsigned)((maxc + 63) / 64), COLSUM_SLICES, (unsigned)n), 1024, 0, s>>>(jobs, Q, part);
+  k_colsum_finish<<<dim3((unsigned)((maxc + 3) / 4), (unsigned)n), 256, 0, s>>>(jobs, part, alpha, accumulate ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
+}
+
 int orca_colsum(hipStream_t s, const float* X, int64_t Q, int64_t ld, int ncols, float* out, float alpha, bool accumulate,
                 float* part) {
   if (ncols <= 0) return ORCA_OK;
-  k_colsum<<<dim3((unsigned)((ncols + 63) / 64), COLSUM_SLICES), 1024, 0, s>>>(X, Q, ld, ncols, part);
-  k_colsum_finish<<<(unsigned)((ncols + 3) / 4), 256, 0, s>>>(part, ncols, out, alpha, accumulate ? 1 : 0);
-  return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
+  const int nc = ncols;
+  return orca_colsum_group(s, 1, &X, &ld, &nc, &out, Q, alpha, accumulate, part);
 }
 
 namespace {
@@ -372,6 +427,8 @@ __global__ __launch_bounds__(256) void k_bwd_prep(orca_tgat_inputs in, int64_t Q
 
 // recompute of the attention core: a[q][h][j] = softmax_j(q~_h . x_j) over the unmasked slots,
 // xbar[q][h] = sum_j a_hj x_j;  invalid[q] = 1 for an all-padded query (temporal_attention.py:46-47,52)
+// (gathering the K rows once into registers, as k_bwd_attn_bwd does, measured slower here: 47 vs 35 us -- at 188
+// VGPRs the launch no longer fits the chip in one round, and two passes over the rows do not pay for that)
 __global__ __launch_bounds__(256) void k_bwd_attn_fwd(orca_tgat_inputs in, int64_t Q, int K, int d_e,
                                                       const float* __restrict__ qt, float* __restrict__ a_out,
                                                       float* __restrict__ xbar, float* __restrict__ invalid,
@@ -497,6 +554,9 @@ __global__ __launch_bounds__(256) void k_bwd_ln(const float* __restrict__ y, con
 // dx_j = sum_h (a_hj dxbar_h + ds_hj q~_h) goes to d_nbr (columns 0..99), is dropped for the edge columns (the edge
 // features are data, not parameters) and for the time columns goes to d_nbr_time (dense mode) or, through
 // d cos(dt w + b), into this query's row of tgrad = [d time_w | d time_b] (gather mode).
+// KT = compile-time bound of K: the K key rows of a query are gathered ONCE into registers for the three passes
+// (66 -> 56 us per launch)
+template <int KT>
 __global__ __launch_bounds__(256) void k_bwd_attn_bwd(orca_tgat_inputs in, int64_t Q, int K, int d_e,
                                                       const float* __restrict__ qt, const float* __restrict__ a_in,
                                                       const float* __restrict__ dxbar, float* __restrict__ dqt,
@@ -520,13 +580,16 @@ __global__ __launch_bounds__(256) void k_bwd_attn_bwd(orca_tgat_inputs in, int64
   }
   const float a0 = lane < K ? a_in[(q * 2 + 0) * K + lane] : 0.f;
   const float a1 = lane < K ? a_in[(q * 2 + 1) * K + lane] : 0.f;
+  float x[KT][MAXC];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) key_row(x[j], in, S, q, j < K ? j : 0, K, d_e, lane);
   float da0 = 0.f, da1 = 0.f;
-  for (int j = 0; j < K; ++j) {
-    float x[MAXC];
-    key_row(x, in, S, q, j, K, d_e, lane);
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    if (j >= K) continue;   // (no break: the loop must unroll fully, x[][] lives in registers)
     float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) { p0 += x[i] * g0[i]; p1 += x[i] * g1[i]; }
+    for (int i = 0; i < MAXC; ++i) { p0 += x[j][i] * g0[i]; p1 += x[j][i] * g1[i]; }
     p0 = wave_sum(p0);
     p1 = wave_sum(p1);
     if (lane == j) { da0 = p0; da1 = p1; }
@@ -543,16 +606,16 @@ __global__ __launch_bounds__(256) void k_bwd_attn_bwd(orca_tgat_inputs in, int64
   }
   const float ds0 = a0 * (da0 - wave_sum(a0 * da0)), ds1 = a1 * (da1 - wave_sum(a1 * da1));
   const float aw0 = a0 * m0, aw1 = a1 * m1;
-  for (int j = 0; j < K; ++j) {
-    float x[MAXC];
-    key_row(x, in, S, q, j, K, d_e, lane);
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    if (j >= K) continue;   // (no break: the loop must unroll fully, x[][] lives in registers)
     const float w0 = __shfl(aw0, j, 64), w1 = __shfl(aw1, j, 64), e0 = __shfl(ds0, j, 64), e1 = __shfl(ds1, j, 64);
     const float dt = __shfl(S.dt, j, 64);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
-      r0[i] += e0 * x[i];
-      r1[i] += e1 * x[i];
+      r0[i] += e0 * x[j][i];
+      r1[i] += e1 * x[j][i];
       const float dx = w0 * g0[i] + w1 * g1[i] + e0 * q0[i] + e1 * q1[i];
       if (c < D) {
         d_nbr[(q * K + j) * D + c] = dx;
@@ -621,7 +684,7 @@ Ws ws_layout(int d_e, int64_t Q, int K) {
   w.part = o;
   // the eight weight-gradient problems with their bias columns (each rounded up to 64 floats), or a column sum's slices
   o += (int64_t)SPLITS * ((int64_t)D * (D + 1) + (int64_t)D * (3 * D + 1) + 2 * (int64_t)QD * (QD + 1) + 4 * (int64_t)D * (kdim + 1)) + 64 * 8
-       + 64 * QD;
+       + 4 * 64 * 320;
   w.total = o;
   return w;
 }
@@ -706,8 +769,13 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
 
   // ---- backward: the data gradients, a chain ------------------------------------------------------------
   k_bwd_ln<<<qb, 256, 0, s>>>(y, grad_out, P->ln_w, Q, dy, gx);
-  rc |= colsum(s, gx, Q, D, D, G->ln_w, 1.f, true, part);
-  rc |= colsum(s, grad_out, Q, D, D, G->ln_b, 1.f, true, part);
+  {   // LayerNorm's affine gradients: column sums of g * xhat and of g
+    const float* X[2] = {gx, grad_out};
+    const int64_t ld[2] = {D, D};
+    const int nc[2] = {D, D};
+    float* out[2] = {G->ln_w, G->ln_b};
+    rc |= orca_colsum_group(s, 2, X, ld, nc, out, Q, 1.f, true, part);
+  }
   {   // fc2: dz1 = (dy W2) where h1 > 0
     OrcaGemm g = G1(M, D, D, dy, D, 1, P->fc2_w, D, 1, dh1, D, 1, nullptr, 1.f);
     g.gate = h1;
@@ -730,7 +798,10 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
     rc |= orca_sgemm_group(s, g, 2, nullptr);
   }
   const bool want_t = in->dt && d_time_w;
-  k_bwd_attn_bwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
+  if (K <= 10)
+    k_bwd_attn_bwd<10><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
+  else
+    k_bwd_attn_bwd<ORCA_MAX_K><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
   {   // key fold: dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs
     OrcaGemm g[2];
     for (int h = 0; h < 2; ++h)
@@ -763,10 +834,17 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
     g[7] = GW(QD, QD, dq, QD, xq, QD, G->q_w, G->in_b);
     rc |= orca_sgemm_group(s, g, 8, part);
   }
-  if (drop) rc |= colsum(s, scaled, Q, QD, QD, G->in_b + 2 * QD, 1.f, true, part);
-  if (want_t) {
-    rc |= colsum(s, tgrad, Q, QD, D, d_time_w, 1.f, true, part);
-    rc |= colsum(s, tgrad + D, Q, QD, D, d_time_b, 1.f, true, part);
+  {   // what is left of the bias-like gradients: the value bias under dropout, the time encoder's w and b
+    const float* X[3];
+    int64_t ld[3];
+    int nc[3], nj = 0;
+    float* out[3];
+    if (drop) { X[nj] = scaled; ld[nj] = QD; nc[nj] = QD; out[nj++] = G->in_b + 2 * QD; }
+    if (want_t) {
+      X[nj] = tgrad; ld[nj] = QD; nc[nj] = D; out[nj++] = d_time_w;
+      X[nj] = tgrad + D; ld[nj] = QD; nc[nj] = D; out[nj++] = d_time_b;
+    }
+    rc |= orca_colsum_group(s, nj, X, ld, nc, out, Q, 1.f, true, part);
   }
   if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
     orca_set_error("orca_tgat_backward: kernel launch failed");
