@@ -320,6 +320,14 @@ int orca_find_uncached(const int32_t* nbr, int64_t n_nbr, const int64_t* batch_n
 int orca_scatter_rows(float* table, int64_t width, const int64_t* ids, int64_t n, const float* x,
                       void* stream);
 
+/* optimizer.step() of train.py:238 for torch.optim.Adam(tgn.parameters(), lr) (train.py:180; no weight decay, no
+ * amsgrad) over n tensors in one launch per 24 tensors: params / grads / exp_avg / exp_avg_sq and sizes are HOST arrays
+ * of n device pointers / element counts; step = 1 for the first call (the caller counts).  Arithmetic in the order of
+ * torch's multi-tensor implementation. */
+int orca_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const int64_t* sizes, double lr, double beta1, double beta2, double eps,
+                   int64_t step, void* stream);
+
 /* ---- native step driver: model/tgn_model.py:95-147 with modules/embedding_module.py:154-182 ----- */
 
 /* One TGN batch step in the embedding-reuse (--reuse, budget 0) formulation, issued from C++ on one

@@ -725,13 +725,15 @@ class OrcaEngine:
     h = torch.relu(x @ aff["fc1.weight"].t() + aff["fc1.bias"])
     score = (h @ aff["fc2.weight"].t() + aff["fc2.bias"]).sigmoid().squeeze(1)
     bce = torch.nn.functional.binary_cross_entropy
-    loss = bce(score[:bs], torch.ones(bs, device=dev)) + bce(score[bs:], torch.zeros(bs, device=dev))
+    if getattr(self, "_targets", None) is None or self._targets[0].numel() != bs:
+      self._targets = (torch.ones(bs, device=dev), torch.zeros(bs, device=dev))
+    loss = bce(score[:bs], self._targets[0]) + bce(score[bs:], self._targets[1])
     loss.backward()
     grads = {"affinity_score." + k: v.grad for k, v in aff.items()}
     # ---- backward through the attention calls, last to first (this rank's slice) ----
     d = leaf.grad[lo:hi].contiguous()
-    d_tw = torch.zeros(D, dtype=torch.float32, device=dev)
-    d_tb = torch.zeros(D, dtype=torch.float32, device=dev)
+    want_t = self.train_time_encoder       # (frozen upstream, model/time_encoding.py:20-21: its gradient is not computed)
+    d_time = torch.zeros(2, D, dtype=torch.float32, device=dev) if want_t else None
     into_memory = None
     for layer, m, (nbr, eid, dt), tables, sink in reversed(steps):
       p = f"embedding_module.attention_models.{layer - 1}."
@@ -740,11 +742,12 @@ class OrcaEngine:
       kw.update(tables)
       if layer == 1:
         kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
-      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, m, K, d, want_time_param_grads=True, **kw)
+      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, m, K, d, want_time_param_grads=want_t, **kw)
       for k, v in g.items():                           # Path A evaluates a layer once per batch, like Path B
         grads[p + k] = v
-      d_tw += tw
-      d_tb += tb
+      if want_t:
+        d_time[0] += tw
+        d_time[1] += tb
       if sink == "cat":                                # Path A: the neighbours' rows are embeddings of the level below
         d = torch.cat([d_src, d_nbr])
       elif sink is None:                               # Path B inner layer: history rows are detached
@@ -771,10 +774,10 @@ class OrcaEngine:
     else:
       for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
         grads[p + k] = torch.zeros_like(self.params[p + k])
-    if self.train_time_encoder:
-      grads["time_encoder.w.weight"] = d_tw.view(D, 1)
+    if want_t:
+      grads["time_encoder.w.weight"] = d_time[0].view(D, 1)
       if "time_encoder.w.bias" in self.params:
-        grads["time_encoder.w.bias"] = d_tb
+        grads["time_encoder.w.bias"] = d_time[1]
     if self.world > 1:                     # every rank holds the decoder's full gradient already
       keys = sorted(k for k in grads if not k.startswith("affinity_score."))
       flat = torch.cat([grads[k].reshape(-1) for k in keys])
@@ -800,20 +803,30 @@ class OrcaEngine:
     ev.record()
     return ev
 
-  def optimizer(self, lr=1e-4):
-    """torch.optim.Adam over the raw parameter tensors (train.py:180): the optimizer updates self.params in place;
-    step_optimizer() feeds it train_step's gradients and re-packs the kernels' blobs."""
-    self._opt_params = {k: torch.nn.Parameter(v) for k, v in self.params.items() if v.is_floating_point() and
-                        (self.train_time_encoder or not k.startswith("time_encoder."))}
-    self._opt = torch.optim.Adam(self._opt_params.values(), lr=lr)
+  def optimizer(self, lr=1e-4, fused=True):
+    """Adam over the raw parameter tensors (train.py:180): updates self.params in place; step_optimizer() feeds it
+    train_step's gradients and re-packs the kernels' blobs.  fused: one launch per step (ops.FusedAdam over
+    orca_adam_step, torch.optim.Adam's arithmetic); fused=False: torch.optim.Adam itself (seven launches and 0.3 ms of
+    host time per step)."""
+    trainable = {k: v for k, v in self.params.items() if v.is_floating_point() and
+                 (self.train_time_encoder or not k.startswith("time_encoder."))}
+    if fused:
+      self._opt_params = None
+      self._opt = ops.FusedAdam(trainable, lr=lr)
+    else:
+      self._opt_params = {k: torch.nn.Parameter(v) for k, v in trainable.items()}
+      self._opt = torch.optim.Adam(self._opt_params.values(), lr=lr)
     return self._opt
 
   def step_optimizer(self, grads):
     """optimizer.step() of train.py:238 with the gradients of train_step, then refresh()."""
-    for k, p in self._opt_params.items():
-      g = grads.get(k)
-      p.grad = None if g is None else g.reshape(p.shape)
-    self._opt.step()
+    if self._opt_params is None:
+      self._opt.step(grads)
+    else:
+      for k, p in self._opt_params.items():
+        g = grads.get(k)
+        p.grad = None if g is None else g.reshape(p.shape)
+      self._opt.step()
     self.refresh()
 
   def _dev(self, x, dtype):

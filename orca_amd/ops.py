@@ -303,7 +303,11 @@ def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_
   g_bias_hh, d_x, d_h) -- the last two None unless want_inputs."""
   dev = d_out.device
   ps = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
-  gs = [torch.zeros_like(p) for p in ps]
+  flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in ps), dtype=torch.float32, device=dev)    # one fill for the four
+  gs, o = [], 0
+  for p in ps:
+    gs.append(flat[o:o + p.numel()].view(p.shape))
+    o += -(-p.numel() // 64) * 64
   msg_dim = ps[0].shape[1]
   n = d_out.shape[0]
   nw = _lib.load().orca_gru_backward_workspace_floats(int(msg_dim), int(n))
@@ -410,6 +414,44 @@ def gather_rows(table, idx, out=None):
 def scatter_rows(table, ids, x):
   check(_lib.load().orca_scatter_rows(ptr(table), table.shape[1], ptr(ids), ids.numel(), ptr(x), stream()),
         "orca_scatter_rows")
+
+
+class FusedAdam:
+  """torch.optim.Adam(params, lr) (train.py:180) as one launch per step (orca_adam_step): params is a dict name ->
+  fp32 device tensor, updated in place; step(grads) takes a dict with (a subset of) the same names -- a parameter
+  without a gradient is skipped, as torch skips p.grad is None."""
+
+  def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    self.params = {k: v for k, v in params.items()}
+    self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+    n = sum(-(-v.numel() // 64) * 64 for v in self.params.values())
+    dev = next(iter(self.params.values())).device
+    self._state = torch.zeros(2, max(n, 1), dtype=torch.float32, device=dev)     # exp_avg | exp_avg_sq, one fill
+    self.exp_avg, self.exp_avg_sq, o = {}, {}, 0
+    for k, v in self.params.items():
+      if v.dtype != torch.float32 or not v.is_contiguous() or not v.is_cuda:
+        raise _lib.OrcaError(f"FusedAdam: parameter {k} must be a contiguous fp32 tensor on the HIP device")
+      self.exp_avg[k] = self._state[0, o:o + v.numel()]
+      self.exp_avg_sq[k] = self._state[1, o:o + v.numel()]
+      o += -(-v.numel() // 64) * 64
+    self.steps = {k: 0 for k in self.params}       # torch counts steps per parameter (a skipped one does not advance)
+
+  def step(self, grads):
+    by_step = {}
+    for k, p in self.params.items():
+      g = grads.get(k)
+      if g is None:
+        continue
+      if g.numel() != p.numel() or g.dtype != torch.float32 or not g.is_cuda:
+        raise _lib.OrcaError(f"FusedAdam: gradient of {k} does not match its parameter")
+      self.steps[k] += 1
+      by_step.setdefault(self.steps[k], []).append((p, g.contiguous(), self.exp_avg[k], self.exp_avg_sq[k]))
+    for t, lst in by_step.items():
+      n = len(lst)
+      arr = lambda j: (ctypes.c_void_p * n)(*[x[j].data_ptr() for x in lst])
+      sizes = (ctypes.c_int64 * n)(*[x[0].numel() for x in lst])
+      check(_lib.load().orca_adam_step(n, arr(0), arr(1), arr(2), arr(3), sizes, self.lr, self.betas[0], self.betas[1],
+                                       self.eps, t, stream()), "orca_adam_step")
 
 
 def find_uncached(nbr, batch_nodes, cache_flag, slot, epoch, bitmap):

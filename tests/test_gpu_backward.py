@@ -402,3 +402,27 @@ def test_api_layer_train_mode_dropout(ops, golden):
   layer.eval()
   plain, _ = call()
   assert_close_fp32(plain.detach().cpu().numpy(), g[tag + "out"], TOL, "eval() switches dropout off")
+
+
+def test_fused_adam_matches_torch_adam(ops):
+  """orca_adam_step (ops.FusedAdam) against torch.optim.Adam (train.py:180,238) over several steps on tensors of
+  ragged sizes, one of them without a gradient on the second step (torch skips it and does not advance its step)."""
+  g = torch.Generator(device="cpu")
+  g.manual_seed(4)
+  shapes = [(200, 200), (300,), (100, 373), (1,), (7, 13), (300, 472)] + [(33,)] * 25      # more than one launch's worth
+  P = {f"p{i}": torch.randn(*s, generator=g) for i, s in enumerate(shapes)}
+  ref = {k: torch.nn.Parameter(v.clone()) for k, v in P.items()}
+  opt = torch.optim.Adam(ref.values(), lr=1e-3)
+  mine = {k: v.clone().to(DEV) for k, v in P.items()}
+  fused = ops.FusedAdam(mine, lr=1e-3)
+  for step in range(5):
+    grads = {k: torch.randn(*v.shape, generator=g) * (10.0 ** (step - 2)) for k, v in P.items()}
+    if step == 1:
+      del grads["p2"]
+    for k, p in ref.items():
+      p.grad = grads.get(k)
+    opt.step()
+    fused.step({k: v.to(DEV) for k, v in grads.items()})
+    for k in P:
+      assert_close_fp32(mine[k].cpu().numpy(), ref[k].detach().numpy(), 1e-6, f"Adam step {step} {k}")
+  assert fused.steps["p2"] == 4 and fused.steps["p0"] == 5
