@@ -64,7 +64,9 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, int m, int n, floa
 constexpr int GEMM_BK = 32;
 template <int TM>
 __global__ __launch_bounds__(256) void k_sgemm(GemmGroup grp) {
-  constexpr int IM = TM / 32;                  // 16-row MFMA tiles per wave along m
+  constexpr int WR = TM >= 32 ? 2 : 1;         // the four waves as WR x (4 / WR) over the TM x 64 tile
+  constexpr int IM = TM / (16 * WR);           // 16-row MFMA tiles per wave along m
+  constexpr int JN = 64 / (16 * (4 / WR));     // 16-column MFMA tiles per wave along n
   constexpr int EA = TM * GEMM_BK / 256;       // A elements per thread and slab
   constexpr int EB = 64 * GEMM_BK / 256;       // B elements per thread and slab
   __shared__ float As[GEMM_BK][TM + 4], Bs[GEMM_BK][68];
@@ -80,12 +82,12 @@ __global__ __launch_bounds__(256) void k_sgemm(GemmGroup grp) {
   const int kbeg = bz * g.kchunk;
   const int kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
   const int Nr = g.ones_out ? g.N - 1 : g.N;
-  const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * 32;
-  f32x4 acc[IM][2];
+  const int wm = WR == 2 ? (wave >> 1) * (TM / 2) : 0, wn = WR == 2 ? (wave & 1) * 32 : wave * 16;
+  f32x4 acc[IM][JN];
 #pragma unroll
   for (int i = 0; i < IM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < JN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
   float ra[EA], rb[EB];
   auto a_index = [&](int e, int& m, int& k) {
@@ -149,22 +151,22 @@ __global__ __launch_bounds__(256) void k_sgemm(GemmGroup grp) {
     const int ksteps = (kend - k0 < GEMM_BK ? kend - k0 + 3 : GEMM_BK) / 4;     // rows past kend hold zeros: skip them
     for (int kk = 0; kk < ksteps; ++kk) {
       const int kr = kk * 4 + (lane >> 4);
-      float a[IM], b[2];
+      float a[IM], b[JN];
 #pragma unroll
       for (int i = 0; i < IM; ++i) a[i] = As[kr][wm + i * 16 + (lane & 15)];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wn + j * 16 + (lane & 15)];
+      for (int j = 0; j < JN; ++j) b[j] = Bs[kr][wn + j * 16 + (lane & 15)];
 #pragma unroll
       for (int i = 0; i < IM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < IM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < JN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + i * 16 + 4 * (lane >> 4) + r, n = n0 + wn + j * 16 + (lane & 15);
@@ -299,8 +301,9 @@ int orca_sgemm_group(hipStream_t s, const OrcaGemm* in, int n, float* part) {
   }
   if (np == 0) return ORCA_OK;
   grp.n = np;
-  const bool small = tiles64 < 512;     // under two blocks per CU: halve the tile, double the blocks
-  const int TM = small ? 32 : 64;
+  // under two blocks per CU: halve the tile, double the blocks (a block is one wave per SIMD: its chain of slabs is
+  // latency-bound, and only more resident blocks hide that); under one: quarter it
+  const int TM = tiles64 < 256 ? 16 : tiles64 < 512 ? 32 : 64;
   int first = 0;
   for (int i = 0; i < np; ++i) {
     grp.first[i] = first;
@@ -308,7 +311,8 @@ int orca_sgemm_group(hipStream_t s, const OrcaGemm* in, int n, float* part) {
     first += grp.g[i].gx * grp.g[i].gy * grp.g[i].gz;
   }
   grp.first[np] = first;
-  if (small) k_sgemm<32><<<(unsigned)first, 256, 0, s>>>(grp);
+  if (TM == 16) k_sgemm<16><<<(unsigned)first, 256, 0, s>>>(grp);
+  else if (TM == 32) k_sgemm<32><<<(unsigned)first, 256, 0, s>>>(grp);
   else k_sgemm<64><<<(unsigned)first, 256, 0, s>>>(grp);
   if (any_split) {
     GemmGroup red{};

@@ -789,7 +789,10 @@ class OrcaEngine:
         o += m
     # ---- the state moves on (tgn_model.py:127-141) ----
     positives = nodes[:2 * bs]
-    self._persist_memory(positives)
+    if self.world > 1:       # this rank's forward put GRU(message, memory) of ITS pending roots into the overlay: the
+      self._overlay_updated_memory(None, positives)    # other ranks' positives follow (same kernel: same bits as one rank)
+    ops.persist_overlay(positives, self.pending, self.overlay, self.memory, self.last_update, self.msg_ts)
+    ops.set_flags(self.pending, ids64=positives, v=0)
     ops.message_store(src, dst, eidx, ts, self.memory, self.last_update, self.edge_feats, self.time_w, self.time_b,
                       self.slot, self._slot_epoch(2 * bs), self.messages, self.msg_ts, self.pending)
     return loss.detach(), grads

@@ -323,6 +323,13 @@ def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_
   return (*gs, d_x, d_h)
 
 
+def persist_overlay(ids64, pending, overlay, memory, last_update, msg_ts):
+  """memory[id] = overlay[id], last_update[id] = msg_ts[id] for the pending ids of ids64 (memory_updater.py:25-39 when
+  the overlay already holds their GRU rows)"""
+  check(_lib.load().orca_persist_overlay(ptr(ids64), ids64.numel(), ptr(pending), ptr(overlay), ptr(memory), ptr(last_update),
+                                         ptr(msg_ts), memory.shape[0], stream()), "orca_persist_overlay")
+
+
 def gru_update(blob, msg_dim, ids, n, n_dev, x, h, out, last_update=None, msg_ts=None):
   check(_lib.load().orca_gru_update(ptr(blob), int(msg_dim), ptr(ids), int(n), ptr(n_dev), ptr(x), ptr(h), ptr(out),
                                     ptr(last_update), ptr(msg_ts), stream()), "orca_gru_update")
