@@ -30,6 +30,11 @@ void orca_set_error(const char* fmt, ...);
 
 #define ORCA_LAUNCH_CHECK() ORCA_HIP_TRY(hipGetLastError())
 
+// fence index of a CSR's timestamps (sampler.h, csr.hip): lvl[k] == NULL from the first unused level on
+constexpr int ORCA_FENCE_B0 = 32, ORCA_FENCE_LEVELS = 6;
+struct orca_fences { const double* lvl[ORCA_FENCE_LEVELS]; };
+int orca_csr_fences(const orca_csr_t* c, orca_fences* out);
+
 // ---- library-internal entry points (hidden visibility; used by the native step driver) -------------
 // First pass of orca_worklist_build fused into the sampler: every sampled neighbour / root whose flag is set
 // stores slot[id] = epoch + position, positions numbered [neighbours (Q*K) ; roots (Q)]; *count is zeroed.

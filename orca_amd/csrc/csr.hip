@@ -15,6 +15,8 @@ struct orca_csr {
   int32_t* nbr;     // [nnz]
   int32_t* eid;     // [nnz]
   double* ts;       // [nnz]
+  double* fence_mem;  // the fence levels of ts (sampler.h), one allocation
+  orca_fences F;
 };
 
 static thread_local char g_err[512] = "";
@@ -33,6 +35,7 @@ static void csr_free(orca_csr* c) {
   if (c->nbr) (void)hipFree(c->nbr);
   if (c->eid) (void)hipFree(c->eid);
   if (c->ts) (void)hipFree(c->ts);
+  if (c->fence_mem) (void)hipFree(c->fence_mem);
   delete c;
 }
 
@@ -42,6 +45,45 @@ static int csr_alloc(orca_csr* c) {
   ORCA_HIP_TRY(hipMalloc(&c->nbr, n * sizeof(int32_t)));
   ORCA_HIP_TRY(hipMalloc(&c->eid, n * sizeof(int32_t)));
   ORCA_HIP_TRY(hipMalloc(&c->ts, n * sizeof(double)));
+  return ORCA_OK;
+}
+
+// dst[j] = src[stride * j + stride - 1], j < n
+__global__ void k_fence_level(const double* __restrict__ src, int64_t stride, double* __restrict__ dst, int64_t n) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) dst[j] = src[stride * j + stride - 1];
+}
+// the fence levels over c->ts (sampler.h): +3 % of the timestamps' bytes
+static int csr_build_fences(orca_csr* c, hipStream_t stream) {
+  int64_t n[ORCA_FENCE_LEVELS], total = 0;
+  int64_t prev = c->nnz;
+  for (int k = 0; k < ORCA_FENCE_LEVELS; ++k) {
+    n[k] = prev / (k == 0 ? ORCA_FENCE_B0 : 64);
+    total += (n[k] + 15) / 16 * 16;
+    prev = n[k];
+  }
+  for (int k = 0; k < ORCA_FENCE_LEVELS; ++k) c->F.lvl[k] = nullptr;
+  if (n[0] == 0) return ORCA_OK;
+  ORCA_HIP_TRY(hipMalloc(&c->fence_mem, (size_t)total * sizeof(double)));
+  const double* src = c->ts;
+  double* dst = c->fence_mem;
+  for (int k = 0; k < ORCA_FENCE_LEVELS && n[k] > 0; ++k) {
+    k_fence_level<<<(unsigned)ceil_div64(n[k], 256), 256, 0, stream>>>(src, k == 0 ? ORCA_FENCE_B0 : 64, dst, n[k]);
+    c->F.lvl[k] = dst;
+    src = dst;
+    dst += (n[k] + 15) / 16 * 16;
+  }
+  ORCA_HIP_TRY(hipGetLastError());
+  return ORCA_OK;
+}
+// (ORCA_NO_FENCES=1 in the environment: the samplers search the timestamps directly, for A/B measurements)
+static orca_fences csr_F(const orca_csr* c) {
+  static const bool off = getenv("ORCA_NO_FENCES") && atoi(getenv("ORCA_NO_FENCES")) != 0;
+  return off ? orca_fences{} : c->F;
+}
+int orca_csr_fences(const orca_csr_t* c, orca_fences* out) {
+  ORCA_REQUIRE(c && out, "orca_csr_fences: null argument");
+  *out = csr_F(c);
   return ORCA_OK;
 }
 
@@ -96,6 +138,9 @@ ORCA_API int orca_csr_create_host(int64_t E, const int64_t* src, const int64_t* 
     orca_set_error("orca_csr_create_host: upload failed");
     return ORCA_EHIP;
   }
+  rc = csr_build_fences(c, nullptr);
+  if (rc == ORCA_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = ORCA_EHIP;
+  if (rc != ORCA_OK) { csr_free(c); return rc; }
   *out = c;
   return ORCA_OK;
 }
@@ -226,6 +271,8 @@ ORCA_API int orca_csr_create_device(int64_t E, const int64_t* src, const int64_t
   k_fill_csr<<<(unsigned)ceil_div64(n2, B), B, 0, stream>>>(src, dst, eidx, ts, v_out, n2, c->nbr, c->eid, c->ts);
   k_indptr<<<(unsigned)ceil_div64(n_rows + 1, B), B, 0, stream>>>(k2b, n2, n_rows, c->indptr);
   TRY_OR_FAIL(hipGetLastError());
+  rc = csr_build_fences(c, stream);
+  if (rc != ORCA_OK) { cleanup(); csr_free(c); return rc; }
   TRY_OR_FAIL(hipStreamSynchronize(stream));
   cleanup();
 #undef TRY_OR_FAIL
@@ -253,6 +300,9 @@ ORCA_API int orca_csr_from_arrays_host(int64_t n_rows, const int64_t* indptr, co
     orca_set_error("orca_csr_from_arrays_host: upload failed");
     return ORCA_EHIP;
   }
+  rc = csr_build_fences(c, nullptr);
+  if (rc == ORCA_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = ORCA_EHIP;
+  if (rc != ORCA_OK) { csr_free(c); return rc; }
   *out = c;
   return ORCA_OK;
 }
@@ -298,7 +348,7 @@ ORCA_API int orca_csr_copy_range_host(const orca_csr_t* c, int64_t begin, int64_
 __global__ __launch_bounds__(256) void k_sample_recent(const int64_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ nbr,
                                                        const int32_t* __restrict__ eid,
-                                                       const double* __restrict__ ts, int64_t n_rows,
+                                                       const double* __restrict__ ts, orca_fences F, int64_t n_rows,
                                                        const int64_t* __restrict__ nodes,
                                                        const double* __restrict__ qts, int64_t Q, int K,
                                                        int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid,
@@ -307,7 +357,7 @@ __global__ __launch_bounds__(256) void k_sample_recent(const int64_t* __restrict
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= Q) return;
-  sample_recent_wave(indptr, nbr, eid, ts, n_rows, nodes[q], qts[q], q, Q, K, o_nbr, o_eid, o_et, o_dt, err_flag, claim, lane);
+  sample_recent_wave(indptr, nbr, eid, ts, F, n_rows, nodes[q], qts[q], q, Q, K, o_nbr, o_eid, o_et, o_dt, err_flag, claim, lane);
 }
 
 int orca_sample_recent_claim(const orca_csr_t* c, const int64_t* nodes, const double* ts, int64_t Q, int K,
@@ -318,8 +368,8 @@ int orca_sample_recent_claim(const orca_csr_t* c, const int64_t* nodes, const do
   ORCA_REQUIRE(nodes && ts && out_nbr && out_eidx && out_et, "orca_sample_recent: null pointer");
   const int wpb = 4;
   ORCA_LAUNCH_TIMED(k_sample_recent, (unsigned)ceil_div64(Q, wpb), wpb * 64, 0, (hipStream_t)stream,
-                    c->indptr, c->nbr, c->eid, c->ts, c->n_rows, nodes, ts, Q, K, out_nbr, out_eidx, out_et, out_dt, err_flag,
-                    claim ? *claim : orca_claim{});
+                    c->indptr, c->nbr, c->eid, c->ts, csr_F(c), c->n_rows, nodes, ts, Q, K, out_nbr, out_eidx, out_et, out_dt,
+                    err_flag, claim ? *claim : orca_claim{});
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -331,7 +381,7 @@ ORCA_API int orca_sample_recent(const orca_csr_t* c, const int64_t* nodes, const
 }
 
 __global__ __launch_bounds__(256) void k_find_before(const int64_t* __restrict__ indptr, const double* __restrict__ ts,
-                                                     int64_t n_rows, const int64_t* __restrict__ nodes,
+                                                     orca_fences F, int64_t n_rows, const int64_t* __restrict__ nodes,
                                                      const double* __restrict__ qts, int64_t Q, int64_t* out) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -340,7 +390,7 @@ __global__ __launch_bounds__(256) void k_find_before(const int64_t* __restrict__
   int64_t cnt = 0;
   if (v >= 0 && v < n_rows) {
     int64_t lo = indptr[v];
-    cnt = wave_lower_bound(ts, lo, indptr[v + 1], qts[q], lane) - lo;
+    cnt = wave_lower_bound(ts, F, lo, indptr[v + 1], qts[q], lane) - lo;
   }
   if (lane == 0) out[q] = cnt;
 }
@@ -349,7 +399,7 @@ ORCA_API int orca_find_before(const orca_csr_t* c, const int64_t* nodes, const d
                               void* stream) {
   ORCA_REQUIRE(c && Q >= 0, "orca_find_before: bad arguments");
   if (Q == 0) return ORCA_OK;
-  k_find_before<<<(unsigned)ceil_div64(Q, 4), 256, 0, (hipStream_t)stream>>>(c->indptr, c->ts, c->n_rows, nodes, ts, Q, out);
+  k_find_before<<<(unsigned)ceil_div64(Q, 4), 256, 0, (hipStream_t)stream>>>(c->indptr, c->ts, csr_F(c), c->n_rows, nodes, ts, Q, out);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -358,7 +408,7 @@ ORCA_API int orca_find_before(const orca_csr_t* c, const int64_t* nodes, const d
 __global__ __launch_bounds__(256) void k_sample_uniform(const int64_t* __restrict__ indptr,
                                                         const int32_t* __restrict__ nbr,
                                                         const int32_t* __restrict__ eid,
-                                                        const double* __restrict__ ts, int64_t n_rows,
+                                                        const double* __restrict__ ts, orca_fences F, int64_t n_rows,
                                                         const int64_t* __restrict__ nodes,
                                                         const double* __restrict__ qts, int64_t Q, int K,
                                                         uint64_t seed, int64_t q0, int32_t* __restrict__ o_nbr,
@@ -367,7 +417,7 @@ __global__ __launch_bounds__(256) void k_sample_uniform(const int64_t* __restric
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= Q) return;
-  sample_uniform_wave(indptr, nbr, eid, ts, n_rows, nodes[q], qts[q], q, Q, K, seed, q0 + q, o_nbr, o_eid, o_et, o_dt,
+  sample_uniform_wave(indptr, nbr, eid, ts, F, n_rows, nodes[q], qts[q], q, Q, K, seed, q0 + q, o_nbr, o_eid, o_et, o_dt,
                       err_flag, orca_claim{}, lane);
 }
 
@@ -377,8 +427,8 @@ ORCA_API int orca_sample_uniform(const orca_csr_t* c, const int64_t* nodes, cons
   ORCA_REQUIRE(c && Q >= 0 && K >= 1 && K <= 64 && q0 >= 0, "orca_sample_uniform: bad arguments (Q=%lld K=%d)", (long long)Q, K);
   if (Q == 0) return ORCA_OK;
   ORCA_LAUNCH_TIMED(k_sample_uniform, (unsigned)ceil_div64(Q, 4), 256, 0, (hipStream_t)stream,
-                    c->indptr, c->nbr, c->eid, c->ts, c->n_rows, nodes, ts, Q, K, seed, q0, out_nbr, out_eidx, out_et, out_dt,
-                    err_flag);
+                    c->indptr, c->nbr, c->eid, c->ts, csr_F(c), c->n_rows, nodes, ts, Q, K, seed, q0, out_nbr, out_eidx, out_et,
+                    out_dt, err_flag);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

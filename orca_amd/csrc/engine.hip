@@ -200,6 +200,7 @@ struct begin_elect {
 struct begin_sample {
   int mode;                     // ORCA_SAMPLE_*
   uint64_t seed;
+  orca_fences fences;           // the CSR's fence index (sampler.h)
 };
 // The eager GRU as a role of the first kernel (blocks 0 .. n_blocks-1, ahead of every other role: theirs is the
 // longest chain of the launch): GRU(message, memory) -> overlay for the ids the previous step stored.  It shares no
@@ -285,9 +286,9 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     qts[i] = t;
   }
   if (smp.mode == ORCA_SAMPLE_UNIFORM)
-    sample_uniform_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, ql, nq, K, smp.seed, i, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
+    sample_uniform_wave(indptr, c_nbr, c_eid, c_ts, smp.fences, n_rows, v, t, ql, nq, K, smp.seed, i, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
   else
-    sample_recent_wave(indptr, c_nbr, c_eid, c_ts, n_rows, v, t, ql, nq, K, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
+    sample_recent_wave(indptr, c_nbr, c_eid, c_ts, smp.fences, n_rows, v, t, ql, nq, K, o_nbr, o_eid, o_et, o_dt, nullptr, claim, lane);
 }
 
 // ---- owner-computes step (several ranks): kernels over the exchange buffers ---------------------------------
@@ -670,7 +671,8 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
       el.win_push = d.winners;
       el.msg_list = my_list; el.msg_count = my_count;
     }
-    const begin_sample smp{e->sampling, e->seed};
+    begin_sample smp{e->sampling, e->seed, {}};
+    if ((rc = orca_csr_fences(d.csr, &smp.fences)) != ORCA_OK) return rc;
     Timed t(e, ORCA_PROF_SAMPLE, stream);
     if (gru.n_blocks)
       ORCA_LAUNCH_TIMED(k_begin_queries<true>, (unsigned)(gru.n_blocks + nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,

@@ -30,9 +30,53 @@ __device__ __forceinline__ void wave_narrow(const double* __restrict__ ts, int64
   }
 }
 
-__device__ __forceinline__ int64_t wave_lower_bound(const double* __restrict__ ts, int64_t lo, int64_t hi, double t,
-                                                    int lane) {
-  wave_narrow(ts, lo, hi, t, lane, 64);
+// Fence index (csr.hip builds it with the CSR): level 1 holds the LAST timestamp of every aligned block of
+// ORCA_FENCE_B0 = 32 entries of ts, level k+1 the last entry of every aligned block of 64 entries of level k.  A
+// 64-ary round of wave_narrow touches 64 different cache lines (and, in a hub's row, 64 different pages of a
+// gigabyte-sized array) to use 8 bytes of each: 11x the algorithmic bytes of the sampler.  With the
+// fences a round reads 64 CONTIGUOUS doubles instead.  Blocks are aligned to the global array, not to rows: for a row
+// [lo, hi) the fences with index in R_1 = [lo/32, hi/32) are entries of that row (fence j is entry 32j+31), so they
+// are sorted, and "the first fence >= t" names the block that holds the bound (clipped to the row; no such fence:
+// the bound is in the row's tail).  R_{k+1} = [s_k/64, e_k/64) in the same way.  The search walks down from the
+// first level whose range fits one wave; every level is one round trip, the result is a window of <= 32 entries.
+__device__ __forceinline__ void fence_narrow(const double* __restrict__ ts, const orca_fences& F, int64_t& lo, int64_t& hi,
+                                             double t, int lane, int window) {
+  if (hi - lo <= window) return;
+  if (!F.lvl[0]) { wave_narrow(ts, lo, hi, t, lane, window); return; }
+  // R_{k+1} = [lo >> (5 + 6k), hi >> (5 + 6k)): chained floor divisions are shifts (ORCA_FENCE_B0 = 32, then 64 a level)
+  static_assert(ORCA_FENCE_B0 == 32, "the shifts below assume 32-entry blocks");
+  int top = 0;
+#pragma unroll
+  for (int k = 1; k < ORCA_FENCE_LEVELS; ++k)
+    if (top == k - 1 && (hi >> (6 * k - 1)) - (lo >> (6 * k - 1)) > 64 && F.lvl[k]) top = k;
+  int64_t a = lo >> (5 + 6 * top), b = hi >> (5 + 6 * top);
+  if (b - a > 64) {       // (a row that needs more than ORCA_FENCE_LEVELS levels: not below 2^35 entries)
+    const int64_t end = b;
+    wave_narrow(F.lvl[top], a, b, t, lane, 63);
+    if (b < end) ++b;     // fence b is >= t: it stays in the range, so that "none found" keeps meaning "the tail"
+  }
+#pragma unroll
+  for (int k = ORCA_FENCE_LEVELS - 1; k >= 0; --k) {
+    if (k > top) continue;
+    const int64_t p = a + lane;
+    const bool less = p < b ? (F.lvl[k][p] < t) : false;
+    const int64_t j = a + __popcll(__ballot(less));          // first fence of [a, b) that is >= t, or b
+    const bool found = j < b;
+    if (k > 0) {
+      const int64_t sk = lo >> (6 * k - 1), ek = hi >> (6 * k - 1);       // R_k
+      a = j * 64 > sk ? j * 64 : sk;
+      b = found && j * 64 + 64 < ek ? j * 64 + 64 : ek;
+    } else {
+      lo = j * ORCA_FENCE_B0 > lo ? j * ORCA_FENCE_B0 : lo;
+      hi = found && j * ORCA_FENCE_B0 + ORCA_FENCE_B0 < hi ? j * ORCA_FENCE_B0 + ORCA_FENCE_B0 : hi;
+    }
+  }
+  if (hi - lo > window) wave_narrow(ts, lo, hi, t, lane, window);  // (window < 32: K > 32)
+}
+
+__device__ __forceinline__ int64_t wave_lower_bound(const double* __restrict__ ts, const orca_fences& F, int64_t lo,
+                                                    int64_t hi, double t, int lane) {
+  fence_narrow(ts, F, lo, hi, t, lane, 64);
   int64_t p = lo + lane;
   bool less = (p < hi) ? (ts[p] < t) : false;
   return lo + __popcll(__ballot(less));
@@ -43,7 +87,7 @@ __device__ __forceinline__ int64_t wave_lower_bound(const double* __restrict__ t
 // pass of the distinct-id work-list over [neighbours (Q*K positions) ; roots (Q positions)] (state.hip).
 __device__ __forceinline__ void sample_recent_wave(const int64_t* __restrict__ indptr, const int32_t* __restrict__ nbr,
                                                    const int32_t* __restrict__ eid, const double* __restrict__ ts,
-                                                   int64_t n_rows, int64_t v, double t, int64_t q, int64_t Q, int K,
+                                                   const orca_fences& F, int64_t n_rows, int64_t v, double t, int64_t q, int64_t Q, int K,
                                                    int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid,
                                                    float* __restrict__ o_et, float* __restrict__ o_dt, int* err_flag,
                                                    const orca_claim& claim, int lane) {
@@ -62,7 +106,7 @@ __device__ __forceinline__ void sample_recent_wave(const int64_t* __restrict__ i
     if (ok) {
       row_lo = lo = indptr[v];
       hi = indptr[v + 1];
-      wave_narrow(ts, lo, hi, t, lane, 64 - K);
+      fence_narrow(ts, F, lo, hi, t, lane, 64 - K);
     } else if (err_flag && lane == 0) {
       *err_flag = 1;
     }
@@ -91,7 +135,7 @@ __device__ __forceinline__ void sample_recent_wave(const int64_t* __restrict__ i
   if (v >= 0 && v < n_rows) {
     lo = indptr[v];
     int64_t hi = indptr[v + 1];
-    i = wave_lower_bound(ts, lo, hi, t, lane);
+    i = wave_lower_bound(ts, F, lo, hi, t, lane);
   } else if (err_flag && lane == 0) {
     *err_flag = 1;
   }
@@ -128,7 +172,7 @@ __host__ __device__ static inline uint64_t orca_mix64(uint64_t x) {  // splitmix
 
 __device__ __forceinline__ void sample_uniform_wave(const int64_t* __restrict__ indptr, const int32_t* __restrict__ nbr,
                                                     const int32_t* __restrict__ eid, const double* __restrict__ ts,
-                                                    int64_t n_rows, int64_t v, double t, int64_t q, int64_t Q, int K,
+                                                    const orca_fences& F, int64_t n_rows, int64_t v, double t, int64_t q, int64_t Q, int K,
                                                     uint64_t seed, int64_t key, int32_t* __restrict__ o_nbr,
                                                     int32_t* __restrict__ o_eid, float* __restrict__ o_et,
                                                     float* __restrict__ o_dt, int* err_flag, const orca_claim& claim,
@@ -140,7 +184,7 @@ __device__ __forceinline__ void sample_uniform_wave(const int64_t* __restrict__ 
   int64_t lo = 0, cnt = 0;
   if (v >= 0 && v < n_rows) {
     lo = indptr[v];
-    cnt = wave_lower_bound(ts, lo, indptr[v + 1], t, lane) - lo;
+    cnt = wave_lower_bound(ts, F, lo, indptr[v + 1], t, lane) - lo;
   } else if (err_flag && lane == 0) {
     *err_flag = 1;
   }
