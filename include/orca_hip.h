@@ -232,9 +232,9 @@ int orca_gru_backward(int msg_dim, const float* weight_ih, const float* weight_h
 
 /* dst_table[id] = src_table[id] (rows of ORCA_D floats) and, if last_update != NULL, last_update[id] =
  * msg_ts[id], for the first min(n, *n_dev) ids of a work-list: commits GRU rows held in the overlay into
- * the persistent memory (modules/memory_updater.py:36-39). */
+ * the persistent memory (modules/memory_updater.py:36-39).  Ids outside [0, n_nodes) are skipped. */
 int orca_commit_rows(const int32_t* ids, int64_t n, const int32_t* n_dev, const float* src_table,
-                     float* dst_table, float* last_update, const float* msg_ts, void* stream);
+                     float* dst_table, float* last_update, const float* msg_ts, int64_t n_nodes, void* stream);
 
 /* For every position p < n with pending[ids[p]]: memory[id] = overlay[id], last_update[id] = msg_ts[id]
  * (duplicates copy the same values).  modules/memory_updater.py:25-39 when the overlay already holds
@@ -255,9 +255,12 @@ int orca_worklist_build(const int32_t* ids32, int64_t n32, const int64_t* ids64,
                         int32_t* worklist, int32_t* count, void* stream);
 int orca_fill_i32(int32_t* p, int64_t n, int32_t v, void* stream);
 int orca_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream);
-/* flags[ids[i]] = v for i < n (ids int64, or the int32 work-list when ids64 == NULL) */
+/* flags[ids[i]] = v for i < n (ids int64, or the int32 work-list when ids64 == NULL).  Every id-indexed entry point
+ * of this header takes the size of the table it indexes and SKIPS ids outside it (a gather reads zeros): a bad id is
+ * never an out-of-bounds access; callers that want the reference's IndexError check their ids on the host, as
+ * orca_amd.api does for the NumPy ids the reference's interface passes. */
 int orca_set_flags(uint8_t* flags, const int64_t* ids64, const int32_t* ids32, int64_t n,
-                   const int32_t* n_dev, uint8_t v, void* stream);
+                   const int32_t* n_dev, uint8_t v, int64_t n_nodes, void* stream);
 
 /* ---- raw messages: model/tgn_model.py:131-141,172-191 + modules/memory.py:25-28 ----------- */
 
@@ -296,8 +299,8 @@ int orca_message_store(const int64_t* src, const int64_t* dst, const int64_t* ei
 int orca_history_push(float* emb, const float* x, const int64_t* ids, int64_t n, int64_t* slot,
                       int64_t epoch, int64_t n_nodes, void* stream);
 /* History.pull (history.py:32-36) / any row gather: out[p] = table[idx[p]], rows of `width` floats.
- * idx is int64, or int32 when idx64 == NULL. */
-int orca_gather_rows(const float* table, int64_t width, const int64_t* idx64, const int32_t* idx32,
+ * idx is int64, or int32 when idx64 == NULL; an index outside [0, n_rows) gives a row of zeros. */
+int orca_gather_rows(const float* table, int64_t n_rows, int64_t width, const int64_t* idx64, const int32_t* idx32,
                      int64_t n, float* out, void* stream);
 /* Gradient accumulation onto the rows that get_updated_memory produced (memory_updater.py:56-78): autograd's
  * index backward of `updated_memory[nodes]` (embedding_module.py:121,160), restricted to the flagged (pending) ids,
@@ -305,7 +308,7 @@ int orca_gather_rows(const float* table, int64_t width, const int64_t* idx64, co
  * orca_index_positions: pos[list[i]] = i for i < min(n, *n_dev) (list = the distinct pending ids, n_dev may be NULL).
  * orca_scatter_add_flagged: dst[pos[id]] += rows[p] (ORCA_D floats) for every p < n whose id = idx[p] has flags[id];
  * idx is int64, or int32 when idx64 == NULL; dst is zeroed by the caller. */
-int orca_index_positions(const int32_t* list, int64_t n, const int32_t* n_dev, int32_t* pos, void* stream);
+int orca_index_positions(const int32_t* list, int64_t n, const int32_t* n_dev, int32_t* pos, int64_t n_nodes, void* stream);
 int orca_scatter_add_flagged(const float* rows, const int64_t* idx64, const int32_t* idx32, int64_t n,
                              const uint8_t* flags, const int32_t* pos, int64_t n_nodes, float* dst, void* stream);
 /* find_uncached_out_of_batch_neighbors (modules/embedding_module.py:200-212): the distinct ids of nbr [n_nbr] (int32,
@@ -316,8 +319,8 @@ int orca_scatter_add_flagged(const float* rows, const int64_t* idx64, const int3
 int orca_find_uncached(const int32_t* nbr, int64_t n_nbr, const int64_t* batch_nodes, int64_t n_batch,
                        const uint8_t* cache_flag, int64_t* slot, int64_t epoch, int64_t n_nodes, uint32_t* bitmap,
                        int64_t* out, int64_t cap, int32_t* count, void* stream);
-/* out_table[ids[p]] = x[p] (ids unique; Memory.set_memory modules/memory.py:33-34) */
-int orca_scatter_rows(float* table, int64_t width, const int64_t* ids, int64_t n, const float* x,
+/* out_table[ids[p]] = x[p] (ids unique; Memory.set_memory modules/memory.py:33-34); ids outside [0, n_rows) are skipped */
+int orca_scatter_rows(float* table, int64_t n_rows, int64_t width, const int64_t* ids, int64_t n, const float* x,
                       void* stream);
 
 /* optimizer.step() of train.py:238 for torch.optim.Adam(tgn.parameters(), lr) (train.py:180; no weight decay, no

@@ -69,7 +69,7 @@ SIGNATURES = {
     "orca_tgat_blob_floats": (i64, [i32]),
     "orca_tgat_pack": (i32, [i32] + [vp] * 14),
     "orca_tgat_pack_gather": (i32, [i32] + [vp] * 6),
-    "orca_index_positions": (i32, [vp, i64, vp, vp, vp]),
+    "orca_index_positions": (i32, [vp, i64, vp, vp, i64, vp]),
     "orca_scatter_add_flagged": (i32, [vp, vp, vp, i64, vp, vp, i64, vp, vp]),
     "orca_gru_backward_workspace_floats": (i64, [i32, i64]),
     "orca_gru_backward": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 11),
@@ -82,19 +82,19 @@ SIGNATURES = {
     "orca_gru_blob_floats": (i64, [i32]),
     "orca_gru_pack": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "orca_gru_update": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
-    "orca_commit_rows": (i32, [vp, i64, vp, vp, vp, vp, vp, vp]),
+    "orca_commit_rows": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp]),
     "orca_persist_overlay": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp]),
     "orca_worklist_build": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, vp]),
     "orca_fill_i32": (i32, [vp, i64, i32, vp]),
     "orca_fill_u8": (i32, [vp, i64, u8, vp]),
-    "orca_set_flags": (i32, [vp, vp, vp, i64, vp, u8, vp]),
+    "orca_set_flags": (i32, [vp, vp, vp, i64, vp, u8, i64, vp]),
     "orca_segment_last": (i32, [vp, i64, vp, i64, i64, vp, vp]),
     "orca_segment_last_static": (i32, [vp, i64, i64, vp, vp]),
     "orca_segment_mean": (i32, [vp, i64, i64, vp, vp, vp, i64, i64, vp, vp, vp]),
     "orca_message_store": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, vp]),
     "orca_history_push": (i32, [vp, vp, vp, i64, vp, i64, i64, vp]),
-    "orca_gather_rows": (i32, [vp, i64, vp, vp, i64, vp, vp]),
-    "orca_scatter_rows": (i32, [vp, i64, vp, i64, vp, vp]),
+    "orca_gather_rows": (i32, [vp, i64, i64, vp, vp, i64, vp, vp]),
+    "orca_scatter_rows": (i32, [vp, i64, i64, vp, i64, vp, vp]),
     "orca_adam_step": (i32, [i32, vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, i64, vp]),
     "orca_find_uncached": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, vp]),
     "orca_engine_create": (i32, [ctypes.POINTER(EngineDesc), ctypes.POINTER(vp)]),

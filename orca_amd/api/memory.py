@@ -32,8 +32,14 @@ class Memory(nn.Module):
     return self.pending.cpu().numpy().astype(bool)
 
   def _ids(self, x):
+    """node ids -> int64 device tensor.  Host ids (the NumPy arrays the reference's interface passes) are range-checked
+    here and raise IndexError like the reference's NumPy indexing; ids that are already on the device are not read
+    back: the kernels skip the ones outside the table (include/orca_hip.h)."""
     if not isinstance(x, torch.Tensor):
-      x = torch.from_numpy(np.ascontiguousarray(x))
+      x = np.ascontiguousarray(x)
+      if x.size and (int(x.min()) < -self.n_nodes or int(x.max()) >= self.n_nodes):
+        raise IndexError(f"node id out of range for a memory of {self.n_nodes} nodes")
+      x = torch.from_numpy(np.where(x < 0, x + self.n_nodes, x)) if x.size and int(x.min()) < 0 else torch.from_numpy(x)
     return x.to(device=self.memory.device, dtype=torch.int64).contiguous()
 
   def store_raw_messages(self, nodes, messages, timestamps):

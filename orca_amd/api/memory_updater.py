@@ -80,7 +80,10 @@ class GRUMemoryUpdater(nn.Module):
   @staticmethod
   def _ids(memory, x):
     if not isinstance(x, torch.Tensor):
-      x = torch.from_numpy(np.ascontiguousarray(x))
+      x = np.ascontiguousarray(x)
+      if x.size and (int(x.min()) < 0 or int(x.max()) >= memory.n_nodes):
+        raise IndexError(f"node id out of range for a memory of {memory.n_nodes} nodes")
+      x = torch.from_numpy(x)
     return x.to(device=memory.memory.device, dtype=torch.int64).contiguous()
 
   @torch.no_grad()

@@ -829,9 +829,9 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
                            nullptr, stream_);
       if (rc != ORCA_OK) return rc;
     }
-    rc = orca_commit_rows(d.worklist, bound, d.count, d.overlay, d.memory, d.last_update, d.msg_ts, stream_);
+    rc = orca_commit_rows(d.worklist, bound, d.count, d.overlay, d.memory, d.last_update, d.msg_ts, d.n_nodes, stream_);
     if (rc != ORCA_OK) return rc;
-    return orca_set_flags(d.pending, d.nodes, nullptr, 2 * bs, nullptr, 0, stream_);
+    return orca_set_flags(d.pending, d.nodes, nullptr, 2 * bs, nullptr, 0, d.n_nodes, stream_);
   };
   auto store = [&]() -> int {     // tgn_model.py:131-141,172-191 + memory.py:25-28
     if (e->store_done) return ORCA_OK;   // the last attention layer stored the messages (orca_tgat_side)

@@ -445,25 +445,26 @@ namespace {
 __global__ __launch_bounds__(256) void k_commit_rows(const int32_t* __restrict__ ids, int64_t n_max,
                                                      const int32_t* __restrict__ n_dev, const float* __restrict__ src,
                                                      float* __restrict__ dst, float* last_update,
-                                                     const float* __restrict__ msg_ts) {
+                                                     const float* __restrict__ msg_ts, int64_t n_nodes) {
   int64_t n = n_max;
   if (n_dev) { int64_t nd = *n_dev; n = nd < n ? nd : n; }
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= n) return;
   const int64_t id = ids[r];
+  if (id < 0 || id >= n_nodes) return;
   for (int c = lane; c < D; c += 64) dst[id * D + c] = src[id * D + c];
   if (last_update && lane == 0) last_update[id] = msg_ts[id];
 }
 }  // namespace
 
 ORCA_API int orca_commit_rows(const int32_t* ids, int64_t n, const int32_t* n_dev, const float* src_table,
-                              float* dst_table, float* last_update, const float* msg_ts, void* stream) {
-  ORCA_REQUIRE(n >= 0, "orca_commit_rows: n < 0");
+                              float* dst_table, float* last_update, const float* msg_ts, int64_t n_nodes, void* stream) {
+  ORCA_REQUIRE(n >= 0 && n_nodes >= 0, "orca_commit_rows: n < 0");
   if (n == 0) return ORCA_OK;
   ORCA_REQUIRE(ids && src_table && dst_table && (!last_update || msg_ts), "orca_commit_rows: null pointer");
   k_commit_rows<<<(unsigned)ceil_div64(n, 4), 256, 0, (hipStream_t)stream>>>(ids, n, n_dev, src_table, dst_table,
-                                                                            last_update, msg_ts);
+                                                                            last_update, msg_ts, n_nodes);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

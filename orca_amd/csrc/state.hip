@@ -71,12 +71,12 @@ __global__ __launch_bounds__(1024) void k_worklist_append(const int32_t* __restr
 }
 
 __global__ void k_set_flags(uint8_t* flags, const int64_t* ids64, const int32_t* ids32, int64_t n,
-                            const int32_t* n_dev, uint8_t v) {
+                            const int32_t* n_dev, uint8_t v, int64_t n_nodes) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n_dev && i >= *n_dev) return;
   if (i >= n) return;
   int64_t id = ids64 ? ids64[i] : (int64_t)ids32[i];
-  flags[id] = v;
+  if (id >= 0 && id < n_nodes) flags[id] = v;       // ids outside the table are skipped, as everywhere in this file
 }
 
 // last-occurrence election: slot[id] = max over positions of (epoch + p)
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_push_rows(float* __restrict__ emb, cons
   for (int c = lane; c < D; c += 64) emb[id * D + c] = x[p * D + c];
 }
 
-__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table, int64_t width,
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table, int64_t n_rows, int64_t width,
                                                      const int64_t* __restrict__ idx64,
                                                      const int32_t* __restrict__ idx32, int64_t n,
                                                      float* __restrict__ out) {
@@ -180,15 +180,16 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
   const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= n) return;
   const int64_t r = idx64 ? idx64[p] : (int64_t)idx32[p];
-  for (int64_t c = lane; c < width; c += 64) out[p * width + c] = table[r * width + c];
+  const bool ok = r >= 0 && r < n_rows;       // a row index outside the table reads as zeros
+  for (int64_t c = lane; c < width; c += 64) out[p * width + c] = ok ? table[r * width + c] : 0.f;
 }
 
 // pos[list[i]] = i for the first min(n, *n_dev) entries of a list of distinct ids
 __global__ void k_index_positions(const int32_t* __restrict__ list, int64_t n, const int32_t* __restrict__ n_dev,
-                                  int32_t* __restrict__ pos) {
+                                  int32_t* __restrict__ pos, int64_t n_nodes) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t m = n_dev ? (*n_dev < n ? *n_dev : n) : n;
-  if (i < m) pos[list[i]] = (int32_t)i;
+  if (i < m && list[i] >= 0 && list[i] < n_nodes) pos[list[i]] = (int32_t)i;
 }
 // dst[pos[id]] += rows[p] for every position p whose id carries a flag.  Several positions share an id -- in a
 // power-law batch a hub id thousands of them -- and fp32 atomics on one row serialise at L2 (95 us for 41 k rows), so a
@@ -266,13 +267,14 @@ __global__ __launch_bounds__(1024) void k_scatter_add_flagged(const float* __res
   }
 }
 
-__global__ __launch_bounds__(256) void k_scatter_rows(float* __restrict__ table, int64_t width,
+__global__ __launch_bounds__(256) void k_scatter_rows(float* __restrict__ table, int64_t n_rows, int64_t width,
                                                       const int64_t* __restrict__ ids, int64_t n,
                                                       const float* __restrict__ x) {
   const int lane = threadIdx.x & 63;
   const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= n) return;
   const int64_t r = ids[p];
+  if (r < 0 || r >= n_rows) return;
   for (int64_t c = lane; c < width; c += 64) table[r * width + c] = x[p * width + c];
 }
 
@@ -398,10 +400,10 @@ int orca_worklist_append(const int32_t* ids32, int64_t n32, const int64_t* ids64
 }
 
 ORCA_API int orca_set_flags(uint8_t* flags, const int64_t* ids64, const int32_t* ids32, int64_t n,
-                            const int32_t* n_dev, uint8_t v, void* stream) {
-  ORCA_REQUIRE(flags && n >= 0 && (n == 0 || ids64 || ids32), "orca_set_flags: bad arguments");
+                            const int32_t* n_dev, uint8_t v, int64_t n_nodes, void* stream) {
+  ORCA_REQUIRE(flags && n >= 0 && n_nodes >= 0 && (n == 0 || ids64 || ids32), "orca_set_flags: bad arguments");
   if (n == 0) return ORCA_OK;
-  k_set_flags<<<blocks(n, 256), 256, 0, (hipStream_t)stream>>>(flags, ids64, ids32, n, n_dev, v);
+  k_set_flags<<<blocks(n, 256), 256, 0, (hipStream_t)stream>>>(flags, ids64, ids32, n, n_dev, v, n_nodes);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -538,19 +540,20 @@ int orca_history_push_winners(float* emb, const float* x, const int64_t* ids, in
   return ORCA_OK;
 }
 
-ORCA_API int orca_gather_rows(const float* table, int64_t width, const int64_t* idx64, const int32_t* idx32,
+ORCA_API int orca_gather_rows(const float* table, int64_t n_rows, int64_t width, const int64_t* idx64, const int32_t* idx32,
                               int64_t n, float* out, void* stream) {
-  ORCA_REQUIRE(n >= 0 && width > 0 && (n == 0 || (table && out && (idx64 || idx32))), "orca_gather_rows: bad arguments");
+  ORCA_REQUIRE(n >= 0 && width > 0 && n_rows >= 0 && (n == 0 || (table && out && (idx64 || idx32))), "orca_gather_rows: bad arguments");
   if (n == 0) return ORCA_OK;
-  k_gather_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(table, width, idx64, idx32, n, out);
+  k_gather_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(table, n_rows, width, idx64, idx32, n, out);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
 
-ORCA_API int orca_index_positions(const int32_t* list, int64_t n, const int32_t* n_dev, int32_t* pos, void* stream) {
-  ORCA_REQUIRE(n >= 0 && (n == 0 || (list && pos)), "orca_index_positions: bad arguments");
+ORCA_API int orca_index_positions(const int32_t* list, int64_t n, const int32_t* n_dev, int32_t* pos, int64_t n_nodes,
+                                  void* stream) {
+  ORCA_REQUIRE(n >= 0 && n_nodes >= 0 && (n == 0 || (list && pos)), "orca_index_positions: bad arguments");
   if (n == 0) return ORCA_OK;
-  k_index_positions<<<blocks(n, 256), 256, 0, (hipStream_t)stream>>>(list, n, n_dev, pos);
+  k_index_positions<<<blocks(n, 256), 256, 0, (hipStream_t)stream>>>(list, n, n_dev, pos, n_nodes);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -566,11 +569,11 @@ ORCA_API int orca_scatter_add_flagged(const float* rows, const int64_t* idx64, c
   return ORCA_OK;
 }
 
-ORCA_API int orca_scatter_rows(float* table, int64_t width, const int64_t* ids, int64_t n, const float* x,
+ORCA_API int orca_scatter_rows(float* table, int64_t n_rows, int64_t width, const int64_t* ids, int64_t n, const float* x,
                                void* stream) {
-  ORCA_REQUIRE(n >= 0 && width > 0 && (n == 0 || (table && ids && x)), "orca_scatter_rows: bad arguments");
+  ORCA_REQUIRE(n >= 0 && width > 0 && n_rows >= 0 && (n == 0 || (table && ids && x)), "orca_scatter_rows: bad arguments");
   if (n == 0) return ORCA_OK;
-  k_scatter_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(table, width, ids, n, x);
+  k_scatter_rows<<<blocks(n, 4), 256, 0, (hipStream_t)stream>>>(table, n_rows, width, ids, n, x);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

@@ -357,7 +357,7 @@ def worklist_build(ids32, ids64, flags, slot, epoch, worklist, count):
 def set_flags(flags, ids64=None, ids32=None, n=None, n_dev=None, v=1):
   if n is None:
     n = (ids64 if ids64 is not None else ids32).numel()
-  check(_lib.load().orca_set_flags(ptr(flags), ptr(ids64), ptr(ids32), int(n), ptr(n_dev), int(v), stream()),
+  check(_lib.load().orca_set_flags(ptr(flags), ptr(ids64), ptr(ids32), int(n), ptr(n_dev), int(v), flags.numel(), stream()),
         "orca_set_flags")
 
 
@@ -393,7 +393,7 @@ def history_push(emb, x, ids, slot, epoch):
 
 
 def index_positions(lst, n, n_dev, pos):
-  check(_lib.load().orca_index_positions(ptr(lst), int(n), ptr(n_dev), ptr(pos), stream()), "orca_index_positions")
+  check(_lib.load().orca_index_positions(ptr(lst), int(n), ptr(n_dev), ptr(pos), pos.numel(), stream()), "orca_index_positions")
 
 
 def scatter_add_flagged(rows, idx, flags, pos, dst):
@@ -414,12 +414,12 @@ def gather_rows(table, idx, out=None):
   i32 = idx if idx.dtype == torch.int32 else None
   if i64 is None and i32 is None:
     raise TypeError("gather_rows: idx must be int64 or int32")
-  check(_lib.load().orca_gather_rows(ptr(table), width, ptr(i64), ptr(i32), n, ptr(out), stream()), "orca_gather_rows")
+  check(_lib.load().orca_gather_rows(ptr(table), table.shape[0], width, ptr(i64), ptr(i32), n, ptr(out), stream()), "orca_gather_rows")
   return out
 
 
 def scatter_rows(table, ids, x):
-  check(_lib.load().orca_scatter_rows(ptr(table), table.shape[1], ptr(ids), ids.numel(), ptr(x), stream()),
+  check(_lib.load().orca_scatter_rows(ptr(table), table.shape[0], table.shape[1], ptr(ids), ids.numel(), ptr(x), stream()),
         "orca_scatter_rows")
 
 

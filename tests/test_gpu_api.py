@@ -391,3 +391,34 @@ def test_training_loop_through_the_drop_in(api, reuse, L):
   assert len(kink_batches) <= 1, kink_batches
   for k in grads:        # every parameter the loss reaches has been trained (the GRU from the second batch on)
     assert not torch.equal(named[k].detach().reshape(-1), sd[k].to(DEV).reshape(-1)), f"{k} did not move"
+
+
+def test_bad_node_ids(api):
+  """an id outside the table must never be an out-of-bounds device access.  Host ids (what the reference's
+  interface passes) raise IndexError in the mirror, as NumPy indexing does upstream; device ids reach the kernels,
+  which skip them (a gather reads zeros)."""
+  from orca_amd import ops
+  mem = api.Memory(n_nodes=50, memory_dimension=100, input_dimension=0, message_dimension=472, device=DEV)
+  with pytest.raises(IndexError):
+    mem.get_memory(np.array([3, 50]))
+  with pytest.raises(IndexError):
+    mem.set_memory(np.array([-51]), torch.zeros(1, 100, device=DEV))
+  with pytest.raises(IndexError):
+    mem.store_raw_messages(np.array([7, 99]), torch.zeros(2, 472, device=DEV), torch.zeros(2, device=DEV))
+  table = torch.arange(50 * 100, dtype=torch.float32, device=DEV).view(50, 100)
+  bad = torch.tensor([4, 50, -1, 49, 1 << 40], dtype=torch.int64, device=DEV)
+  got = ops.gather_rows(table, bad)
+  assert torch.equal(got[0], table[4]) and torch.equal(got[3], table[49])
+  assert float(got[1].abs().max()) == 0.0 and float(got[2].abs().max()) == 0.0 and float(got[4].abs().max()) == 0.0
+  before = table.clone()
+  ops.scatter_rows(table, bad, torch.ones(5, 100, device=DEV))
+  assert torch.equal(table[4], torch.ones(100, device=DEV)) and torch.equal(table[49], torch.ones(100, device=DEV))
+  keep = torch.ones(50, dtype=torch.bool, device=DEV)
+  keep[4] = keep[49] = False
+  assert torch.equal(table[keep], before[keep])
+  flags = torch.zeros(50, dtype=torch.uint8, device=DEV)
+  ops.set_flags(flags, ids64=bad, v=1)
+  assert int(flags.sum()) == 2 and int(flags[4]) == 1 and int(flags[49]) == 1
+  pos = torch.full((50,), -7, dtype=torch.int32, device=DEV)
+  ops.index_positions(torch.tensor([9, 77, -3, 2], dtype=torch.int32, device=DEV), 4, None, pos)
+  assert int(pos[9]) == 0 and int(pos[2]) == 3 and int((pos == -7).sum()) == 48
