@@ -157,6 +157,10 @@ def ptr(t):
   if t is None:
     return None
   if hasattr(t, "data_ptr"):
+    # torch tensors are DEVICE memory at this boundary (host arrays are NumPy arrays): a CPU tensor handed to a kernel
+    # is a GPU memory fault on a machine that has a GPU, not an error code
+    if not t.is_cuda:
+      raise OrcaError("orca_amd: a CPU tensor was passed where device memory is expected (there is no CPU fallback)")
     assert t.is_contiguous(), "orca_amd: tensor must be contiguous"
     return t.data_ptr()
   return t.ctypes.data

@@ -148,6 +148,10 @@ class GraphAttentionEmbedding(nn.Module):
     for layer in range(2, n_layers + 1):
       h = self.histories[layer - 2]
       h.update_times[nodes.cpu()] = batch_id                       # :107
+      if getattr(self.args, "gradient", False) and torch.is_grad_enabled() and emb.requires_grad:
+        rows = h.push_and_pull(emb, nodes, nbr.reshape(-1))         # :112, rows of this batch keep their graph
+        emb = self._attend(layer, n, K, nbr, eid, dt, dict(table=emb), None, dict(table=rows), None)
+        continue
       h.push(emb, nodes)                                            # :109
       emb = self._attend(layer, n, K, nbr, eid, dt, dict(table=emb), None, dict(table=h.emb), nbr)   # :110 pull, fused
     return emb

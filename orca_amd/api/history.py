@@ -63,8 +63,24 @@ class History(torch.nn.Module):
     self._epoch += ids.numel() + 1
 
   def push_and_pull(self, x, push_inds, pull_inds):
-    """history.py:42-46 (forward semantics; the table is rebound to a fresh copy as upstream)."""
-    self.push(x, push_inds)
-    out = self.pull(pull_inds)
-    self.emb = self.emb.clone()
-    return out
+    """history.py:42-46, the --gradient variant (train.py:43): the pulled rows that were pushed in this call stay
+    connected to x in the autograd graph (orca::history_pull_pushed); the other rows are data.  Upstream rebinds the
+    table to a copy that carries the graph until detach_history() (train.py:263); here the table itself never carries
+    one -- the graph hangs on the returned rows -- so there is nothing to copy or detach."""
+    ids = self._ids(push_inds)
+    pull = self._ids(pull_inds).reshape(-1)
+    epoch = self._epoch
+    self.push(x, ids)
+    if not (torch.is_grad_enabled() and x.requires_grad):
+      return self.pull(pull)
+    from .. import torch_ops  # noqa: F401
+    with torch.no_grad():
+      n = self.emb.shape[0]
+      if getattr(self, "_pushed", None) is None or self._pushed.numel() != n or self._pushed.device != self.emb.device:
+        self._pushed = torch.zeros(n, dtype=torch.uint8, device=self.emb.device)
+        self._wpos = torch.zeros(n, dtype=torch.int32, device=self.emb.device)
+      ops.fill_u8(self._pushed, 0)
+      ops.set_flags(self._pushed, ids64=ids, v=1)
+      # the push stamped slot[id] = epoch + (position of the last occurrence of id)
+      self._wpos[ids] = (self._slot[ids] - epoch).to(torch.int32)
+    return torch.ops.orca.history_pull_pushed(self.emb, x, pull, self._pushed.clone(), self._wpos.clone())

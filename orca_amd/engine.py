@@ -34,7 +34,8 @@ D = ORCA_D
 
 class OrcaEngine:
   def __init__(self, state_dict, edge_feats, n_nodes, n_layers, n_neighbors, reuse=False, budget=0,
-               device="cuda:0", group=None, sampling="recent", seed=0, exchange_cap=None, pretend=None, dropout=0.0):
+               device="cuda:0", group=None, sampling="recent", seed=0, exchange_cap=None, pretend=None, dropout=0.0,
+               gradient=False):
     """state_dict: the TGN state_dict of the reference (key names of SURVEY §8b); edge_feats
     [n_edges+1, d_e] (row 0 = padding); n_nodes = number of table rows (args.n_nodes, train.py:129).
     sampling: "recent" (the reference's NeighborFinder) or "uniform" (seeded, not in the reference: BASELINE
@@ -62,6 +63,9 @@ class OrcaEngine:
     # attention-weight dropout of train_step (train.py:30 --drop_out, nn.MultiheadAttention's); the forward-only
     # entry points never drop (module.eval()).  Counter RNG keyed (seed, batch, layer, query, head, slot).
     self.dropout = float(dropout)
+    # train.py:43 --gradient (history.py:42-46 push_and_pull): in train_step the history rows pushed in the same batch
+    # stay connected to the layer output that produced them (Path B); the forward values are the same either way
+    self.gradient = bool(gradient)
     self.exchange_cap = exchange_cap
     self._sharded = False    # True: memory / last_update / messages / msg_ts rows are current only on their owner
     # the reference freezes its time encoder (model/time_encoding.py:20-23: requires_grad False, forward under no_grad):
@@ -649,7 +653,7 @@ class OrcaEngine:
     attention layers (Path A: also through the inner-layer embeddings of the sampled neighbours) into the
     updated-memory rows of pending ids and from there into the GRU; history rows, stored messages and the memory
     table are detached (history.py:32-40: push / pull run under no_grad in the default configuration, without
-    train.py:43's --gradient switch, which is not built; memory.py:45-47).  An optimizer updates self.params in place; call
+    train.py:43's --gradient switch: OrcaEngine(gradient=True); memory.py:45-47).  An optimizer updates self.params in place; call
     refresh() afterwards.  With several ranks every rank back-propagates its query slice and the parameter
     gradients are all-reduced.  The link decoder (two small dense layers) runs as library
     GEMMs under torch autograd, like its forward in compute_edge_probabilities."""
@@ -686,7 +690,15 @@ class OrcaEngine:
                     (my_nodes, nbr.view(-1))))
       for layer in range(2, self.L + 1):
         full = self._all_gather_rows(emb, Q, per)
-        ops.history_push(self.hist[layer - 2], full, nodes, self.slot, self._slot_epoch(Q))
+        ep = self._slot_epoch(Q)
+        ops.history_push(self.hist[layer - 2], full, nodes, self.slot, ep)
+        if self.gradient and layer == 2:      # which ids this batch pushed, and which root position won each (SURVEY H7:
+          if getattr(self, "_pushed", None) is None:                       # the push stamped slot[id] = ep + position)
+            self._pushed = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+            self._wpos = torch.zeros(self.N, dtype=torch.int32, device=dev)
+          ops.fill_u8(self._pushed, 0)
+          ops.set_flags(self._pushed, ids64=nodes, v=1)
+          self._wpos[nodes] = (self.slot[nodes] - ep).to(torch.int32)
         prev = emb
         dk = self._dropout_kw(layer, lo)
         emb = self._attend(layer, n, nbr, eid, dt, True, prev, None, self.hist[layer - 2], nbr, False, drop=dk)
@@ -750,8 +762,14 @@ class OrcaEngine:
         d_time[1] += tb
       if sink == "cat":                                # Path A: the neighbours' rows are embeddings of the level below
         d = torch.cat([d_src, d_nbr])
-      elif sink is None:                               # Path B inner layer: history rows are detached
-        d = d_src
+      elif sink is None:                               # Path B inner layer: history rows are detached (history.py:32-40),
+        d = d_src                                      # except, with --gradient, those pushed in this batch (:42-46)
+        if self.gradient:
+          extra = torch.zeros(Q, D, dtype=torch.float32, device=dev)
+          ops.scatter_add_flagged(d_nbr, nbr.view(-1), self._pushed, self._wpos, extra)
+          if self.world > 1:
+            dist_utils.all_reduce_sum(extra.view(-1), self.group)
+          d = d_src + extra[lo:hi]
       else:
         into_memory = (sink, d_src, d_nbr)
     # ---- into the updated-memory rows of the pending ids this slice read, then through the GRU ----

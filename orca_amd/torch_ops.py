@@ -197,5 +197,31 @@ def history_pull(emb: Tensor, ids: Tensor) -> Tensor:
   return ops.gather_rows(emb, ids)
 
 
+# ---- history with gradients (train.py:43 --gradient; history.py:42-46 push_and_pull) ----------------------------
+@_lib.custom_op("orca::history_pull_pushed", mutates_args=())
+def history_pull_pushed(emb: Tensor, x: Tensor, pull_ids: Tensor, pushed: Tensor, winner_pos: Tensor) -> Tensor:
+  """out[p] = emb[pull_ids[p]] AFTER x has been pushed into emb (the caller did that, under no_grad), as a node of
+  the autograd graph: the rows that were pushed in this batch are x's rows (pushed[id] != 0, winner_pos[id] = the
+  position in x that won the push), and their gradient goes back to x; the other rows are history: data."""
+  return ops.gather_rows(emb, pull_ids)
+
+
+def _hpp_setup(ctx, inputs, output):
+  emb, x, pull_ids, pushed, winner_pos = inputs
+  ctx.n = x.shape[0]
+  ctx.save_for_backward(pull_ids, pushed, winner_pos)
+
+
+def _hpp_backward(ctx, g_out):
+  pull_ids, pushed, winner_pos = ctx.saved_tensors
+  g_x = torch.zeros(ctx.n, D, dtype=torch.float32, device=g_out.device)
+  if pull_ids.numel() and ctx.n:
+    ops.scatter_add_flagged(g_out.contiguous(), pull_ids, pushed, winner_pos, g_x)
+  return None, g_x, None, None, None
+
+
+_lib.register_autograd("orca::history_pull_pushed", _hpp_backward, setup_context=_hpp_setup)
+
+
 OPS = ("sample_recent", "sample_uniform", "tgat_dense", "tgat_gather", "gru_cell", "message_store", "history_push",
-       "history_pull")
+       "history_pull", "history_pull_pushed")

@@ -310,14 +310,15 @@ def test_eval_edge_prediction_drives_the_hip_model(api, golden):
   assert ap == np.mean(aps) and 0.0 <= auc <= 1.0 and 0.0 <= acc <= 1.0
 
 
-@pytest.mark.parametrize("reuse,L", [(True, 2), (False, 2), (False, 1)])
-def test_training_loop_through_the_drop_in(api, reuse, L):
+@pytest.mark.parametrize("reuse,L,hgrad", [(True, 2, False), (False, 2, False), (False, 1, False), (True, 2, True), (True, 3, True)])
+def test_training_loop_through_the_drop_in(api, reuse, L, hgrad):
   """The reference's training loop shape (train.py:206-264: compute_edge_probabilities -> BCE on pos / neg ->
   loss.backward() -> Adam step) on orca_amd.api.TGN: the loss back-propagates through the custom ops
   (orca::tgat_gather, orca::gru_cell; orca_amd/torch_ops.py) into the attention layers, the GRU and the link decoder.
   Gradients and the parameters after each Adam step must match OrcaEngine.train_step / step_optimizer (whose
   gradients tests/test_gpu_backward.py checks against torch autograd of the oracle) at 2e-5; the time encoder stays
-  frozen as upstream (model/time_encoding.py:20-23).  Dropout 0 (the mirror applies none)."""
+  frozen as upstream (model/time_encoding.py:20-23).  Dropout 0.  hgrad: args.gradient (train.py:43), the history
+  variant whose rows pushed in the same batch keep their graph (orca::history_pull_pushed)."""
   from orca_amd import ops, synth
   from orca_amd.engine import OrcaEngine
   N, E, K, d_e, bs = 1500, 30000, 10, 172, 150
@@ -325,7 +326,7 @@ def test_training_loop_through_the_drop_in(api, reuse, L):
   ef = synth.edge_features(E, d_e, "cuda:0")
   sd = synth.tgn_state_dict(d_e, L, seed=2)
   csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
-  args = argparse.Namespace(n_nodes=N + 1, n_edges=E + 1, reuse=reuse, budget=0, gradient=False, bs=bs, n_degree=K)
+  args = argparse.Namespace(n_nodes=N + 1, n_edges=E + 1, reuse=reuse, budget=0, gradient=hgrad, bs=bs, n_degree=K)
   nf = api.NeighborFinder(None, None, None, device=DEV, _csr=csr)
   tgn = api.TGN(neighbor_finder=nf, node_features=None, edge_features=ef, device=DEV, n_layers=L, n_heads=2, dropout=0.0,
                 n_neighbors=K, args=args)
@@ -333,7 +334,7 @@ def test_training_loop_through_the_drop_in(api, reuse, L):
   # (embedding_module.time_encoder is the same module as time_encoder, as upstream: its keys alias the loaded ones)
   assert not [k for k in missing.missing_keys if not k.startswith("embedding_module.time_encoder.")], missing
   tgn.train()
-  eng = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=0, device="cuda:0")
+  eng = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=0, device="cuda:0", gradient=hgrad)
   eng.set_neighbor_finder(csr)
   opt = torch.optim.Adam(tgn.parameters(), lr=1e-3)               # train.py:180
   eng.optimizer(lr=1e-3)

@@ -162,16 +162,19 @@ def test_gru_backward(ops, msg_dim, n, gather):
   assert_close_fp32(got[5].cpu().numpy(), hr.grad.numpy(), TOL, "gru d_h")
 
 
-@pytest.mark.parametrize("reuse,L,bs,drop", [(True, 2, 150, 0.0), (False, 2, 150, 0.0), (False, 1, 150, 0.0), (True, 2, 1365, 0.0),
-                                              (True, 2, 150, 0.4), (False, 2, 150, 0.4)])
-def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop):
+@pytest.mark.parametrize("reuse,L,bs,drop,hgrad", [(True, 2, 150, 0.0, False), (False, 2, 150, 0.0, False), (False, 1, 150, 0.0, False),
+                                                    (True, 2, 1365, 0.0, False), (True, 2, 150, 0.4, False), (False, 2, 150, 0.4, False),
+                                                    (True, 2, 150, 0.0, True), (True, 2, 1365, 0.4, True)])
+def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop, hgrad):
   """OrcaEngine.train_step (Path B with 2 layers; Path A, the exact recursion, with 2 layers and with 1 layer = the
   reference's default configuration): loss and every parameter gradient against torch autograd of the oracle's
   pieces composed as tgn_model.py:95-157 / embedding_module.py:116-182 compose them, on a warmed-up state (pending
   messages, pushed history); and the state after the step equals the forward-only step's.  bs = 1365 is the bench's
   batch shape (4095 roots: every split-K and tile variant of the backward GEMM is in play).  drop > 0: the
   attention-weight dropout of train.py:30 -- the checker multiplies its softmax by the keep masks the kernels used
-  (orca_tgat_dropout_mask; RNG stream unpinned, masked arithmetic pinned)."""
+  (orca_tgat_dropout_mask; RNG stream unpinned, masked arithmetic pinned).  hgrad: the --gradient history variant
+  (train.py:43, history.py:42-46): the rows pushed in this batch keep their graph -- in the checker the winning
+  (last) occurrence of every root id is written into the history table by a differentiable index_put."""
   from orca_amd import synth
   from orca_amd.engine import OrcaEngine
   N, E, K, d_e = 1500, 30000, 10, 172
@@ -182,7 +185,7 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop):
   csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
   engs = []
   for _ in range(2):
-    e = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=0, device="cuda:0", dropout=drop, seed=11)
+    e = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=0, device="cuda:0", dropout=drop, seed=11, gradient=hgrad)
     e.set_neighbor_finder(csr)
     e.train_time_encoder = True     # the kernels' time-encoder gradient is checked too (frozen upstream: off by default)
     engs.append(e)
@@ -235,8 +238,13 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop):
   nc = nodes.cpu()
   if reuse:
     emb1 = layer(0, mem2[nc], mem2[s0[0].flatten()].view(Q, K, 100), s0)
-    hist2 = hist.clone()
-    hist2[nc] = emb1.detach()           # single-threaded index_put: the last occurrence wins
+    if hgrad:
+      last = {int(v): i for i, v in enumerate(nc.tolist())}           # id -> its last position
+      widx = torch.tensor(sorted(last.values()), dtype=torch.int64)
+      hist2 = hist.index_put((nc[widx],), emb1[widx])                 # differentiable: gradients reach emb1's winning rows
+    else:
+      hist2 = hist.clone()
+      hist2[nc] = emb1.detach()           # single-threaded index_put: the last occurrence wins
     top = layer(1, emb1, hist2[s0[0].flatten()].view(Q, K, 100), s0)
   elif L == 1:
     top = layer(0, mem2[nc], mem2[s0[0].flatten()].view(Q, K, 100), s0)
