@@ -544,36 +544,44 @@ class OrcaEngine:
       self._bitmap = torch.zeros((self.N + 31) // 32, dtype=torch.int32, device=self.device)
     return ops.find_uncached(nbr, nodes, self.cache_flag[0], self.slot, self._slot_epoch(1), self._bitmap)
 
-  def _attend_partitioned(self, layer, n, nbr, eid, dt, train, src_table, src_idx, nbr_table, from_memory):
-    """_attend over this rank's contiguous share of the n queries, rows all-gathered back to [n, D]"""
+  def _attend_partitioned(self, layer, n, nbr, eid, dt, train, src_table, src_idx, nbr_table, from_memory, drop=False):
+    """_attend over this rank's contiguous share of the n queries, rows all-gathered back to [n, D].  drop: apply
+    train_step's attention-weight dropout (keyed by the row's index among the n queries, whatever the slicing)."""
     if self.world == 1:
-      return self._attend(layer, n, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr, from_memory)
+      return self._attend(layer, n, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr, from_memory,
+                          drop=self._dropout_kw(layer, 0) if drop else None)
     lo, hi, per = self._slice(n)
     if src_idx is None:                               # dense source rows: row q belongs to query q
       src_table = src_table[lo:hi]
     else:
       src_idx = src_idx[lo:hi]
     part = self._attend(layer, hi - lo, nbr[lo:hi], eid[lo:hi], dt[lo:hi], train, src_table, src_idx, nbr_table,
-                        nbr[lo:hi], from_memory)
+                        nbr[lo:hi], from_memory, drop=self._dropout_kw(layer, lo) if drop else None)
     return self._all_gather_rows(part, n, per)
 
   # Path C: embedding_module.py:215-285.  Its control flow depends on global sets (which neighbours are cached), so
   # every rank samples all the queries and derives the same sets; the attention evaluations -- the cost -- are cut
   # into per-rank query slices and their rows all-gathered.
-  def _embed_budget(self, nodes, ts, n_layers, cache_plan, train):
+  def _embed_budget(self, nodes, ts, n_layers, cache_plan, train, rec=None):
+    """rec (train_step): a list that receives, innermost layer first, what the backward re-reads of every attention
+    evaluation -- (layer, samples, source ids or rows, history table) -- and switches train_step's dropout on."""
     n = nodes.numel()
     nbr, eid, dt = self._sample(nodes, ts)
     if n_layers == 1:                                 # :224-246
+      n32 = nodes.to(torch.int32)
       if train:
         self._overlay_updated_memory(nbr, nodes)
-      return self._attend_partitioned(1, n, nbr, eid, dt, train, self.memory, nodes.to(torch.int32), self.memory, True)
+      if rec is not None:
+        self._cnt_ready = self._fetch_count()
+        rec.append((1, (nbr, eid, dt), (nodes, n32), None))
+      return self._attend_partitioned(1, n, nbr, eid, dt, train, self.memory, n32, self.memory, True, drop=rec is not None)
     unc = self._find_uncached(nodes, nbr)             # :251
     if unc.numel():                                   # :253-260
       c_nodes = torch.cat([nodes, unc])
       c_ts = torch.cat([ts, ts.max().expand(unc.numel())])
     else:
       c_nodes, c_ts = nodes, ts
-    comb = self._embed_budget(c_nodes, c_ts, n_layers - 1, cache_plan, train)        # :273
+    comb = self._embed_budget(c_nodes, c_ts, n_layers - 1, cache_plan, train, rec)   # :273
     h = self.hist[n_layers - 2]
     ops.history_push(h, comb, c_nodes, self.slot, self._slot_epoch(c_nodes.numel()))  # :186-197
     flag = self.cache_flag[n_layers - 2]
@@ -583,7 +591,9 @@ class OrcaEngine:
         ops.set_flags(flag, ids64=cache_plan, v=1)
     else:                                             # history.py:30
       ops.set_flags(flag, ids64=c_nodes, v=1)
-    return self._attend_partitioned(n_layers, n, nbr, eid, dt, train, comb, None, h, False)
+    if rec is not None:
+      rec.append((n_layers, (nbr, eid, dt), comb, h))
+    return self._attend_partitioned(n_layers, n, nbr, eid, dt, train, comb, None, h, False, drop=rec is not None)
 
   # -------------------------------------------------------------------------------------------
   def compute_temporal_embeddings(self, src, dst, neg, ts, eidx, train=True, cache_plan=None, gather_output=True):
@@ -643,10 +653,11 @@ class OrcaEngine:
     return s[:n].sigmoid(), s[n:].sigmoid()
 
   # -------------------------------------------------------------------------------------------
-  def train_step(self, src, dst, neg, ts, eidx):
+  def train_step(self, src, dst, neg, ts, eidx, cache_plan=None):
     """One training batch of train.py:200-246 up to (not including) optimizer.step(): the train-ordered forward
     of compute_edge_probabilities (tgn_model.py:95-157), the loss BCE(pos, 1) + BCE(neg, 0) (train.py:231-233) and
-    its backward.  Path A (exact recursion) and Path B (`reuse`); no budgeted reuse; attention-weight dropout as the engine was built
+    its backward.  Path A (exact recursion), Path B (`reuse`) and Path C (`reuse` with a budget: pass the batch's
+    cache_plan as to compute_temporal_embeddings); attention-weight dropout as the engine was built
     (dropout=..., train.py:30; counter RNG, see include/orca_hip.h).  Returns
     (loss, grads) with grads keyed like the state_dict (parameters the loss does not reach are absent); the state
     advances exactly as in compute_temporal_embeddings(train=True).  Gradients flow as upstream: through the
@@ -657,8 +668,8 @@ class OrcaEngine:
     refresh() afterwards.  With several ranks every rank back-propagates its query slice and the parameter
     gradients are all-reduced.  The link decoder (two small dense layers) runs as library
     GEMMs under torch autograd, like its forward in compute_edge_probabilities."""
-    if self.reuse and self.budget != 0:
-      raise OrcaError("train_step: the budgeted reuse path (Path C) does not back-propagate yet")
+    if self.reuse and self.budget != 0 and self.gradient:
+      raise OrcaError("train_step: --gradient is wired into Path B (budget 0) only")
     if self.csr is None:
       raise OrcaError("OrcaEngine: set_neighbor_finder() first")
     dev = self.device
@@ -679,7 +690,29 @@ class OrcaEngine:
     # ---- forward, keeping what the backward re-reads (the tables are not touched before it has run).  steps:
     # per attention call (layer, rows, sample, inputs of orca_tgat_inputs that differ between the paths) ----
     steps = []
-    if self.reuse:                                       # embedding_module.py:154-182
+    out = None
+    if self.reuse and self.budget != 0:                  # embedding_module.py:215-285 (Path C)
+      # The forward is _embed_budget as in compute_temporal_embeddings.  Every layer is evaluated for the batch's Q
+      # roots followed by the uncached out-of-batch neighbours it recomputes; those extra rows only feed the history
+      # tables, which are detached (history.py:32-40), so the loss reaches exactly the FIRST Q rows of every layer:
+      # the backward runs over this rank's slice of them.
+      if self.sampling == "uniform":
+        raise OrcaError("OrcaEngine: uniform sampling is wired into Path B (--reuse) and the one-layer exact path only")
+      rec = []
+      plan = self._dev(cache_plan, torch.int64) if cache_plan is not None else None
+      out = self._embed_budget(nodes, t3, self.L, plan, True, rec=rec)
+      cnt_ready = self._cnt_ready
+      sl = slice(lo, hi)
+      for layer, (nbr_l, eid_l, dt_l), src_l, h in rec:
+        dk = self._dropout_kw(layer, lo)
+        smp = (nbr_l[sl], eid_l[sl], dt_l[sl])
+        if layer == 1:
+          ids64, ids32 = src_l
+          steps.append((1, n, smp, dict(src_table=self.memory, src_idx=ids32[sl], nbr_table=self.memory, nbr_idx=smp[0], **dk),
+                        (ids64[sl], smp[0].reshape(-1))))
+        else:
+          steps.append((layer, n, smp, dict(src_table=src_l[sl], nbr_table=h, nbr_idx=smp[0], **dk), None))
+    elif self.reuse:                                     # embedding_module.py:154-182
       nbr, eid, dt = self._sample(my_nodes, t3[lo:hi], q0=lo)
       self._overlay_updated_memory(nbr, my_nodes)
       cnt_ready = self._fetch_count()
@@ -728,7 +761,8 @@ class OrcaEngine:
           dk = self._dropout_kw(layer, 0)
           emb = self._attend(layer, m, nbr, eid, dt, True, prev, None, prev[m:], None, False, drop=dk)
           steps.append((layer, m, samples[lvl], dict(src_table=prev, nbr_table=prev[m:], **dk), "cat"))
-    out = self._all_gather_rows(emb, Q, per)
+    if out is None:
+      out = self._all_gather_rows(emb, Q, per)
     # ---- link decoder + loss (tgn_model.py:150-157, train.py:231-233) ----
     leaf = out.detach().requires_grad_()
     aff = {k: v.detach().requires_grad_() for k, v in self.aff.items()}

@@ -162,10 +162,11 @@ def test_gru_backward(ops, msg_dim, n, gather):
   assert_close_fp32(got[5].cpu().numpy(), hr.grad.numpy(), TOL, "gru d_h")
 
 
-@pytest.mark.parametrize("reuse,L,bs,drop,hgrad", [(True, 2, 150, 0.0, False), (False, 2, 150, 0.0, False), (False, 1, 150, 0.0, False),
-                                                    (True, 2, 1365, 0.0, False), (True, 2, 150, 0.4, False), (False, 2, 150, 0.4, False),
-                                                    (True, 2, 150, 0.0, True), (True, 2, 1365, 0.4, True)])
-def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop, hgrad):
+@pytest.mark.parametrize("reuse,L,bs,drop,hgrad,budget", [
+    (True, 2, 150, 0.0, False, 0), (False, 2, 150, 0.0, False, 0), (False, 1, 150, 0.0, False, 0), (True, 2, 1365, 0.0, False, 0),
+    (True, 2, 150, 0.4, False, 0), (False, 2, 150, 0.4, False, 0), (True, 2, 150, 0.0, True, 0), (True, 2, 1365, 0.4, True, 0),
+    (True, 2, 150, 0.0, False, 60), (True, 2, 150, 0.4, False, 60)])
+def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop, hgrad, budget):
   """OrcaEngine.train_step (Path B with 2 layers; Path A, the exact recursion, with 2 layers and with 1 layer = the
   reference's default configuration): loss and every parameter gradient against torch autograd of the oracle's
   pieces composed as tgn_model.py:95-157 / embedding_module.py:116-182 compose them, on a warmed-up state (pending
@@ -174,7 +175,9 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop, hgrad):
   attention-weight dropout of train.py:30 -- the checker multiplies its softmax by the keep masks the kernels used
   (orca_tgat_dropout_mask; RNG stream unpinned, masked arithmetic pinned).  hgrad: the --gradient history variant
   (train.py:43, history.py:42-46): the rows pushed in this batch keep their graph -- in the checker the winning
-  (last) occurrence of every root id is written into the history table by a differentiable index_put."""
+  (last) occurrence of every root id is written into the history table by a differentiable index_put.  budget > 0:
+  Path C (embedding_module.py:215-285) with a cache plan per batch -- layer 1 also embeds the uncached out-of-batch
+  neighbours (their rows only feed the detached history table)."""
   from orca_amd import synth
   from orca_amd.engine import OrcaEngine
   N, E, K, d_e = 1500, 30000, 10, 172
@@ -185,7 +188,7 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop, hgrad):
   csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
   engs = []
   for _ in range(2):
-    e = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=0, device="cuda:0", dropout=drop, seed=11, gradient=hgrad)
+    e = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=budget, device="cuda:0", dropout=drop, seed=11, gradient=hgrad)
     e.set_neighbor_finder(csr)
     e.train_time_encoder = True     # the kernels' time-encoder gradient is checked too (frozen upstream: off by default)
     engs.append(e)
@@ -195,19 +198,23 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop, hgrad):
   for b in range(4):
     s, e = 20000 + b * bs, 20000 + (b + 1) * bs
     batches.append((src[s:e], dst[s:e], torch.from_numpy(rs.randint(1, N + 1, bs).astype(np.int64)).to(DEV), ts[s:e], eidx[s:e]))
-  for bt in batches[:3]:
-    A.compute_temporal_embeddings(*bt, True)
-    B.compute_temporal_embeddings(*bt, True)
+  plans = [torch.from_numpy(rs.randint(1, N + 1, budget).astype(np.int64)).to(DEV) if budget else None for _ in range(4)]
+  for bt, pl in zip(batches[:3], plans):
+    A.compute_temporal_embeddings(*bt, True, pl)
+    B.compute_temporal_embeddings(*bt, True, pl)
   mem, msg, pend = (t.cpu().clone() for t in (A.memory, A.messages, A.pending))
   hist = A.hist[0].cpu().clone() if reuse else None
+  flag0 = A.cache_flag[0].clone() if budget else None
   bt = batches[3]
-  loss, grads = A.train_step(*bt)
-  B.compute_temporal_embeddings(*bt, True)
+  loss, grads = A.train_step(*bt, cache_plan=plans[3]) if budget else A.train_step(*bt)
+  B.compute_temporal_embeddings(*bt, True, plans[3])
   torch.cuda.synchronize()
   for name in ("memory", "last_update", "messages", "msg_ts", "pending"):
     assert_close_fp32(getattr(A, name).float().cpu().numpy(), getattr(B, name).float().cpu().numpy(), 1e-6, "state " + name)
   if reuse and not drop:
     assert_close_fp32(A.hist[0].cpu().numpy(), B.hist[0].cpu().numpy(), 1e-6, "state hist")
+  if budget:
+    assert torch.equal(A.cache_flag[0], B.cache_flag[0])
   # ---- the checker: torch autograd on the CPU ----
   nodes = torch.cat([bt[0], bt[1], bt[2]])
   t3 = torch.cat([bt[3]] * 3)
@@ -236,7 +243,21 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop, hgrad):
                                nbr == 0, drop_mult=mult)[0]
   s0 = sample(nodes, t3)
   nc = nodes.cpu()
-  if reuse:
+  if budget:
+    # embedding_module.py:251-260: the uncached out-of-batch neighbours join the layer-1 evaluation, at the batch's
+    # latest timestamp; the first Q rows are the roots' own (the same queries as s0)
+    unc = ops.find_uncached(s0[0].to(DEV).to(torch.int32).flatten(), nodes, flag0, torch.zeros(N + 1, dtype=torch.int64, device=DEV), 1,
+                            torch.zeros((N + 32) // 32, dtype=torch.int32, device=DEV))
+    c_nodes = torch.cat([nodes, unc])
+    s1 = sample(c_nodes, torch.cat([t3, t3.max().expand(unc.numel())]))
+    assert torch.equal(s1[0][:Q], s0[0]) and unc.numel() > 0
+    cc = c_nodes.cpu()
+    Qc = cc.numel()
+    emb1 = layer(0, mem2[cc], mem2[s1[0].flatten()].view(Qc, K, 100), s1)
+    hist2 = hist.clone()
+    hist2[cc] = emb1.detach()
+    top = layer(1, emb1[:Q], hist2[s0[0].flatten()].view(Q, K, 100), s0)
+  elif reuse:
     emb1 = layer(0, mem2[nc], mem2[s0[0].flatten()].view(Q, K, 100), s0)
     if hgrad:
       last = {int(v): i for i, v in enumerate(nc.tolist())}           # id -> its last position

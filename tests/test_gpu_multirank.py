@@ -146,6 +146,27 @@ def _worker(rank, world, port, q, full):
             ok, msg = False, f"train_step gradient {k} differs between {world} ranks and 1 rank: rel {err:.2e}"
         ok = ok and torch.equal(multi.memory, single.memory) and torch.equal(multi.messages, single.messages)
         ok = ok and torch.equal(multi.hist[0], single.hist[0])
+      # the same for the budgeted reuse path (Path C): every rank back-propagates its slice of the roots
+      multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=dist.group.WORLD)
+      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None)
+      multi.set_neighbor_finder(csr)
+      single.set_neighbor_finder(csr)
+      for b in range(3):
+        bt = batch(b)
+        plan = torch.randint(1, N + 1, (40,), generator=g, device=dev)
+        la, ga = multi.train_step(*bt, cache_plan=plan)
+        lc, gc = single.train_step(*bt, cache_plan=plan)
+        ok = ok and abs(float(la) - float(lc)) <= 1e-6 and set(ga) == set(gc)
+        for k in gc:
+          scale = max(float(gc[k].abs().max()), 1e-12)
+          err = float((ga[k] - gc[k]).abs().max()) / scale
+          if err > 1e-5:
+            ok, msg = False, f"Path C train_step gradient {k} differs between {world} ranks and 1 rank: rel {err:.2e}"
+        same = torch.equal(multi.memory, single.memory) and torch.equal(multi.hist[0], single.hist[0])
+        same = same and torch.equal(multi.cache_flag[0], single.cache_flag[0]) and torch.equal(multi.messages, single.messages)
+        if not same and not msg:
+          msg = f"Path C train_step batch {b}: state differs from the single-rank engine"
+        ok = ok and same
     q.put((rank, bool(ok), msg))
     dist.barrier()
     dist.destroy_process_group()
