@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256) void k_pack_group(PackGroup grp) {
 
 int orca_pack_group(const OrcaPackJob* jobs, int n, hipStream_t stream) {
   if (n <= 0) return ORCA_OK;
-  if (n > ORCA_PACK_GROUP_MAX) return ORCA_EINVAL;
+  if (n > ORCA_PACK_GROUP_MAX) {
+    orca_set_error("orca_pack_group: %d jobs in one group (at most %d)", n, ORCA_PACK_GROUP_MAX);
+    return ORCA_EINVAL;
+  }
   PackGroup grp{};
   grp.n = n;
   int first = 0;

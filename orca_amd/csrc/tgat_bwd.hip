@@ -274,7 +274,10 @@ int64_t orca_sgemm_group_part_floats(const OrcaGemm* g, int n) {
 
 int orca_sgemm_group(hipStream_t s, const OrcaGemm* in, int n, float* part) {
   if (n <= 0) return ORCA_OK;
-  if (n > ORCA_GEMM_GROUP_MAX) return ORCA_EINVAL;
+  if (n > ORCA_GEMM_GROUP_MAX) {
+    orca_set_error("orca_sgemm_group: %d problems in one group (at most %d)", n, ORCA_GEMM_GROUP_MAX);
+    return ORCA_EINVAL;
+  }
   GemmGroup grp{};
   int64_t tiles64 = 0;
   int np = 0;
@@ -288,7 +291,10 @@ int orca_sgemm_group(hipStream_t s, const OrcaGemm* in, int n, float* part) {
                  p.accumulate, p.relu, p.K < 16 ? 16 : p.K, nullptr, p.gate, p.rowzero, p.rowzero_n, p.ones_out, 0, 0, 1};
     g.gz = group_splits(p);
     if (g.gz > 1) {
-      if (!part || p.bias || p.relu || p.gate || p.rowzero) return ORCA_EINVAL;
+      if (!part || p.bias || p.relu || p.gate || p.rowzero) {
+        orca_set_error("orca_sgemm_group: a split-K problem needs a partial-sum buffer and takes no bias / relu / gate / rowzero");
+        return ORCA_EINVAL;
+      }
       const int sp = p.splits > ORCA_GEMM_SPLITS ? ORCA_GEMM_SPLITS : p.splits;
       int kc = (p.K + sp - 1) / sp;
       g.kchunk = (kc + 15) / 16 * 16;
@@ -342,11 +348,17 @@ int orca_sgemm(hipStream_t s, int M, int N, int K, const float* A, int64_t sam, 
 int orca_colsum_group(hipStream_t s, int n, const float* const* X, const int64_t* ld, const int* ncols, float* const* out,
                       int64_t Q, float alpha, bool accumulate, float* part) {
   if (n <= 0) return ORCA_OK;
-  if (n > COLSUM_JOBS) return ORCA_EINVAL;
+  if (n > COLSUM_JOBS) {
+    orca_set_error("orca_colsum_group: %d sums in one group (at most %d)", n, COLSUM_JOBS);
+    return ORCA_EINVAL;
+  }
   ColsumJobs jobs{};
   int maxc = 0;
   for (int i = 0; i < n; ++i) {
-    if (ncols[i] <= 0 || ncols[i] > COLSUM_MAXC) return ORCA_EINVAL;
+    if (ncols[i] <= 0 || ncols[i] > COLSUM_MAXC) {
+      orca_set_error("orca_colsum_group: %d columns (1 .. %d supported)", ncols[i], COLSUM_MAXC);
+      return ORCA_EINVAL;
+    }
     jobs.X[i] = X[i]; jobs.ld[i] = ld[i]; jobs.ncols[i] = ncols[i]; jobs.out[i] = out[i];
     maxc = ncols[i] > maxc ? ncols[i] : maxc;
   }
