@@ -323,6 +323,17 @@ int orca_find_uncached(const int32_t* nbr, int64_t n_nbr, const int64_t* batch_n
 int orca_scatter_rows(float* table, int64_t n_rows, int64_t width, const int64_t* ids, int64_t n, const float* x,
                       void* stream);
 
+/* The link decoder of a TRAINING step with its loss, forward and backward (model/tgn_model.py:150-157: affinity_score =
+ * MergeLayer utils/util.py:12-24 on (src, dst) and (src, neg), sigmoid; train.py:231-233: BCELoss(pos, 1) +
+ * BCELoss(neg, 0), mean reduction).  emb [3*bs, ORCA_D] = the embeddings of [src; dst; neg]; fc1_w [ORCA_D, 2*ORCA_D],
+ * fc1_b [ORCA_D], fc2_w [1, ORCA_D], fc2_b [1] (affinity_score.fc{1,2}.*).  Out: *loss (device scalar), prob [2*bs] =
+ * [pos; neg] probabilities (may be NULL), d_emb [3*bs, ORCA_D] = dL/d emb, and the parameter gradients ACCUMULATED into
+ * g_* (zeroed by the caller).  workspace: orca_decoder_train_workspace_floats(bs) floats. */
+int64_t orca_decoder_train_workspace_floats(int64_t bs);
+int orca_decoder_train(const float* emb, int64_t bs, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                       const float* fc2_b, float* loss, float* prob, float* d_emb, float* g_fc1_w, float* g_fc1_b,
+                       float* g_fc2_w, float* g_fc2_b, float* workspace, void* stream);
+
 /* optimizer.step() of train.py:238 for torch.optim.Adam(tgn.parameters(), lr) (train.py:180; no weight decay, no
  * amsgrad) over n tensors in one launch per 24 tensors: params / grads / exp_avg / exp_avg_sq and sizes are HOST arrays
  * of n device pointers / element counts; step = 1 for the first call (the caller counts).  Arithmetic in the order of

@@ -95,6 +95,8 @@ SIGNATURES = {
     "orca_history_push": (i32, [vp, vp, vp, i64, vp, i64, i64, vp]),
     "orca_gather_rows": (i32, [vp, i64, i64, vp, vp, i64, vp, vp]),
     "orca_scatter_rows": (i32, [vp, i64, i64, vp, i64, vp, vp]),
+    "orca_decoder_train_workspace_floats": (i64, [i64]),
+    "orca_decoder_train": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "orca_adam_step": (i32, [i32, vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, i64, vp]),
     "orca_find_uncached": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, vp]),
     "orca_engine_create": (i32, [ctypes.POINTER(EngineDesc), ctypes.POINTER(vp)]),

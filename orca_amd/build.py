@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liborca_hip.so")
-SOURCES = ["csr.hip", "tgat.hip", "tgat_bwd.hip", "gru_bwd.hip", "gru.hip", "state.hip", "plan.hip", "plan_dev.hip", "engine.hip", "optim.hip"]
+SOURCES = ["csr.hip", "tgat.hip", "tgat_bwd.hip", "gru_bwd.hip", "gru.hip", "state.hip", "plan.hip", "plan_dev.hip", "engine.hip", "optim.hip", "decoder.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++20", "-fPIC", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-result", "-Wno-unused-function"]
 

@@ -666,8 +666,8 @@ class OrcaEngine:
     table are detached (history.py:32-40: push / pull run under no_grad in the default configuration, without
     train.py:43's --gradient switch: OrcaEngine(gradient=True); memory.py:45-47).  An optimizer updates self.params in place; call
     refresh() afterwards.  With several ranks every rank back-propagates its query slice and the parameter
-    gradients are all-reduced.  The link decoder (two small dense layers) runs as library
-    GEMMs under torch autograd, like its forward in compute_edge_probabilities."""
+    gradients are all-reduced.  The link decoder (two small dense layers) and the loss run
+    forward and backward in orca_decoder_train (csrc/decoder.hip)."""
     if self.reuse and self.budget != 0 and self.gradient:
       raise OrcaError("train_step: --gradient is wired into Path B (budget 0) only")
     if self.csr is None:
@@ -763,21 +763,13 @@ class OrcaEngine:
           steps.append((layer, m, samples[lvl], dict(src_table=prev, nbr_table=prev[m:], **dk), "cat"))
     if out is None:
       out = self._all_gather_rows(emb, Q, per)
-    # ---- link decoder + loss (tgn_model.py:150-157, train.py:231-233) ----
-    leaf = out.detach().requires_grad_()
-    aff = {k: v.detach().requires_grad_() for k, v in self.aff.items()}
-    se, de, ne = leaf[:bs], leaf[bs:2 * bs], leaf[2 * bs:]
-    x = torch.cat([torch.cat([se, se]), torch.cat([de, ne])], dim=1)
-    h = torch.relu(x @ aff["fc1.weight"].t() + aff["fc1.bias"])
-    score = (h @ aff["fc2.weight"].t() + aff["fc2.bias"]).sigmoid().squeeze(1)
-    bce = torch.nn.functional.binary_cross_entropy
-    if getattr(self, "_targets", None) is None or self._targets[0].numel() != bs:
-      self._targets = (torch.ones(bs, device=dev), torch.zeros(bs, device=dev))
-    loss = bce(score[:bs], self._targets[0]) + bce(score[bs:], self._targets[1])
-    loss.backward()
-    grads = {"affinity_score." + k: v.grad for k, v in aff.items()}
+    # ---- link decoder + loss, forward and backward (tgn_model.py:150-157, train.py:231-233): orca_decoder_train ----
+    loss, d_out, ga, _ = ops.decoder_train(out, self.aff["fc1.weight"], self.aff["fc1.bias"], self.aff["fc2.weight"],
+                                           self.aff["fc2.bias"])
+    loss = loss.reshape(())
+    grads = {"affinity_score." + k: v for k, v in ga.items()}
     # ---- backward through the attention calls, last to first (this rank's slice) ----
-    d = leaf.grad[lo:hi].contiguous()
+    d = d_out[lo:hi].contiguous()
     want_t = self.train_time_encoder       # (frozen upstream, model/time_encoding.py:20-21: its gradient is not computed)
     d_time = torch.zeros(2, D, dtype=torch.float32, device=dev) if want_t else None
     into_memory = None
@@ -847,7 +839,7 @@ class OrcaEngine:
     ops.set_flags(self.pending, ids64=positives, v=0)
     ops.message_store(src, dst, eidx, ts, self.memory, self.last_update, self.edge_feats, self.time_w, self.time_b,
                       self.slot, self._slot_epoch(2 * bs), self.messages, self.msg_ts, self.pending)
-    return loss.detach(), grads
+    return loss, grads
 
   def _fetch_count(self):
     """starts the copy of the work-list count to pinned host memory; the returned event completes with it"""

@@ -423,6 +423,29 @@ def scatter_rows(table, ids, x):
         "orca_scatter_rows")
 
 
+def decoder_train(emb, fc1_w, fc1_b, fc2_w, fc2_b, want_prob=False):
+  """orca_decoder_train: link decoder + BCE loss of a training step, forward and backward.  emb [3*bs, D] = embeddings
+  of [src; dst; neg].  Returns (loss [1], d_emb [3*bs, D], grads {fc1.weight, fc1.bias, fc2.weight, fc2.bias}, prob
+  [2*bs] or None)."""
+  dev = emb.device
+  bs = emb.shape[0] // 3
+  ps = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in (fc1_w, fc1_b, fc2_w, fc2_b)]
+  flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in ps) + 64, dtype=torch.float32, device=dev)
+  gs, o = [], 0
+  for p in ps:
+    gs.append(flat[o:o + p.numel()].view(p.shape))
+    o += -(-p.numel() // 64) * 64
+  loss = flat[o:o + 1]
+  nw = _lib.load().orca_decoder_train_workspace_floats(int(bs))
+  wsp = torch.empty(nw, dtype=torch.float32, device=dev)
+  d_emb = torch.empty((3 * bs, D), dtype=torch.float32, device=dev)
+  prob = torch.empty(2 * bs, dtype=torch.float32, device=dev) if want_prob else None
+  e = emb.detach().contiguous()
+  check(_lib.load().orca_decoder_train(ptr(e), int(bs), *(ptr(p) for p in ps), ptr(loss), ptr(prob), ptr(d_emb),
+                                       *(ptr(g) for g in gs), ptr(wsp), stream()), "orca_decoder_train")
+  return loss, d_emb, dict(zip(("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"), gs)), prob
+
+
 class FusedAdam:
   """torch.optim.Adam(params, lr) (train.py:180) as one launch per step (orca_adam_step): params is a dict name ->
   fp32 device tensor, updated in place; step(grads) takes a dict with (a subset of) the same names -- a parameter

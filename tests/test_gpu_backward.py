@@ -455,3 +455,29 @@ def test_fused_adam_matches_torch_adam(ops):
     for k in P:
       assert_close_fp32(mine[k].cpu().numpy(), ref[k].detach().numpy(), 1e-6, f"Adam step {step} {k}")
   assert fused.steps["p2"] == 4 and fused.steps["p0"] == 5
+
+
+@pytest.mark.parametrize("bs", [1, 37, 1365])
+def test_decoder_train_vs_autograd(ops, bs):
+  """orca_decoder_train (link decoder + BCE of a training step, model/tgn_model.py:150-157, utils/util.py:12-24,
+  train.py:231-233) against torch autograd of the same composition on the CPU."""
+  rs = np.random.RandomState(bs)
+  emb = torch.from_numpy(rs.randn(3 * bs, 100).astype(np.float32))
+  P = {"fc1.weight": rs.randn(100, 200) * 0.1, "fc1.bias": rs.randn(100) * 0.1, "fc2.weight": rs.randn(1, 100) * 0.3,
+       "fc2.bias": rs.randn(1) * 0.1}
+  P = {k: torch.from_numpy(v.astype(np.float32)).requires_grad_() for k, v in P.items()}
+  e = emb.clone().requires_grad_()
+  se, de, ne = e[:bs], e[bs:2 * bs], e[2 * bs:]
+  x = torch.cat([torch.cat([se, se]), torch.cat([de, ne])], dim=1)
+  h = torch.relu(x @ P["fc1.weight"].t() + P["fc1.bias"])
+  score = (h @ P["fc2.weight"].t() + P["fc2.bias"]).sigmoid().squeeze(1)
+  bce = torch.nn.functional.binary_cross_entropy
+  ref = bce(score[:bs], torch.ones(bs)) + bce(score[bs:], torch.zeros(bs))
+  ref.backward()
+  loss, d_emb, grads, prob = ops.decoder_train(emb.to(DEV), *(P[k].detach().to(DEV) for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")),
+                                               want_prob=True)
+  assert abs(float(loss) - float(ref.detach())) <= 1e-5 * max(1.0, abs(float(ref.detach())))
+  assert_close_fp32(prob.cpu().numpy(), score.detach().numpy(), TOL, "decoder probabilities")
+  assert_close_fp32(d_emb.cpu().numpy(), e.grad.numpy(), TOL, "decoder d_emb")
+  for k, v in P.items():
+    assert_close_fp32(grads[k].cpu().numpy(), v.grad.numpy(), TOL, "decoder grad " + k)
