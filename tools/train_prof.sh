@@ -10,5 +10,7 @@ timeout -k 10 120 python3 tools/train_probe.py > gpurun_out/prof/train_probe.txt
 cd /tmp
 rm -rf /tmp/prof/train
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/prof/train -o train -- python3 $R/tools/train_probe.py > $R/gpurun_out/prof/train_prof.out 2>&1 || exit 1
-python3 $R/tools/rocprof_summary.py "$(ls /tmp/prof/train/*/*.db /tmp/prof/train/*.db 2>/dev/null | head -n 1)" $R/gpurun_out/prof/train_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 tools/train_probe.py"
+DB="$(ls /tmp/prof/train/*/*.db /tmp/prof/train/*.db 2>/dev/null | head -n 1)"
+python3 $R/tools/step_trace.py "$DB" > $R/gpurun_out/prof/train_step_trace.txt 2>&1
+python3 $R/tools/rocprof_summary.py "$DB" $R/gpurun_out/prof/train_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 tools/train_probe.py"
 cat $R/gpurun_out/prof/train_probe.txt
