@@ -176,6 +176,71 @@ __global__ __launch_bounds__(256) void k_sgemm(GemmGroup grp) {
       }
 }
 
+// ---- the same GEMM without LDS and without barriers, for activations times weights ----------------------------------
+// The backward's data GEMMs are C [M x N] = A [M x K] B with M = the queries (thousands), N and K a few hundred, A
+// row-major.  Here a wave owns a 16-row x 32-column tile outright: lane (r = lane & 15, kq = lane >> 4) loads the
+// float4 A[m0 + r][k0 + 4 kq ..] -- the four k-steps of a 16-deep block -- and, for each of its two column tiles, the
+// matching four values of B (one float4 when B is k-contiguous, i.e. a weight matrix used transposed; four dwords
+// when it is n-contiguous).  MFMA step e then consumes element e of both: the k index 4 kq + e is a permutation of
+// the block's 16, the same on both operands, which is all a sum over k needs.  The next block's loads are issued
+// before the current block's MFMAs; nothing is shared between waves except through L1 / L2 (the four waves of a
+// workgroup read the same 16 rows of A).  Needs 16-byte aligned float4 rows (K, row strides and bases multiples of 4
+// floats): orca_sgemm_group checks and otherwise takes k_sgemm.  About 10 % faster than k_sgemm on these shapes
+// (8-19 us a launch).
+template <bool B_KFAST>
+__global__ __launch_bounds__(256) void k_sgemm_rows(GemmGroup grp) {
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < ORCA_GEMM_GROUP_MAX; ++i) p += (i < grp.n && (int)blockIdx.x >= grp.first[i]) ? 1 : 0;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const GemmArgs g = grp.g[p];
+  const int local = (int)blockIdx.x - grp.first[p];
+  const int bx = local % g.gx, by = local / g.gx;        // gx column groups of 128, gy row tiles of 16
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int m0 = by * 16, n0 = bx * 128 + wave * 32;
+  if (n0 >= g.N) return;
+  const int mr = m0 + r < g.M ? m0 + r : g.M - 1;        // clamped, never skipped (the store is masked)
+  const float* arow = g.A + (int64_t)mr * g.sam + 4 * kq;
+  const float* bcol[2];
+  bool nok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + 16 * j + r;
+    nok[j] = n < g.N;
+    const int nc = nok[j] ? n : 0;
+    bcol[j] = B_KFAST ? g.B + (int64_t)nc * g.sbn + 4 * kq : g.B + (int64_t)(4 * kq) * g.sbk + nc;
+  }
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_a = [&](int k0) { return k0 + 4 * kq < g.K ? *reinterpret_cast<const f32x4*>(arow + k0) : zero4; };
+  auto load_b = [&](int j, int k0) {
+    if (!nok[j] || k0 + 4 * kq >= g.K) return zero4;
+    if (B_KFAST) return *reinterpret_cast<const f32x4*>(bcol[j] + k0);
+    const float* b = bcol[j] + (int64_t)k0 * g.sbk;
+    return f32x4{b[0], b[g.sbk], b[2 * g.sbk], b[3 * g.sbk]};
+  };
+  // (four blocks per step with twelve loads in flight measured no faster, and slower where its 116-170 VGPRs cost
+  // occupancy: these launches are not bound by the latency of their own load chain)
+  f32x4 a = load_a(0), b0 = load_b(0, 0), b1 = load_b(1, 0);
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    const f32x4 an = load_a(k0 + 16), b0n = load_b(0, k0 + 16), b1n = load_b(1, k0 + 16);   // (past K: zeros, no loads)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], acc[1], 0, 0, 0);
+    }
+    a = an; b0 = b0n; b1 = b1n;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + 4 * kq + i, n = n0 + 16 * j + r;
+      if (m < g.M && n < g.N) gemm_store(g, m, n, acc[j][i]);
+    }
+}
+
 // the split-K sums of every problem of a group that has them
 __global__ __launch_bounds__(256) void k_splitk_reduce(GemmGroup grp) {
   int p = 0;
@@ -307,6 +372,30 @@ int orca_sgemm_group(hipStream_t s, const OrcaGemm* in, int n, float* part) {
   }
   if (np == 0) return ORCA_OK;
   grp.n = np;
+  {   // activations x weights (see k_sgemm_rows): every problem row-major in A, aligned for float4 rows, no split-K
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    bool rows = !any_split, kfast = grp.g[0].sbk == 1 && grp.g[0].sbn != 1;
+    for (int i = 0; i < np && rows; ++i) {
+      const GemmArgs& g = grp.g[i];
+      const bool kf = g.sbk == 1 && g.sbn != 1;
+      rows = g.sak == 1 && g.K % 4 == 0 && g.sam % 4 == 0 && al16(g.A) && !g.ones_out && g.M >= 256 && kf == kfast &&
+             (kf ? (g.sbn % 4 == 0 && al16(g.B)) : g.sbn == 1);
+    }
+    static const bool off = getenv("ORCA_GEMM_ROWS") && atoi(getenv("ORCA_GEMM_ROWS")) == 0;
+    if (rows && !off) {
+      int first = 0;
+      for (int i = 0; i < np; ++i) {
+        grp.first[i] = first;
+        grp.g[i].gx = (grp.g[i].N + 127) / 128;
+        grp.g[i].gy = (grp.g[i].M + 15) / 16;
+        first += grp.g[i].gx * grp.g[i].gy;
+      }
+      grp.first[np] = first;
+      if (kfast) k_sgemm_rows<true><<<(unsigned)first, 256, 0, s>>>(grp);
+      else k_sgemm_rows<false><<<(unsigned)first, 256, 0, s>>>(grp);
+      return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
+    }
+  }
   // under two blocks per CU: halve the tile, double the blocks (a block is one wave per SIMD: its chain of slabs is
   // latency-bound, and only more resident blocks hide that); under one: quarter it
   const int TM = tiles64 < 256 ? 16 : tiles64 < 512 ? 32 : 64;
