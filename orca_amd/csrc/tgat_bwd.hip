@@ -350,7 +350,7 @@ int orca_sgemm_group(hipStream_t s, const OrcaGemm* in, int n, float* part) {
   int64_t po = 0;
   for (int i = 0; i < n; ++i) {
     const OrcaGemm& p = in[i];
-    if (p.M <= 0 || p.N <= 0) continue;
+    if (p.M <= 0 || (p.N <= 0 && !p.ones_out)) continue;
     GemmArgs& g = grp.g[np++];
     g = GemmArgs{p.M, p.N + (p.ones_out ? 1 : 0), p.K, p.A, p.sam, p.sak, p.B, p.sbk, p.sbn, p.C, p.scm, p.scn, p.bias, p.alpha,
                  p.accumulate, p.relu, p.K < 16 ? 16 : p.K, nullptr, p.gate, p.rowzero, p.rowzero_n, p.ones_out, 0, 0, 1};
@@ -771,6 +771,334 @@ __global__ void k_bwd_finish(orca_tgat_inputs in, int64_t Q, const float* __rest
   }
 }
 
+// ---- fused row chains (d_e = 172) ----------------------------------------------------------------------------
+// Between the two per-query attention kernels the backward is a chain of activations x weights products, each row of
+// every product depending on the same row of the one before.  As launches of their own they are bound by the floor
+// under a launch of this size (8-22 us each, 12 per layer); here a 1024-thread workgroup takes 16 rows through a whole
+// chain, the activations staying in LDS (row stride / 4 odd: float4 reads of 16 rows hit distinct banks) and each
+// weight fragment read once per workgroup, straight from L2 into MFMA operands as in k_sgemm_rows.  What the
+// weight-gradient GEMMs and the attention kernels need is written to the same workspace rows as before.
+//   chain A: prep -> qs = 0.1 (xq Wq^T + bq) -> q~_h = qs_h Wk_h
+//   chain B: ocat -> out-proj -> fc1 -> fc2 -> LayerNorm backward -> fc2^T -> fc1^T -> out-proj^T -> value map^T
+//   chain C: dqs_h = 0.1 dq~_h Wk_h^T -> dxq = dq Wq -> d_src / time gradients
+constexpr int CH_WAVES = 16, CH_T = 64 * CH_WAVES;
+
+template <int N, int K, int NH, bool KFAST, int KS>
+struct ChainShape {
+  static_assert(K % 4 == 0 && N % 2 == 0, "float4 rows of A, float2 columns of B");
+  static constexpr int TW = KFAST ? 16 : 32;               // columns of a wave's tile
+  static constexpr int NT = (N + TW - 1) / TW;
+  static constexpr int NP = NT * TW;
+  static constexpr int KB = (K + 15) / 16;                 // 16-deep blocks of the reduction
+  static constexpr int BPI = (KB + KS - 1) / KS;           // blocks per work item
+  static constexpr int ITEMS = NH * NT * KS;
+  static constexpr int PFLOATS = KS > 1 ? KS * NH * 16 * NP : 0;
+};
+
+// One stage: C_h [16 x N] = A[:, h*ash : h*ash + K] B_h for h < NH.  A in LDS (row stride lda); B_h = B + h*bsh in
+// global memory with B_h(k, n) = B_h[n*ldb + k] (KFAST: a weight matrix used transposed, float4 along k) or
+// B_h[k*ldb + n] (float2 along n, a 32-column tile).  The NH*NT tiles x KS reduction pieces are dealt to the 16 waves;
+// a piece's weights (BPI blocks) are all requested before its first MFMA.  KS > 1: the pieces meet in P and are added
+// in a fixed order.  epi(h, m, n, value) stores an element; ends with a barrier.
+template <int N, int K, int NH, bool KFAST, int KS, class Epi>
+__device__ __forceinline__ void chain_gemm(const float* As, int lda, int ash, const float* __restrict__ B, int ldb,
+                                           int bsh, float* P, Epi epi) {
+  using S = ChainShape<N, K, NH, KFAST, KS>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int item = wave; item < S::ITEMS; item += CH_WAVES) {
+    const int ks = item / (NH * S::NT), tile = item % (NH * S::NT), h = tile / S::NT, nt = tile % S::NT;
+    const float* ap = As + r * lda + h * ash + 4 * kq;
+    const int kb0 = ks * S::BPI;
+    if constexpr (KFAST) {
+      const int n = nt * 16 + r;
+      const bool nok = n < N;
+      const float* bp = B + (int64_t)h * bsh + (int64_t)(nok ? n : 0) * ldb + 4 * kq;
+      f32x4 b[S::BPI];
+#pragma unroll
+      for (int i = 0; i < S::BPI; ++i) {
+        const int k0 = 16 * (kb0 + i);
+        const bool ok = k0 + 4 * kq < K;
+        b[i] = *reinterpret_cast<const f32x4*>(bp + (ok ? k0 : 0));      // clamped, never skipped
+        if (!ok || !nok) b[i] = zero4;
+      }
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int i = 0; i < S::BPI; ++i) {
+        const int k0 = 16 * (kb0 + i);
+        const bool ok = k0 + 4 * kq < K;
+        f32x4 a = *reinterpret_cast<const f32x4*>(ap + (ok ? k0 : 0));
+        if (!ok) a = zero4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[i][e], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 4 * kq + i;
+        if constexpr (KS == 1) { if (nok) epi(h, m, n, acc[i]); }
+        else P[((ks * NH + h) * 16 + m) * S::NP + n] = acc[i];
+      }
+    } else {
+      const int n = nt * 32 + 2 * r;                      // this lane's two columns (N is even: both or neither)
+      const bool nok = n < N;
+      const float* bp = B + (int64_t)h * bsh + (int64_t)(4 * kq) * ldb + (nok ? n : 0);
+      float2 b[S::BPI][4];
+#pragma unroll
+      for (int i = 0; i < S::BPI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k0 = 16 * (kb0 + i);
+          const bool ok = k0 + 4 * kq < K;
+          b[i][e] = *reinterpret_cast<const float2*>(bp + (int64_t)((ok ? k0 : 0) + e) * ldb);
+          if (!ok || !nok) b[i][e] = make_float2(0.f, 0.f);
+        }
+      f32x4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+      for (int i = 0; i < S::BPI; ++i) {
+        const int k0 = 16 * (kb0 + i);
+        const bool ok = k0 + 4 * kq < K;
+        f32x4 a = *reinterpret_cast<const f32x4*>(ap + (ok ? k0 : 0));
+        if (!ok) a = zero4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[i][e].x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[i][e].y, acc1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 4 * kq + i;
+        if constexpr (KS == 1) {
+          if (nok) { epi(h, m, n, acc0[i]); epi(h, m, n + 1, acc1[i]); }
+        } else {
+          *reinterpret_cast<float2*>(&P[((ks * NH + h) * 16 + m) * S::NP + n]) = make_float2(acc0[i], acc1[i]);
+        }
+      }
+    }
+  }
+  if constexpr (KS > 1) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NH * 16 * N; idx += CH_T) {
+      const int h = idx / (16 * N), m = (idx % (16 * N)) / N, n = idx % N;
+      float v = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) v += P[((ks * NH + h) * 16 + m) * S::NP + n];
+      epi(h, m, n, v);
+    }
+  }
+  __syncthreads();
+}
+
+constexpr int CH_S2 = QD + 4, CH_S3 = 3 * D + 8, CH_S1 = D + 8;     // LDS row strides of 200-, 300- and 100-wide rows
+template <int KD> struct ChainLds {
+  static constexpr int SB = 2 * KD + 4;                                // stride of a [2 x kdim] row
+  static_assert((SB / 4) % 2 == 1 && (CH_S2 / 4) % 2 == 1 && (CH_S3 / 4) % 2 == 1 && (CH_S1 / 4) % 2 == 1, "bank spread");
+  // chain A: xq, qs, P;  chain C: dq~ rows, dq, dxq, P;  chain B: xbar rows (later h1, y, dy, dh1), P, ocat/docat, x1/dx1
+  static constexpr int A_P = ChainShape<QD, QD, 1, true, 2>::PFLOATS;
+  static constexpr int A_FLOATS = 2 * 16 * CH_S2 + A_P;
+  static constexpr int C_P1 = ChainShape<D, KD, 2, true, 3>::PFLOATS, C_P2 = ChainShape<QD, QD, 1, false, 2>::PFLOATS;
+  static constexpr int C_P = C_P1 > C_P2 ? C_P1 : C_P2;
+  static constexpr int C_FLOATS = 16 * SB + 2 * 16 * CH_S2 + C_P;
+  static constexpr int B_P = C_P1 > 4 * 16 * 128 ? C_P1 : 4 * 16 * 128;
+  static constexpr int B_FLOATS = 16 * SB + B_P + 16 * CH_S2 + 16 * CH_S3;
+  static_assert(4 * 16 * CH_S1 <= 16 * SB, "the narrow rows alias the xbar rows");
+};
+
+template <int KD>
+__global__ __launch_bounds__(CH_T) void k_chain_a(orca_tgat_inputs in, int64_t Q, const float* __restrict__ Wq,
+                                                  const float* __restrict__ bq, const float* __restrict__ Wk,
+                                                  float* __restrict__ xq, float* __restrict__ x1, float* __restrict__ qs,
+                                                  float* __restrict__ qt) {
+  extern __shared__ __align__(16) float lds[];
+  float* XQ = lds;
+  float* QS = XQ + 16 * CH_S2;
+  float* P = QS + 16 * CH_S2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * 16;
+  {   // wave = row: xq = [src | src_time], x1[:, 200:300] = src   (rows past Q repeat the last one and store nothing)
+    const int64_t q = m0 + wave, qc = q < Q ? q : Q - 1;
+    const int64_t row = in.src_idx ? (int64_t)in.src_idx[qc] : qc;
+    const float* tab = (in.src_flags && in.src_flags[row]) ? in.src_overlay : in.src_table;
+    for (int c = lane; c < D; c += 64) {
+      const float s = tab[row * D + c];
+      const float tv = in.dt ? orca_cosf(orca_time_arg(0.0f, in.time_w[c], in.time_b[c])) : in.src_time[qc * D + c];
+      XQ[wave * CH_S2 + c] = s;
+      XQ[wave * CH_S2 + D + c] = tv;
+      if (q < Q) {
+        xq[q * QD + c] = s;
+        xq[q * QD + D + c] = tv;
+        x1[q * 3 * D + QD + c] = s;
+      }
+    }
+  }
+  __syncthreads();
+  chain_gemm<QD, QD, 1, true, 2>(XQ, CH_S2, 0, Wq, QD, 0, P, [&](int, int m, int n, float v) {
+    v = 0.1f * (v + bq[n]);
+    QS[m * CH_S2 + n] = v;
+    if (m0 + m < Q) qs[(m0 + m) * QD + n] = v;
+  });
+  chain_gemm<KD, D, 2, false, 1>(QS, CH_S2, D, Wk, KD, D * KD, P, [&](int h, int m, int n, float v) {
+    if (m0 + m < Q) qt[(m0 + m) * 2 * KD + h * KD + n] = v;
+  });
+}
+
+struct ChainB {
+  const float *v_w, *bv, *o_w, *o_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln_w;     // parameters
+  const float *grad_out, *xbar, *invalid, *wsum;                                // inputs
+  float *x1, *ocat, *h1, *dy, *gx, *dh1, *dx1, *docat, *dxbar, *scaled, *dsum;  // rows kept for the weight gradients
+  int drop;
+};
+template <int KD>
+__global__ __launch_bounds__(CH_T) void k_chain_b(ChainB c, int64_t Q) {
+  using L = ChainLds<KD>;
+  extern __shared__ __align__(16) float lds[];
+  float* BIG = lds;                        // xbar rows; once they are consumed: h1, y, dy, dh1
+  float* P = BIG + 16 * L::SB;
+  float* OC = P + L::B_P;                  // ocat, later docat
+  float* X1 = OC + 16 * CH_S2;             // x1, later dx1
+  float *H1 = BIG, *Y = BIG + 16 * CH_S1, *DY = BIG + 2 * 16 * CH_S1, *DH = BIG + 3 * 16 * CH_S1;
+  __shared__ float inval[16], ws[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * 16;
+  for (int i = threadIdx.x; i < 16 * (2 * KD / 4); i += CH_T) {       // xbar rows, float4 at a time
+    const int m = i / (2 * KD / 4), c4 = i % (2 * KD / 4);
+    const int64_t q = m0 + m < Q ? m0 + m : Q - 1;
+    *reinterpret_cast<f32x4*>(&BIG[m * L::SB + 4 * c4]) = *reinterpret_cast<const f32x4*>(&c.xbar[q * 2 * KD + 4 * c4]);
+  }
+  for (int i = threadIdx.x; i < 16 * D; i += CH_T) {                  // the merger's second input (written by chain A)
+    const int m = i / D, n = i % D;
+    const int64_t q = m0 + m < Q ? m0 + m : Q - 1;
+    X1[m * CH_S3 + QD + n] = c.x1[q * 3 * D + QD + n];
+  }
+  if (threadIdx.x < 16) {
+    const int64_t q = m0 + threadIdx.x < Q ? m0 + threadIdx.x : Q - 1;
+    inval[threadIdx.x] = c.invalid[q];
+    ws[2 * threadIdx.x] = c.drop ? c.wsum[q * 2] : 1.f;
+    ws[2 * threadIdx.x + 1] = c.drop ? c.wsum[q * 2 + 1] : 1.f;
+  }
+  __syncthreads();
+  // ocat_h = xbar_h Wv_h^T + bv_h (dropout: times the sum of the head's kept weights)
+  chain_gemm<D, KD, 2, true, 3>(BIG, L::SB, KD, c.v_w, KD, D * KD, P, [&](int h, int m, int n, float v) {
+    v += ws[2 * m + h] * c.bv[h * D + n];
+    OC[m * CH_S2 + h * D + n] = v;
+    if (m0 + m < Q) c.ocat[(m0 + m) * QD + h * D + n] = v;
+  });
+  // o = ocat Wo^T + bo, zero for a query without neighbours                          (temporal_attention.py:52)
+  chain_gemm<QD, QD, 1, true, 2>(OC, CH_S2, 0, c.o_w, QD, 0, P, [&](int, int m, int n, float v) {
+    v = inval[m] != 0.f ? 0.f : v + c.o_b[n];
+    X1[m * CH_S3 + n] = v;
+    if (m0 + m < Q) c.x1[(m0 + m) * 3 * D + n] = v;
+  });
+  // h1 = relu(x1 W1^T + b1), y = h1 W2^T + b2                                         (utils/util.py:22-24)
+  chain_gemm<D, 3 * D, 1, true, 2>(X1, CH_S3, 0, c.fc1_w, 3 * D, 0, P, [&](int, int m, int n, float v) {
+    v = fmaxf(v + c.fc1_b[n], 0.f);
+    H1[m * CH_S1 + n] = v;
+    if (m0 + m < Q) c.h1[(m0 + m) * D + n] = v;
+  });
+  chain_gemm<D, D, 1, true, 2>(H1, CH_S1, 0, c.fc2_w, D, 0, P, [&](int, int m, int n, float v) {
+    Y[m * CH_S1 + n] = v + c.fc2_b[n];
+  });
+  {   // LayerNorm backward, wave = row (k_bwd_ln)
+    const int m = wave, c1 = lane + 64;
+    const int64_t q = m0 + m < Q ? m0 + m : Q - 1;
+    const float ya = Y[m * CH_S1 + lane], yb = c1 < D ? Y[m * CH_S1 + c1] : 0.f;
+    const float mean = wave_sum(ya + yb) * (1.0f / D);
+    const float da = ya - mean, db = c1 < D ? yb - mean : 0.f;
+    const float var = wave_sum(da * da + db * db) * (1.0f / D);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float xa = da * rstd, xb = db * rstd;
+    const float ga = c.grad_out[q * D + lane], gb = c1 < D ? c.grad_out[q * D + c1] : 0.f;
+    const float ha = ga * c.ln_w[lane], hb = c1 < D ? gb * c.ln_w[c1] : 0.f;
+    const float s1 = wave_sum(ha + hb) * (1.0f / D);
+    const float s2 = wave_sum(ha * xa + hb * xb) * (1.0f / D);
+    const float va = (ha - s1 - xa * s2) * rstd, vb = (hb - s1 - xb * s2) * rstd;
+    DY[m * CH_S1 + lane] = va;
+    if (c1 < D) DY[m * CH_S1 + c1] = vb;
+    if (m0 + m < Q) {
+      c.dy[q * D + lane] = va;
+      c.gx[q * D + lane] = ga * xa;
+      if (c1 < D) {
+        c.dy[q * D + c1] = vb;
+        c.gx[q * D + c1] = gb * xb;
+      }
+    }
+  }
+  __syncthreads();
+  // fc2: dz1 = (dy W2) where h1 > 0;  fc1: dx1 = dz1 W1, its first 200 columns zero where the output was zeroed
+  chain_gemm<D, D, 1, false, 4>(DY, CH_S1, 0, c.fc2_w, D, 0, P, [&](int, int m, int n, float v) {
+    if (!(H1[m * CH_S1 + n] > 0.f)) v = 0.f;
+    DH[m * CH_S1 + n] = v;
+    if (m0 + m < Q) c.dh1[(m0 + m) * D + n] = v;
+  });
+  chain_gemm<3 * D, D, 1, false, 1>(DH, CH_S1, 0, c.fc1_w, 3 * D, 0, P, [&](int, int m, int n, float v) {
+    if (n < QD && inval[m] != 0.f) v = 0.f;
+    X1[m * CH_S3 + n] = v;
+    if (m0 + m < Q) c.dx1[(m0 + m) * 3 * D + n] = v;
+  });
+  // out-proj: docat = do Wo
+  chain_gemm<QD, QD, 1, false, 2>(X1, CH_S3, 0, c.o_w, QD, 0, P, [&](int, int m, int n, float v) {
+    OC[m * CH_S2 + n] = v;
+    if (m0 + m < Q) {
+      c.docat[(m0 + m) * QD + n] = v;
+      if (c.drop) c.scaled[(m0 + m) * QD + n] = v * ws[2 * m + n / D];      // the bv gradient's summand
+    }
+  });
+  if (c.drop) {   // dsum_h = docat_h . bv_h, wave = row (k_bias_scale_bwd)
+    const int m = wave;
+    for (int h = 0; h < 2; ++h) {
+      float acc = 0.f;
+      for (int n = lane; n < D; n += 64) acc += OC[m * CH_S2 + h * D + n] * c.bv[h * D + n];
+      acc = wave_sum(acc);
+      if (lane == 0 && m0 + m < Q) c.dsum[(m0 + m) * 2 + h] = acc;
+    }
+  }
+  // value map: dxbar_h = docat_h Wv_h
+  chain_gemm<KD, D, 2, false, 1>(OC, CH_S2, D, c.v_w, KD, D * KD, P, [&](int h, int m, int n, float v) {
+    if (m0 + m < Q) c.dxbar[(m0 + m) * 2 * KD + h * KD + n] = v;
+  });
+}
+
+template <int KD>
+__global__ __launch_bounds__(CH_T) void k_chain_c(orca_tgat_inputs in, int64_t Q, const float* __restrict__ Wk,
+                                                  const float* __restrict__ Wq, const float* __restrict__ dqt,
+                                                  const float* __restrict__ dx1, float* __restrict__ dq,
+                                                  float* __restrict__ d_src, float* __restrict__ d_src_time,
+                                                  float* __restrict__ tgrad) {
+  using L = ChainLds<KD>;
+  extern __shared__ __align__(16) float lds[];
+  float* BIG = lds;
+  float* DQ = BIG + 16 * L::SB;
+  float* DXQ = DQ + 16 * CH_S2;
+  float* P = DXQ + 16 * CH_S2;
+  const int64_t m0 = (int64_t)blockIdx.x * 16;
+  for (int i = threadIdx.x; i < 16 * (2 * KD / 4); i += CH_T) {
+    const int m = i / (2 * KD / 4), c4 = i % (2 * KD / 4);
+    const int64_t q = m0 + m < Q ? m0 + m : Q - 1;
+    *reinterpret_cast<f32x4*>(&BIG[m * L::SB + 4 * c4]) = *reinterpret_cast<const f32x4*>(&dqt[q * 2 * KD + 4 * c4]);
+  }
+  __syncthreads();
+  // key fold: dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs;  q projection: dxq = dq Wq
+  chain_gemm<D, KD, 2, true, 3>(BIG, L::SB, KD, Wk, KD, D * KD, P, [&](int h, int m, int n, float v) {
+    v *= 0.1f;
+    DQ[m * CH_S2 + h * D + n] = v;
+    if (m0 + m < Q) dq[(m0 + m) * QD + h * D + n] = v;
+  });
+  chain_gemm<QD, QD, 1, false, 2>(DQ, CH_S2, 0, Wq, QD, 0, P, [&](int, int m, int n, float v) { DXQ[m * CH_S2 + n] = v; });
+  for (int i = threadIdx.x; i < 16 * D; i += CH_T) {     // k_bwd_finish
+    const int m = i / D, n = i % D;
+    const int64_t q = m0 + m;
+    if (q >= Q) continue;
+    if (d_src) d_src[q * D + n] = dx1[q * 3 * D + QD + n] + DXQ[m * CH_S2 + n];
+    const float dst = DXQ[m * CH_S2 + D + n];
+    if (in.dt) {
+      if (tgrad) tgrad[q * QD + D + n] += -orca_sinf(orca_time_arg(0.0f, in.time_w[n], in.time_b[n])) * dst;
+    } else if (d_src_time) {
+      d_src_time[q * D + n] = dst;
+    }
+  }
+}
+
 struct Ws {   // float offsets of the per-query rows inside the workspace
   int64_t xq, qs, qt, a, xbar, ocat, x1, h1, y, dy, gx, dh1, dx1, docat, dxbar, dqt, dq, dxq, tgrad, invalid, wsum, dsum, scaled,
       part, total;
@@ -788,10 +1116,18 @@ Ws ws_layout(int d_e, int64_t Q, int K) {
   w.scaled = take(QD);
   w.part = o;
   // the eight weight-gradient problems with their bias columns (each rounded up to 64 floats), or a column sum's slices
-  o += (int64_t)SPLITS * ((int64_t)D * (D + 1) + (int64_t)D * (3 * D + 1) + 2 * (int64_t)QD * (QD + 1) + 4 * (int64_t)D * (kdim + 1)) + 64 * 8
-       + 4 * 64 * 320;
+  o += (int64_t)SPLITS * ((int64_t)D * (D + 1) + (int64_t)D * (3 * D + 1) + 2 * (int64_t)QD * (QD + 1) + 4 * (int64_t)D * (kdim + 1) + 2 * D)
+       + 64 * 10 + 4 * 64 * 320;
   w.total = o;
   return w;
+}
+
+// the fused chains are built for d_e = 172 and take float4 rows: 16-byte aligned weights and workspace
+bool chain_usable(const orca_tgat_params* P, int d_e, const float* workspace) {
+  static const bool off = getenv("ORCA_BWD_CHAIN") && atoi(getenv("ORCA_BWD_CHAIN")) == 0;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return !off && d_e == 172 && al16(P->q_w) && al16(P->k_w) && al16(P->v_w) && al16(P->o_w) && al16(P->fc1_w) &&
+         al16(P->fc2_w) && al16(workspace);
 }
 
 }  // namespace
@@ -843,84 +1179,100 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
                 float* C, int64_t scm, int64_t scn, const float* bias, float alpha) {
     return OrcaGemm{M_, N_, K_, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, alpha, 0, 0, nullptr, nullptr, 0, nullptr, 1};
   };
-  // ---- forward recompute -------------------------------------------------------------------------------
-  k_bwd_prep<<<qb, 256, 0, s>>>(*in, Q, xq, x1);
-  // qs = 0.1 (xq Wq^T + bq)                                                    (scaling: head_dim^-0.5)
-  rc |= sgemm(s, M, QD, QD, xq, QD, 1, P->q_w, 1, QD, qs, QD, 1, P->in_b, 0.1f, false, false);
-  {   // q~_h = qs_h Wk_h   [Q,100] x [100,kdim], both heads in one launch
+  // ---- forward recompute, then the data gradients: a chain (fused per 16-row tile when the shapes are the built ones) --
+  const bool chain = chain_usable(P, d_e, workspace);
+  const unsigned tiles = (unsigned)ceil_div64(Q, 16);
+  using CL = ChainLds<QD + 172>;
+  if (chain) {
+    static bool attr_set[64] = {};
+    if (orca_first_use_on_device(attr_set)) {
+      const int lim = 160 * 1024 - 256;
+      const void* fns[] = {(const void*)k_chain_a<QD + 172>, (const void*)k_chain_b<QD + 172>, (const void*)k_chain_c<QD + 172>};
+      for (const void* f : fns) ORCA_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    }
+    k_chain_a<QD + 172><<<tiles, CH_T, CL::A_FLOATS * sizeof(float), s>>>(*in, Q, P->q_w, P->in_b, P->k_w, xq, x1, qs, qt);
+  } else {
+    k_bwd_prep<<<qb, 256, 0, s>>>(*in, Q, xq, x1);
+    // qs = 0.1 (xq Wq^T + bq)                                                    (scaling: head_dim^-0.5)
+    rc |= sgemm(s, M, QD, QD, xq, QD, 1, P->q_w, 1, QD, qs, QD, 1, P->in_b, 0.1f, false, false);
+    // q~_h = qs_h Wk_h   [Q,100] x [100,kdim], both heads in one launch
     OrcaGemm g[2];
     for (int h = 0; h < 2; ++h)
       g[h] = G1(M, kdim, D, qs + h * D, QD, 1, P->k_w + (int64_t)h * D * kdim, kdim, 1, qt + h * kdim, 2 * kdim, 1, nullptr, 1.f);
     rc |= orca_sgemm_group(s, g, 2, nullptr);
   }
   k_bwd_attn_fwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
-  {   // ocat_h = xbar_h Wv_h^T + bv_h  (dropout: + (sum of the head's kept weights) bv_h)
-    OrcaGemm g[2];
-    for (int h = 0; h < 2; ++h)
-      g[h] = G1(M, D, kdim, xbar + h * kdim, 2 * kdim, 1, P->v_w + (int64_t)h * D * kdim, 1, kdim, ocat + h * D, QD, 1,
-                drop ? nullptr : P->in_b + 2 * QD + h * D, 1.f);
-    rc |= orca_sgemm_group(s, g, 2, nullptr);
-  }
-  if (drop) k_add_scaled_bias<<<ew(Q * QD), 256, 0, s>>>(ocat, Q, wsum, P->in_b + 2 * QD);
-  {   // o = ocat Wo^T + bo -> x1[:, 0:200], zero for invalid queries                 (temporal_attention.py:52)
-    OrcaGemm g = G1(M, QD, QD, ocat, QD, 1, P->o_w, 1, QD, x1, 3 * D, 1, P->o_b, 1.f);
-    g.rowzero = invalid;
-    g.rowzero_n = QD;
-    rc |= orca_sgemm_group(s, &g, 1, nullptr);
-  }
-  // h1 = relu(x1 W1^T + b1), y = h1 W2^T + b2                                     (utils/util.py:22-24)
-  rc |= sgemm(s, M, D, 3 * D, x1, 3 * D, 1, P->fc1_w, 1, 3 * D, h1, D, 1, P->fc1_b, 1.f, false, true);
-  rc |= sgemm(s, M, D, D, h1, D, 1, P->fc2_w, 1, D, y, D, 1, P->fc2_b, 1.f, false, false);
-
-  // ---- backward: the data gradients, a chain ------------------------------------------------------------
-  k_bwd_ln<<<qb, 256, 0, s>>>(y, grad_out, P->ln_w, Q, dy, gx);
-  {   // LayerNorm's affine gradients: column sums of g * xhat and of g
-    const float* X[2] = {gx, grad_out};
-    const int64_t ld[2] = {D, D};
-    const int nc[2] = {D, D};
-    float* out[2] = {G->ln_w, G->ln_b};
-    rc |= orca_colsum_group(s, 2, X, ld, nc, out, Q, 1.f, true, part);
-  }
-  {   // fc2: dz1 = (dy W2) where h1 > 0
-    OrcaGemm g = G1(M, D, D, dy, D, 1, P->fc2_w, D, 1, dh1, D, 1, nullptr, 1.f);
-    g.gate = h1;
-    rc |= orca_sgemm_group(s, &g, 1, nullptr);
-  }
-  {   // fc1: dx1 = dz1 W1; do = dx1[:, 0:200] = 0 where the output was zeroed
-    OrcaGemm g = G1(M, 3 * D, D, dh1, D, 1, P->fc1_w, 3 * D, 1, dx1, 3 * D, 1, nullptr, 1.f);
-    g.rowzero = invalid;
-    g.rowzero_n = QD;
-    rc |= orca_sgemm_group(s, &g, 1, nullptr);
-  }
-  // out-proj: docat = do Wo
-  rc |= sgemm(s, M, QD, QD, dx1, 3 * D, 1, P->o_w, QD, 1, docat, QD, 1, nullptr, 1.f, false, false);
-  if (drop)       // docat scaled by the weight sums (the bv gradient's summand), dsum = docat_h . bv_h
-    k_bias_scale_bwd<<<qb, 256, 0, s>>>(docat, Q, wsum, P->in_b + 2 * QD, scaled, dsum);
-  {   // value map: dxbar_h = docat_h Wv_h
-    OrcaGemm g[2];
-    for (int h = 0; h < 2; ++h)
-      g[h] = G1(M, kdim, D, docat + h * D, QD, 1, P->v_w + (int64_t)h * D * kdim, kdim, 1, dxbar + h * kdim, 2 * kdim, 1, nullptr, 1.f);
-    rc |= orca_sgemm_group(s, g, 2, nullptr);
+  if (chain) {
+    const ChainB c{P->v_w, P->in_b + 2 * QD, P->o_w, P->o_b, P->fc1_w, P->fc1_b, P->fc2_w, P->fc2_b, P->ln_w,
+                   grad_out, xbar, invalid, wsum,
+                   x1, ocat, h1, dy, gx, dh1, dx1, docat, dxbar, scaled, dsum, drop ? 1 : 0};
+    k_chain_b<QD + 172><<<tiles, CH_T, CL::B_FLOATS * sizeof(float), s>>>(c, Q);
+  } else {
+    {   // ocat_h = xbar_h Wv_h^T + bv_h  (dropout: + (sum of the head's kept weights) bv_h)
+      OrcaGemm g[2];
+      for (int h = 0; h < 2; ++h)
+        g[h] = G1(M, D, kdim, xbar + h * kdim, 2 * kdim, 1, P->v_w + (int64_t)h * D * kdim, 1, kdim, ocat + h * D, QD, 1,
+                  drop ? nullptr : P->in_b + 2 * QD + h * D, 1.f);
+      rc |= orca_sgemm_group(s, g, 2, nullptr);
+    }
+    if (drop) k_add_scaled_bias<<<ew(Q * QD), 256, 0, s>>>(ocat, Q, wsum, P->in_b + 2 * QD);
+    {   // o = ocat Wo^T + bo -> x1[:, 0:200], zero for invalid queries                 (temporal_attention.py:52)
+      OrcaGemm g = G1(M, QD, QD, ocat, QD, 1, P->o_w, 1, QD, x1, 3 * D, 1, P->o_b, 1.f);
+      g.rowzero = invalid;
+      g.rowzero_n = QD;
+      rc |= orca_sgemm_group(s, &g, 1, nullptr);
+    }
+    // h1 = relu(x1 W1^T + b1), y = h1 W2^T + b2                                     (utils/util.py:22-24)
+    rc |= sgemm(s, M, D, 3 * D, x1, 3 * D, 1, P->fc1_w, 1, 3 * D, h1, D, 1, P->fc1_b, 1.f, false, true);
+    rc |= sgemm(s, M, D, D, h1, D, 1, P->fc2_w, 1, D, y, D, 1, P->fc2_b, 1.f, false, false);
+    k_bwd_ln<<<qb, 256, 0, s>>>(y, grad_out, P->ln_w, Q, dy, gx);
+    {   // fc2: dz1 = (dy W2) where h1 > 0
+      OrcaGemm g = G1(M, D, D, dy, D, 1, P->fc2_w, D, 1, dh1, D, 1, nullptr, 1.f);
+      g.gate = h1;
+      rc |= orca_sgemm_group(s, &g, 1, nullptr);
+    }
+    {   // fc1: dx1 = dz1 W1; do = dx1[:, 0:200] = 0 where the output was zeroed
+      OrcaGemm g = G1(M, 3 * D, D, dh1, D, 1, P->fc1_w, 3 * D, 1, dx1, 3 * D, 1, nullptr, 1.f);
+      g.rowzero = invalid;
+      g.rowzero_n = QD;
+      rc |= orca_sgemm_group(s, &g, 1, nullptr);
+    }
+    // out-proj: docat = do Wo
+    rc |= sgemm(s, M, QD, QD, dx1, 3 * D, 1, P->o_w, QD, 1, docat, QD, 1, nullptr, 1.f, false, false);
+    if (drop)       // docat scaled by the weight sums (the bv gradient's summand), dsum = docat_h . bv_h
+      k_bias_scale_bwd<<<qb, 256, 0, s>>>(docat, Q, wsum, P->in_b + 2 * QD, scaled, dsum);
+    {   // value map: dxbar_h = docat_h Wv_h
+      OrcaGemm g[2];
+      for (int h = 0; h < 2; ++h)
+        g[h] = G1(M, kdim, D, docat + h * D, QD, 1, P->v_w + (int64_t)h * D * kdim, kdim, 1, dxbar + h * kdim, 2 * kdim, 1, nullptr, 1.f);
+      rc |= orca_sgemm_group(s, g, 2, nullptr);
+    }
   }
   const bool want_t = in->dt && d_time_w;
   if (K <= 10)
     k_bwd_attn_bwd<10><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
   else
     k_bwd_attn_bwd<ORCA_MAX_K><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
-  {   // key fold: dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs
-    OrcaGemm g[2];
-    for (int h = 0; h < 2; ++h)
-      g[h] = G1(M, D, kdim, dqt + h * kdim, 2 * kdim, 1, P->k_w + (int64_t)h * D * kdim, 1, kdim, dq + h * D, QD, 1, nullptr, 0.1f);
-    rc |= orca_sgemm_group(s, g, 2, nullptr);
+  if (chain) {
+    k_chain_c<QD + 172><<<tiles, CH_T, CL::C_FLOATS * sizeof(float), s>>>(*in, Q, P->k_w, P->q_w, dqt, dx1, dq, d_src, d_src_time,
+                                                                       want_t ? tgrad : nullptr);
+  } else {
+    {   // key fold: dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs
+      OrcaGemm g[2];
+      for (int h = 0; h < 2; ++h)
+        g[h] = G1(M, D, kdim, dqt + h * kdim, 2 * kdim, 1, P->k_w + (int64_t)h * D * kdim, 1, kdim, dq + h * D, QD, 1, nullptr, 0.1f);
+      rc |= orca_sgemm_group(s, g, 2, nullptr);
+    }
+    // q projection: dxq = dq Wq
+    rc |= sgemm(s, M, QD, QD, dq, QD, 1, P->q_w, QD, 1, dxq, QD, 1, nullptr, 1.f, false, false);
+    k_bwd_finish<<<ew(Q * D), 256, 0, s>>>(*in, Q, dx1, dxq, d_src, d_src_time, want_t ? tgrad : nullptr);
   }
-  // q projection: dxq = dq Wq
-  rc |= sgemm(s, M, QD, QD, dq, QD, 1, P->q_w, QD, 1, dxq, QD, 1, nullptr, 1.f, false, false);
-  k_bwd_finish<<<ew(Q * D), 256, 0, s>>>(*in, Q, dx1, dxq, d_src, d_src_time, want_t ? tgrad : nullptr);
   // ---- backward: every weight gradient (a reduction over the queries) in ONE split-K launch, the bias gradients as a
   // column of ones:  dW2 += dy^T h1, dW1 += dz1^T x1, dWo += do^T ocat, dWv_h += docat_h^T xbar_h, dWk_h += qs_h^T dq~_h
-  // (the bk gradient is zero: softmax is shift-invariant), dWq += dq^T xq
+  // (the bk gradient is zero: softmax is shift-invariant), dWq += dq^T xq;  LayerNorm's affine gradients -- column
+  // sums of g * xhat and of g -- ride along as two problems that have only the ones column
   {
-    OrcaGemm g[8];
+    OrcaGemm g[10];
     auto GW = [&](int M_, int N_, const float* A, int64_t sak, const float* B, int64_t sbk, float* C, float* bias_grad) {
       OrcaGemm r = G1(M_, N_, M, A, 1, sak, B, sbk, 1, C, N_, 1, nullptr, 1.f);
       r.accumulate = 1;
@@ -937,7 +1289,9 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
       g[5 + h] = GW(D, kdim, qs + h * D, QD, dqt + h * kdim, 2 * kdim, G->k_w + (int64_t)h * D * kdim, nullptr);
     }
     g[7] = GW(QD, QD, dq, QD, xq, QD, G->q_w, G->in_b);
-    rc |= orca_sgemm_group(s, g, 8, part);
+    g[8] = GW(D, 0, gx, D, gx, 0, nullptr, G->ln_w);
+    g[9] = GW(D, 0, grad_out, D, grad_out, 0, nullptr, G->ln_b);
+    rc |= orca_sgemm_group(s, g, 10, part);
   }
   {   // what is left of the bias-like gradients: the value bias under dropout, the time encoder's w and b
     const float* X[3];
