@@ -492,25 +492,61 @@ __device__ __forceinline__ Slots load_slots(const orca_tgat_inputs& in, int64_t 
   }
   return S;
 }
-// this lane's columns c = lane + 64 i of key row j: [nbr (100) | edge (d_e) | time (100)]
-__device__ __forceinline__ void key_row(float (&x)[MAXC], const orca_tgat_inputs& in, const Slots& S, int64_t q, int j,
-                                        int K, int d_e, int lane) {
+// A key row [nbr (100) | edge (d_e) | time (100)] as NS register slots per lane, one kind of column per slot (no
+// per-column branches: every load is unconditional and clamped): slots 0-1 the neighbour's row (columns lane,
+// lane + 64), 2 .. 1+MAXE the edge row, the last two the time encoding.
+constexpr int MAXE = (ORCA_MAX_DE + 63) / 64, NS = MAXE + 4;
+__device__ __forceinline__ int slot_col(int s, int lane, int d_e) {
+  return s < 2 ? lane + 64 * s : s < 2 + MAXE ? D + lane + 64 * (s - 2) : D + d_e + lane + 64 * (s - 2 - MAXE);
+}
+__device__ __forceinline__ bool slot_ok(int s, int lane, int d_e) {
+  return s < 2 ? lane + 64 * s < D : s < 2 + MAXE ? lane + 64 * (s - 2) < d_e : lane + 64 * (s - 2 - MAXE) < D;
+}
+struct TimeCols { float w0, w1, b0, b1; };      // this lane's columns of the time encoder (gather mode)
+__device__ __forceinline__ TimeCols load_time_cols(const orca_tgat_inputs& in, int lane) {
+  TimeCols t{0.f, 0.f, 0.f, 0.f};
+  if (in.dt) {
+    const int c1 = lane + 64 < D ? lane + 64 : 0;
+    t.w0 = in.time_w[lane]; t.b0 = in.time_b[lane];
+    t.w1 = in.time_w[c1]; t.b1 = in.time_b[c1];
+  }
+  return t;
+}
+__device__ __forceinline__ void key_row(float (&x)[NS], const orca_tgat_inputs& in, const Slots& S, const TimeCols& tc,
+                                        int64_t q, int j, int K, int d_e, int lane) {
   const int nr = __shfl(S.nrow, j, 64), er = __shfl(S.erow, j, 64), ov = __shfl(S.ovl, j, 64);
   const float dt = __shfl(S.dt, j, 64);
   const float* np = (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D;
   const float* ep = in.edge_table + (int64_t)er * d_e;
-  const int kdim = QD + d_e;
+  const bool hi = lane + 64 < D;
+  x[0] = np[lane];
+  x[1] = np[hi ? lane + 64 : 0];
+  if (!hi) x[1] = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
+  for (int i = 0; i < MAXE; ++i) {
     const int c = lane + 64 * i;
-    float v = 0.f;
-    if (c < D) v = np[c];
-    else if (c < D + d_e) v = ep[c - D];
-    else if (c < kdim) {
-      const int ct = c - D - d_e;
-      v = in.dt ? orca_cosf(orca_time_arg(dt, in.time_w[ct], in.time_b[ct])) : in.nbr_time[(q * K + j) * D + ct];
-    }
-    x[i] = v;
+    x[2 + i] = ep[c < d_e ? c : 0];
+    if (c >= d_e) x[2 + i] = 0.f;
+  }
+  if (in.dt) {
+    x[2 + MAXE] = orca_cosf(orca_time_arg(dt, tc.w0, tc.b0));
+    x[3 + MAXE] = hi ? orca_cosf(orca_time_arg(dt, tc.w1, tc.b1)) : 0.f;
+  } else {
+    const float* tp = in.nbr_time + (q * K + j) * D;
+    x[2 + MAXE] = tp[lane];
+    x[3 + MAXE] = tp[hi ? lane + 64 : 0];
+    if (!hi) x[3 + MAXE] = 0.f;
+  }
+}
+// a [2 x kdim] row of the workspace (q~, dxbar, ...) in the same slots
+__device__ __forceinline__ void load_slots2(float (&v0)[NS], float (&v1)[NS], const float* __restrict__ p, int kdim, int d_e, int lane) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const bool ok = slot_ok(s, lane, d_e);
+    const int c = ok ? slot_col(s, lane, d_e) : 0;
+    v0[s] = p[c];
+    v1[s] = p[kdim + c];
+    if (!ok) v0[s] = v1[s] = 0.f;
   }
 }
 
@@ -531,72 +567,89 @@ __global__ __launch_bounds__(256) void k_bwd_prep(orca_tgat_inputs in, int64_t Q
 }
 
 // recompute of the attention core: a[q][h][j] = softmax_j(q~_h . x_j) over the unmasked slots,
-// xbar[q][h] = sum_j a_hj x_j;  invalid[q] = 1 for an all-padded query (temporal_attention.py:46-47,52)
-// (gathering the K rows once into registers, as k_bwd_attn_bwd does, measured slower here: 47 vs 35 us -- at 188
-// VGPRs the launch no longer fits the chip in one round, and two passes over the rows do not pay for that)
-__global__ __launch_bounds__(256) void k_bwd_attn_fwd(orca_tgat_inputs in, int64_t Q, int K, int d_e,
-                                                      const float* __restrict__ qt, float* __restrict__ a_out,
-                                                      float* __restrict__ xbar, float* __restrict__ invalid,
-                                                      float* __restrict__ wsum) {
+// xbar[q][h] = sum_j a_hj x_j;  invalid[q] = 1 for an all-padded query (temporal_attention.py:46-47,52).
+// One wave per query; a wave is alone with its chain of row gathers (the launch is a single round of 16 waves per CU),
+// so the rows are fetched FIVE at a time and visited once: scores of the five, then an online softmax (running maximum,
+// accumulators rescaled when it moves) adds them to the weighted sums -- two dependent memory round trips per query
+// instead of twenty (one row per trip, two passes: 35 us per launch).  KT = compile-time bound of K.
+constexpr int AF_ROWS = 5;
+template <int KT>
+__global__ __launch_bounds__(256, 4) void k_bwd_attn_fwd(orca_tgat_inputs in, int64_t Q, int K, int d_e,
+                                                         const float* __restrict__ qt, float* __restrict__ a_out,
+                                                         float* __restrict__ xbar, float* __restrict__ invalid,
+                                                         float* __restrict__ wsum) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= Q) return;
   const int kdim = QD + d_e;
   const Slots S = load_slots(in, q, K, lane);
+  const TimeCols tc = load_time_cols(in, lane);
   unsigned long long live = __ballot(lane < K && !S.masked);
   const bool inv = live == 0ull;
   if (inv) live = 1ull;
-  float q0[MAXC], q1[MAXC];
+  float q0[NS], q1[NS], b0[NS], b1[NS];
+  load_slots2(q0, q1, qt + q * 2 * kdim, kdim, d_e, lane);
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    q0[i] = c < kdim ? qt[q * 2 * kdim + c] : 0.f;
-    q1[i] = c < kdim ? qt[q * 2 * kdim + kdim + c] : 0.f;
-  }
-  float s0 = -INFINITY, s1 = -INFINITY;
-  for (int j = 0; j < K; ++j) {
-    float x[MAXC];
-    key_row(x, in, S, q, j, K, d_e, lane);
-    float p0 = 0.f, p1 = 0.f;
+  for (int s = 0; s < NS; ++s) b0[s] = b1[s] = 0.f;
+  const bool drop = in.dropout_p > 0.f;
+  const float dsc = drop ? 1.0f / (1.0f - in.dropout_p) : 1.f;
+  float s0 = 0.f, s1 = 0.f;                   // lane j keeps the scores of slot j
+  float m0 = -INFINITY, m1 = -INFINITY;       // running maxima, sums of exponentials, sums of kept weights
+  float l0 = 0.f, l1 = 0.f, w0s = 0.f, w1s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) { p0 += x[i] * q0[i]; p1 += x[i] * q1[i]; }
-    p0 = wave_sum(p0);
-    p1 = wave_sum(p1);
-    if (lane == j && ((live >> j) & 1ull)) { s0 = p0; s1 = p1; }
-  }
-  const float m0 = wave_max_f(s0), m1 = wave_max_f(s1);
-  float e0 = (lane < K && ((live >> lane) & 1ull)) ? expf(s0 - m0) : 0.f;
-  float e1 = (lane < K && ((live >> lane) & 1ull)) ? expf(s1 - m1) : 0.f;
-  float a0 = e0 / wave_sum(e0), a1 = e1 / wave_sum(e1);
-  if (lane < K) {     // the softmax output itself (its backward needs it); dropout acts on what is summed below
-    a_out[(q * 2 + 0) * K + lane] = a0;
-    a_out[(q * 2 + 1) * K + lane] = a1;
-  }
-  if (in.dropout_p > 0.f) {
-    const float sc = 1.0f / (1.0f - in.dropout_p);
-    const int j = lane < K ? lane : 0;
-    a0 *= orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, 0, j, in.dropout_p, sc);
-    a1 *= orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, 1, j, in.dropout_p, sc);
-    const float s0 = wave_sum(a0), s1 = wave_sum(a1);
-    if (lane == 0) { wsum[q * 2] = s0; wsum[q * 2 + 1] = s1; }
-  }
-  float b0[MAXC], b1[MAXC];
+  for (int jb = 0; jb < KT; jb += AF_ROWS) {
+    if (jb >= K) break;                       // wave-uniform
+    float x[AF_ROWS][NS], p0[AF_ROWS], p1[AF_ROWS];
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) b0[i] = b1[i] = 0.f;
-  for (int j = 0; j < K; ++j) {
-    if (!((live >> j) & 1ull)) continue;   // wave-uniform
-    float x[MAXC];
-    key_row(x, in, S, q, j, K, d_e, lane);
-    const float w0 = __shfl(a0, j, 64), w1 = __shfl(a1, j, 64);
+    for (int u = 0; u < AF_ROWS; ++u) key_row(x[u], in, S, tc, q, jb + u < K ? jb + u : 0, K, d_e, lane);
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) { b0[i] += w0 * x[i]; b1[i] += w1 * x[i]; }
+    for (int u = 0; u < AF_ROWS; ++u) {
+      p0[u] = p1[u] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { p0[u] += x[u][s] * q0[s]; p1[u] += x[u][s] * q1[s]; }
+    }
+#pragma unroll
+    for (int u = 0; u < AF_ROWS; ++u) { p0[u] = wave_sum(p0[u]); p1[u] = wave_sum(p1[u]); }
+    float n0 = m0, n1 = m1;
+#pragma unroll
+    for (int u = 0; u < AF_ROWS; ++u) {
+      const bool ok = jb + u < K && ((live >> (jb + u)) & 1ull);
+      if (ok) { n0 = fmaxf(n0, p0[u]); n1 = fmaxf(n1, p1[u]); }
+      if (lane == jb + u) { s0 = p0[u]; s1 = p1[u]; }
+    }
+    const float r0 = m0 == -INFINITY ? 0.f : expf(m0 - n0), r1 = m1 == -INFINITY ? 0.f : expf(m1 - n1);
+    l0 *= r0; l1 *= r1; w0s *= r0; w1s *= r1;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { b0[s] *= r0; b1[s] *= r1; }
+    m0 = n0; m1 = n1;
+#pragma unroll
+    for (int u = 0; u < AF_ROWS; ++u) {
+      const bool ok = jb + u < K && ((live >> (jb + u)) & 1ull);      // wave-uniform
+      const float e0 = ok ? expf(p0[u] - m0) : 0.f, e1 = ok ? expf(p1[u] - m1) : 0.f;
+      l0 += e0; l1 += e1;
+      float w0 = e0, w1 = e1;     // dropout acts on what is summed, not on the softmax output itself
+      if (drop) {
+        w0 *= orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, 0, jb + u, in.dropout_p, dsc);
+        w1 *= orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, 1, jb + u, in.dropout_p, dsc);
+      }
+      w0s += w0; w1s += w1;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { b0[s] += w0 * x[u][s]; b1[s] += w1 * x[u][s]; }
+    }
   }
+  const float i0 = 1.0f / l0, i1 = 1.0f / l1;
+  if (lane < K) {     // the softmax output itself (its backward needs it)
+    const bool ok = (live >> lane) & 1ull;
+    a_out[(q * 2 + 0) * K + lane] = ok ? expf(s0 - m0) * i0 : 0.f;
+    a_out[(q * 2 + 1) * K + lane] = ok ? expf(s1 - m1) * i1 : 0.f;
+  }
+  if (drop && lane == 0) { wsum[q * 2] = w0s * i0; wsum[q * 2 + 1] = w1s * i1; }
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (c < kdim) {
-      xbar[q * 2 * kdim + c] = b0[i];
-      xbar[q * 2 * kdim + kdim + c] = b1[i];
+  for (int s = 0; s < NS; ++s) {
+    if (slot_ok(s, lane, d_e)) {
+      const int c = slot_col(s, lane, d_e);
+      xbar[q * 2 * kdim + c] = b0[s] * i0;
+      xbar[q * 2 * kdim + kdim + c] = b1[s] * i1;
     }
   }
   if (lane == 0) invalid[q] = inv ? 1.f : 0.f;
@@ -654,101 +707,130 @@ __global__ __launch_bounds__(256) void k_bwd_ln(const float* __restrict__ y, con
   }
 }
 
-// backward of the attention core.  In: dxbar[q][h] (gradient of the weighted key sums), a, q~.  Out:
-// dqt[q][h] = sum_j ds_hj x_j with ds = softmax backward of da_hj = dxbar_h . x_j;  the key-row gradient
-// dx_j = sum_h (a_hj dxbar_h + ds_hj q~_h) goes to d_nbr (columns 0..99), is dropped for the edge columns (the edge
+__device__ __forceinline__ float mul_rounded(float a, float b) {     // a product that is never fused into an fma
+#pragma clang fp contract(off)
+  return a * b;
+}
+// backward of the attention core.  In: dxbar[q][h] = g_h (gradient of the weighted key sums), a, q~.  Out:
+// dqt[q][h] = sum_j ds_hj x_j with ds = softmax backward of da_hj = g_h . x_j;  the key-row gradient
+// dx_j = sum_h (a_hj g_h + ds_hj q~_h) goes to d_nbr (columns 0..99), is dropped for the edge columns (the edge
 // features are data, not parameters) and for the time columns goes to d_nbr_time (dense mode) or, through
 // d cos(dt w + b), into this query's row of tgrad = [d time_w | d time_b] (gather mode).
-// KT = compile-time bound of K: the K key rows of a query are gathered ONCE into registers for the three passes
-// (66 -> 56 us per launch)
+// The key rows are visited ONCE, five at a time (as in k_bwd_attn_fwd): with c_h = sum_i a_hi da_hi,
+// sum_j ds_hj x_j = sum_j a_hj da_hj x_j - c_h sum_j a_hj x_j, two sums that need no second look at the rows, and dx_j
+// needs no x_j at all.  (Keeping all K rows in registers for two passes took 197 VGPRs: two rounds of waves, 49 us.)
 template <int KT>
-__global__ __launch_bounds__(256) void k_bwd_attn_bwd(orca_tgat_inputs in, int64_t Q, int K, int d_e,
-                                                      const float* __restrict__ qt, const float* __restrict__ a_in,
-                                                      const float* __restrict__ dxbar, float* __restrict__ dqt,
-                                                      float* __restrict__ d_nbr, float* __restrict__ d_nbr_time,
-                                                      float* __restrict__ tgrad, const float* __restrict__ dsum) {
+__global__ __launch_bounds__(256, 4) void k_bwd_attn_bwd(orca_tgat_inputs in, int64_t Q, int K, int d_e,
+                                                         const float* __restrict__ qt, const float* __restrict__ a_in,
+                                                         const float* __restrict__ dxbar, float* __restrict__ dqt,
+                                                         float* __restrict__ d_nbr, float* __restrict__ d_nbr_time,
+                                                         float* __restrict__ tgrad, const float* __restrict__ dsum) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= Q) return;
-  const int kdim = QD + d_e, t0 = D + d_e;
+  const int kdim = QD + d_e;
   const Slots S = load_slots(in, q, K, lane);
-  float q0[MAXC], q1[MAXC], g0[MAXC], g1[MAXC], r0[MAXC], r1[MAXC], tw[MAXC], tb[MAXC];
+  const TimeCols tc = load_time_cols(in, lane);
+  float g0[NS], g1[NS], t0[NS], t1[NS], u0[NS], u1[NS];
+  load_slots2(g0, g1, dxbar + q * 2 * kdim, kdim, d_e, lane);
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    const bool ok = c < kdim;
-    q0[i] = ok ? qt[q * 2 * kdim + c] : 0.f;
-    q1[i] = ok ? qt[q * 2 * kdim + kdim + c] : 0.f;
-    g0[i] = ok ? dxbar[q * 2 * kdim + c] : 0.f;
-    g1[i] = ok ? dxbar[q * 2 * kdim + kdim + c] : 0.f;
-    r0[i] = r1[i] = tw[i] = tb[i] = 0.f;
-  }
+  for (int s = 0; s < NS; ++s) t0[s] = t1[s] = u0[s] = u1[s] = 0.f;
   const float a0 = lane < K ? a_in[(q * 2 + 0) * K + lane] : 0.f;
   const float a1 = lane < K ? a_in[(q * 2 + 1) * K + lane] : 0.f;
-  float x[KT][MAXC];
-#pragma unroll
-  for (int j = 0; j < KT; ++j) key_row(x[j], in, S, q, j < K ? j : 0, K, d_e, lane);
-  float da0 = 0.f, da1 = 0.f;
-#pragma unroll
-  for (int j = 0; j < KT; ++j) {
-    if (j >= K) continue;   // (no break: the loop must unroll fully, x[][] lives in registers)
-    float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) { p0 += x[j][i] * g0[i]; p1 += x[j][i] * g1[i]; }
-    p0 = wave_sum(p0);
-    p1 = wave_sum(p1);
-    if (lane == j) { da0 = p0; da1 = p1; }
-  }
   // dropout: the key sums (and each head's weight sum, whose gradient is dsum) were taken with a' = a * mult
-  float m0 = 1.f, m1 = 1.f;
+  float m0 = 1.f, m1 = 1.f, ds0 = 0.f, ds1 = 0.f;
   if (in.dropout_p > 0.f) {
     const float sc = 1.0f / (1.0f - in.dropout_p);
     const int j = lane < K ? lane : 0;
     m0 = orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, 0, j, in.dropout_p, sc);
     m1 = orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, 1, j, in.dropout_p, sc);
-    da0 = (da0 + dsum[q * 2]) * m0;
-    da1 = (da1 + dsum[q * 2 + 1]) * m1;
+    ds0 = dsum[q * 2];
+    ds1 = dsum[q * 2 + 1];
   }
-  const float ds0 = a0 * (da0 - wave_sum(a0 * da0)), ds1 = a1 * (da1 - wave_sum(a1 * da1));
+  float da0 = 0.f, da1 = 0.f;      // lane j: da_hj - z_h
+  // (softmax backward does not see a constant z_h added to da_h.: slot 0's value is taken off, which keeps the two sums
+  // below -- they cancel against each other -- small when the da share a large common part)
+  float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+  for (int jb = 0; jb < KT; jb += AF_ROWS) {
+    if (jb >= K) break;            // wave-uniform
+    float x[AF_ROWS][NS], p0[AF_ROWS], p1[AF_ROWS];
+#pragma unroll
+    for (int u = 0; u < AF_ROWS; ++u) key_row(x[u], in, S, tc, q, jb + u < K ? jb + u : 0, K, d_e, lane);
+#pragma unroll
+    for (int u = 0; u < AF_ROWS; ++u) {
+      p0[u] = p1[u] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { p0[u] += x[u][s] * g0[s]; p1[u] += x[u][s] * g1[s]; }
+    }
+#pragma unroll
+    for (int u = 0; u < AF_ROWS; ++u) { p0[u] = wave_sum(p0[u]); p1[u] = wave_sum(p1[u]); }
+    if (jb == 0) {
+      z0 = (p0[0] + ds0) * __shfl(m0, 0, 64);
+      z1 = (p1[0] + ds1) * __shfl(m1, 0, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < AF_ROWS; ++u) {
+      const bool ok = jb + u < K;
+      const int j = ok ? jb + u : 0;
+      const float w0 = ok ? __shfl(a0, j, 64) : 0.f, w1 = ok ? __shfl(a1, j, 64) : 0.f;
+      const float d0 = (p0[u] + ds0) * __shfl(m0, j, 64) - z0, d1 = (p1[u] + ds1) * __shfl(m1, j, 64) - z1;
+      if (lane == jb + u) { da0 = d0; da1 = d1; }
+      const float e0 = w0 * d0, e1 = w1 * d1;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        t0[s] += e0 * x[u][s]; t1[s] += e1 * x[u][s];
+        u0[s] += w0 * x[u][s]; u1[s] += w1 * x[u][s];
+      }
+    }
+  }
+  const float c0 = wave_sum(a0 * da0), c1 = wave_sum(a1 * da1);
+  const float s0 = a0 * (da0 - c0), s1 = a1 * (da1 - c1);      // lane j: ds_hj
   const float aw0 = a0 * m0, aw1 = a1 * m1;
 #pragma unroll
-  for (int j = 0; j < KT; ++j) {
-    if (j >= K) continue;   // (no break: the loop must unroll fully, x[][] lives in registers)
-    const float w0 = __shfl(aw0, j, 64), w1 = __shfl(aw1, j, 64), e0 = __shfl(ds0, j, 64), e1 = __shfl(ds1, j, 64);
+  for (int s = 0; s < NS; ++s) {
+    if (slot_ok(s, lane, d_e)) {
+      const int c = slot_col(s, lane, d_e);
+      // (products rounded before the subtraction, not fused into it: with a single live slot both terms are the same
+      // rounded number and the gradient is exactly zero, as autograd's is)
+      dqt[q * 2 * kdim + c] = t0[s] - mul_rounded(c0, u0[s]);
+      dqt[q * 2 * kdim + kdim + c] = t1[s] - mul_rounded(c1, u1[s]);
+    }
+  }
+  // the key-row gradients: dx_j = a'_0j g_0 + a'_1j g_1 + ds_0j q~_0 + ds_1j q~_1 on the neighbour and time columns
+  float q0[NS], q1[NS];
+  load_slots2(q0, q1, qt + q * 2 * kdim, kdim, d_e, lane);
+  float tw[2] = {0.f, 0.f}, tb[2] = {0.f, 0.f};
+  const bool hi = lane + 64 < D;
+  for (int j = 0; j < K; ++j) {
+    const float w0 = __shfl(aw0, j, 64), w1 = __shfl(aw1, j, 64), e0 = __shfl(s0, j, 64), e1 = __shfl(s1, j, 64);
     const float dt = __shfl(S.dt, j, 64);
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int c = lane + 64 * i;
-      r0[i] += e0 * x[j][i];
-      r1[i] += e1 * x[j][i];
-      const float dx = w0 * g0[i] + w1 * g1[i] + e0 * q0[i] + e1 * q1[i];
-      if (c < D) {
-        d_nbr[(q * K + j) * D + c] = dx;
-      } else if (c >= t0 && c < kdim) {
-        const int ct = c - t0;
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int sn = h2, st = 2 + MAXE + h2;
+      const float dxn = w0 * g0[sn] + w1 * g1[sn] + e0 * q0[sn] + e1 * q1[sn];
+      const float dxt = w0 * g0[st] + w1 * g1[st] + e0 * q0[st] + e1 * q1[st];
+      if (h2 == 0 || hi) {
+        const int c = lane + 64 * h2;
+        d_nbr[(q * K + j) * D + c] = dxn;
         if (in.dt) {
           if (tgrad) {
-            const float arg = orca_time_arg(dt, in.time_w[ct], in.time_b[ct]);
-            const float dth = -orca_sinf(arg) * dx;
-            tw[i] += dt * dth;
-            tb[i] += dth;
+            const float dth = -orca_sinf(orca_time_arg(dt, h2 ? tc.w1 : tc.w0, h2 ? tc.b1 : tc.b0)) * dxt;
+            tw[h2] += dt * dth;
+            tb[h2] += dth;
           }
         } else if (d_nbr_time) {
-          d_nbr_time[(q * K + j) * D + ct] = dx;
+          d_nbr_time[(q * K + j) * D + c] = dxt;
         }
       }
     }
   }
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (c < kdim) {
-      dqt[q * 2 * kdim + c] = r0[i];
-      dqt[q * 2 * kdim + kdim + c] = r1[i];
-    }
-    if (tgrad && c >= t0 && c < kdim) {
-      tgrad[q * QD + (c - t0)] = tw[i];
-      tgrad[q * QD + D + (c - t0)] = tb[i];
+  if (tgrad) {
+    tgrad[q * QD + lane] = tw[0];
+    tgrad[q * QD + D + lane] = tb[0];
+    if (hi) {
+      tgrad[q * QD + lane + 64] = tw[1];
+      tgrad[q * QD + D + lane + 64] = tb[1];
     }
   }
 }
@@ -783,111 +865,179 @@ __global__ void k_bwd_finish(orca_tgat_inputs in, int64_t Q, const float* __rest
 //   chain C: dqs_h = 0.1 dq~_h Wk_h^T -> dxq = dq Wq -> d_src / time gradients
 constexpr int CH_WAVES = 16, CH_T = 64 * CH_WAVES;
 
+// One stage: C_h [16 x N] = A[:, h*ash : h*ash + K] B_h for h < NH.  A in LDS (row stride lda).  B_h is a weight
+// matrix, used transposed (KFAST: the matrix is k-contiguous, a wave's tile is 16 columns) or as stored (a 32-column
+// tile, two columns per lane).  The weights are read from a copy in MFMA-fragment order (k_chain_pack, one launch per
+// backward call): every wave load is 1 KB contiguous -- straight from the row-major tensors a load touched 16 half
+// lines and the stages ran at 34 GB/s per CU, half of what packed weights stream at.  The NH*NT tiles x KS reduction
+// pieces ("items") are dealt to the 16 waves, round by round; an item's weights arrive in chunks of 8 fragments
+// (Frag), and the NEXT chunk -- of this item, of the wave's next item, or the first of the NEXT STAGE -- is requested
+// before the current one is multiplied.  Rounds and chunks are compile-time and fully unrolled (no loop-carried
+// loads: s_waitcnt placement stays exact).  KS > 1: the pieces meet in P and are added in a fixed order.
+// epi(h, m, n, value) stores an element; run() ends with a barrier.
+struct Frag { float v[32]; };
+
 template <int N, int K, int NH, bool KFAST, int KS>
-struct ChainShape {
-  static_assert(K % 4 == 0 && N % 2 == 0, "float4 rows of A, float2 columns of B");
+struct ChainStage {
+  static_assert(K % 4 == 0 && N % 2 == 0, "float4 rows of A, two columns per lane");
   static constexpr int TW = KFAST ? 16 : 32;               // columns of a wave's tile
-  static constexpr int NT = (N + TW - 1) / TW;
-  static constexpr int NP = NT * TW;
+  static constexpr int NT = (N + TW - 1) / TW, NP = NT * TW;
   static constexpr int KB = (K + 15) / 16;                 // 16-deep blocks of the reduction
-  static constexpr int BPI = (KB + KS - 1) / KS;           // blocks per work item
+  static constexpr int BPI = (KB + KS - 1) / KS;           // blocks per item
   static constexpr int ITEMS = NH * NT * KS;
   static constexpr int PFLOATS = KS > 1 ? KS * NH * 16 * NP : 0;
-};
+  static constexpr int FPB = KFAST ? 1 : 2;                // fragments ([64 lanes][4 floats]) per block
+  static constexpr int CB = 8 / FPB;                       // blocks per chunk
+  static constexpr int CPI = (BPI + CB - 1) / CB;          // chunks per item
+  static constexpr int R = (ITEMS + CH_WAVES - 1) / CH_WAVES;
+  static constexpr int FRAGS = NH * NT * KB * FPB;         // of the packed copy: [tile = h*NT + nt][block][FPB]
+  const float* Wp;
 
-// One stage: C_h [16 x N] = A[:, h*ash : h*ash + K] B_h for h < NH.  A in LDS (row stride lda); B_h = B + h*bsh in
-// global memory with B_h(k, n) = B_h[n*ldb + k] (KFAST: a weight matrix used transposed, float4 along k) or
-// B_h[k*ldb + n] (float2 along n, a 32-column tile).  The NH*NT tiles x KS reduction pieces are dealt to the 16 waves;
-// a piece's weights (BPI blocks) are all requested before its first MFMA.  KS > 1: the pieces meet in P and are added
-// in a fixed order.  epi(h, m, n, value) stores an element; ends with a barrier.
-template <int N, int K, int NH, bool KFAST, int KS, class Epi>
-__device__ __forceinline__ void chain_gemm(const float* As, int lda, int ash, const float* __restrict__ B, int ldb,
-                                           int bsh, float* P, Epi epi) {
-  using S = ChainShape<N, K, NH, KFAST, KS>;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, kq = lane >> 4;
-  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int item = wave; item < S::ITEMS; item += CH_WAVES) {
-    const int ks = item / (NH * S::NT), tile = item % (NH * S::NT), h = tile / S::NT, nt = tile % S::NT;
-    const float* ap = As + r * lda + h * ash + 4 * kq;
-    const int kb0 = ks * S::BPI;
-    if constexpr (KFAST) {
-      const int n = nt * 16 + r;
+  // requests chunk ch of an item's weights (item and block clamped: never skipped; what lies past K is multiplied by
+  // zeros of A)
+  __device__ __forceinline__ void load(Frag& f, int item, int ch) const {
+    const int lane = threadIdx.x & 63;
+    item = item < ITEMS ? item : ITEMS - 1;
+    const int ks = item / (NH * NT), tile = item % (NH * NT);
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      if (ch * CB + i >= BPI) continue;
+      int kb = ks * BPI + ch * CB + i;
+      if (KS * BPI > KB) kb = kb < KB ? kb : KB - 1;
+      const float* bp = Wp + ((int64_t)(tile * KB + kb) * FPB * 64 + lane) * 4;
+#pragma unroll
+      for (int u = 0; u < FPB; ++u) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(bp + u * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.v[4 * (i * FPB + u) + e] = t[e];
+      }
+    }
+  }
+
+  // f: chunk 0 of item `wave`, requested earlier; on return f holds whatever next(f) requested (the next stage's first)
+  template <class Epi, class Next>
+  __device__ __forceinline__ void run(Frag& f, const float* As, int lda, int ash, float* P, Epi epi, Next next) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const int item = wave + CH_WAVES * rr;
+      const bool active = item < ITEMS;                    // wave-uniform
+      const int itc = active ? item : ITEMS - 1;
+      const int ks = itc / (NH * NT), tile = itc % (NH * NT), h = tile / NT, nt = tile % NT;
+      const float* ap = As + r * lda + h * ash + 4 * kq;
+      const int n = KFAST ? nt * 16 + r : nt * 32 + 2 * r;
       const bool nok = n < N;
-      const float* bp = B + (int64_t)h * bsh + (int64_t)(nok ? n : 0) * ldb + 4 * kq;
-      f32x4 b[S::BPI];
-#pragma unroll
-      for (int i = 0; i < S::BPI; ++i) {
-        const int k0 = 16 * (kb0 + i);
-        const bool ok = k0 + 4 * kq < K;
-        b[i] = *reinterpret_cast<const f32x4*>(bp + (ok ? k0 : 0));      // clamped, never skipped
-        if (!ok || !nok) b[i] = zero4;
-      }
-      f32x4 acc = zero4;
-#pragma unroll
-      for (int i = 0; i < S::BPI; ++i) {
-        const int k0 = 16 * (kb0 + i);
-        const bool ok = k0 + 4 * kq < K;
-        f32x4 a = *reinterpret_cast<const f32x4*>(ap + (ok ? k0 : 0));
-        if (!ok) a = zero4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[i][e], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = 4 * kq + i;
-        if constexpr (KS == 1) { if (nok) epi(h, m, n, acc[i]); }
-        else P[((ks * NH + h) * 16 + m) * S::NP + n] = acc[i];
-      }
-    } else {
-      const int n = nt * 32 + 2 * r;                      // this lane's two columns (N is even: both or neither)
-      const bool nok = n < N;
-      const float* bp = B + (int64_t)h * bsh + (int64_t)(4 * kq) * ldb + (nok ? n : 0);
-      float2 b[S::BPI][4];
-#pragma unroll
-      for (int i = 0; i < S::BPI; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k0 = 16 * (kb0 + i);
-          const bool ok = k0 + 4 * kq < K;
-          b[i][e] = *reinterpret_cast<const float2*>(bp + (int64_t)((ok ? k0 : 0) + e) * ldb);
-          if (!ok || !nok) b[i][e] = make_float2(0.f, 0.f);
-        }
       f32x4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
-      for (int i = 0; i < S::BPI; ++i) {
-        const int k0 = 16 * (kb0 + i);
-        const bool ok = k0 + 4 * kq < K;
-        f32x4 a = *reinterpret_cast<const f32x4*>(ap + (ok ? k0 : 0));
-        if (!ok) a = zero4;
+      for (int ch = 0; ch < CPI; ++ch) {
+        Frag g;
+        if (ch + 1 < CPI) load(g, itc, ch + 1);
+        else if (rr + 1 < R) load(g, item + CH_WAVES, 0);
+        else next(g);
+        if (active) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[i][e].x, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[i][e].y, acc1, 0, 0, 0);
+          for (int i = 0; i < CB; ++i) {
+            if (ch * CB + i >= BPI) continue;
+            const int k0 = 16 * (ks * BPI + ch * CB + i);
+            const bool ok = k0 + 4 * kq < K;
+            f32x4 a = *reinterpret_cast<const f32x4*>(ap + (ok ? k0 : 0));
+            if (!ok) a = zero4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {       // (the packed weights hold zeros past N and K)
+              if constexpr (KFAST) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], f.v[4 * i + e], acc0, 0, 0, 0);
+              } else {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], f.v[8 * i + 2 * e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], f.v[8 * i + 2 * e + 1], acc1, 0, 0, 0);
+              }
+            }
+          }
         }
+        f = g;
       }
+      if (active) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = 4 * kq + i;
-        if constexpr (KS == 1) {
-          if (nok) { epi(h, m, n, acc0[i]); epi(h, m, n + 1, acc1[i]); }
-        } else {
-          *reinterpret_cast<float2*>(&P[((ks * NH + h) * 16 + m) * S::NP + n]) = make_float2(acc0[i], acc1[i]);
+        for (int i = 0; i < 4; ++i) {
+          const int m = 4 * kq + i;
+          if constexpr (KS == 1) {
+            if (nok) {
+              epi(h, m, n, acc0[i]);
+              if constexpr (!KFAST) epi(h, m, n + 1, acc1[i]);
+            }
+          } else if constexpr (KFAST) {
+            P[((ks * NH + h) * 16 + m) * NP + n] = acc0[i];
+          } else {
+            *reinterpret_cast<float2*>(&P[((ks * NH + h) * 16 + m) * NP + n]) = make_float2(acc0[i], acc1[i]);
+          }
         }
       }
     }
-  }
-  if constexpr (KS > 1) {
+    if constexpr (KS > 1) {
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < NH * 16 * N; idx += CH_T) {
+        const int h = idx / (16 * N), m = (idx % (16 * N)) / N, n = idx % N;
+        float v = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) v += P[((ks * NH + h) * 16 + m) * NP + n];
+        epi(h, m, n, v);
+      }
+    }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < NH * 16 * N; idx += CH_T) {
-      const int h = idx / (16 * N), m = (idx % (16 * N)) / N, n = idx % N;
-      float v = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) v += P[((ks * NH + h) * 16 + m) * S::NP + n];
-      epi(h, m, n, v);
-    }
   }
-  __syncthreads();
+};
+
+// the stages of the three chains and where their packed weights start (in fragments of 256 floats)
+template <int KD> struct ChainW {
+  using A1 = ChainStage<QD, QD, 1, true, 2>;      // qs = xq Wq^T
+  using A2 = ChainStage<KD, D, 2, false, 1>;      // q~_h = qs_h Wk_h
+  using B1 = ChainStage<D, KD, 2, true, 3>;       // ocat_h = xbar_h Wv_h^T
+  using B2 = ChainStage<QD, QD, 1, true, 2>;      // o = ocat Wo^T
+  using B3 = ChainStage<D, 3 * D, 1, true, 2>;    // h1 = x1 W1^T
+  using B4 = ChainStage<D, D, 1, true, 2>;        // y = h1 W2^T
+  using B5 = ChainStage<D, D, 1, false, 4>;       // dz1 = dy W2
+  using B6 = ChainStage<3 * D, D, 1, false, 1>;   // dx1 = dz1 W1
+  using B7 = ChainStage<QD, QD, 1, false, 2>;     // docat = do Wo
+  using B8 = ChainStage<KD, D, 2, false, 1>;      // dxbar_h = docat_h Wv_h
+  using C1 = ChainStage<D, KD, 2, true, 3>;       // dqs_h = dq~_h Wk_h^T
+  using C2 = ChainStage<QD, QD, 1, false, 2>;     // dxq = dq Wq
+  static constexpr int a1 = 0, a2 = a1 + A1::FRAGS, b1 = a2 + A2::FRAGS, b2 = b1 + B1::FRAGS, b3 = b2 + B2::FRAGS,
+                       b4 = b3 + B3::FRAGS, b5 = b4 + B4::FRAGS, b6 = b5 + B5::FRAGS, b7 = b6 + B6::FRAGS,
+                       b8 = b7 + B7::FRAGS, c1 = b8 + B8::FRAGS, c2 = c1 + C1::FRAGS, total = c2 + C2::FRAGS;
+};
+// fragment-order copies of the weights: fragment = [64 lanes][4 floats]; lane (r = lane & 15, kq = lane >> 4).
+// KFAST (tile of 16 columns): fragment (tile, block) element j = B(16 block + 4 kq + j, 16 tile + r);
+// otherwise (tile of 32 columns, two fragments per block): fragment (tile, block, u) element j =
+// B(16 block + 4 kq + 2 u + (j >> 1), 32 tile + 2 r + (j & 1)).  Zeros past N and K.  B_h(k, n) = src[h*sh + k*sbk + n*sbn].
+struct ChainPackJob {
+  const float* src;
+  int sbk, sbn, sh, N, K, NT, KB, kfast, first;
+};
+constexpr int CHAIN_PACK_JOBS = 12;
+struct ChainPack { ChainPackJob j[CHAIN_PACK_JOBS]; int total; };
+__global__ __launch_bounds__(256) void k_chain_pack(ChainPack jobs, float* __restrict__ dst) {
+  const int gid = blockIdx.x * 256 + threadIdx.x, frag = gid >> 6, lane = gid & 63;
+  if (frag >= jobs.total) return;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < CHAIN_PACK_JOBS; ++i) p += frag >= jobs.j[i].first ? 1 : 0;
+  const ChainPackJob& J = jobs.j[p];
+  const int local = frag - J.first, r = lane & 15, kq = lane >> 4;
+  const int fpb = J.kfast ? 1 : 2;
+  const int tile = local / (J.KB * fpb), kb = (local / fpb) % J.KB, u = local % fpb;
+  const int h = tile / J.NT, nt = tile % J.NT;
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = 16 * kb + 4 * kq + (J.kfast ? j : 2 * u + (j >> 1));
+    const int n = J.kfast ? 16 * nt + r : 32 * nt + 2 * r + (j & 1);
+    v[j] = (k < J.K && n < J.N) ? J.src[(int64_t)h * J.sh + (int64_t)k * J.sbk + (int64_t)n * J.sbn] : 0.f;
+  }
+  *reinterpret_cast<f32x4*>(dst + (int64_t)gid * 4) = v;
+}
+template <class S> ChainPackJob chain_pack_job(const float* src, int sbk, int sbn, int sh, int N, int K, bool kfast, int first) {
+  return ChainPackJob{src, sbk, sbn, sh, N, K, S::NT, S::KB, kfast ? 1 : 0, first};
 }
 
 constexpr int CH_S2 = QD + 4, CH_S3 = 3 * D + 8, CH_S1 = D + 8;     // LDS row strides of 200-, 300- and 100-wide rows
@@ -895,27 +1045,34 @@ template <int KD> struct ChainLds {
   static constexpr int SB = 2 * KD + 4;                                // stride of a [2 x kdim] row
   static_assert((SB / 4) % 2 == 1 && (CH_S2 / 4) % 2 == 1 && (CH_S3 / 4) % 2 == 1 && (CH_S1 / 4) % 2 == 1, "bank spread");
   // chain A: xq, qs, P;  chain C: dq~ rows, dq, dxq, P;  chain B: xbar rows (later h1, y, dy, dh1), P, ocat/docat, x1/dx1
-  static constexpr int A_P = ChainShape<QD, QD, 1, true, 2>::PFLOATS;
+  static constexpr int A_P = ChainW<KD>::A1::PFLOATS;
   static constexpr int A_FLOATS = 2 * 16 * CH_S2 + A_P;
-  static constexpr int C_P1 = ChainShape<D, KD, 2, true, 3>::PFLOATS, C_P2 = ChainShape<QD, QD, 1, false, 2>::PFLOATS;
+  static constexpr int C_P1 = ChainW<KD>::C1::PFLOATS, C_P2 = ChainW<KD>::C2::PFLOATS;
   static constexpr int C_P = C_P1 > C_P2 ? C_P1 : C_P2;
   static constexpr int C_FLOATS = 16 * SB + 2 * 16 * CH_S2 + C_P;
-  static constexpr int B_P = C_P1 > 4 * 16 * 128 ? C_P1 : 4 * 16 * 128;
+  static constexpr int B_P = ChainW<KD>::B1::PFLOATS > ChainW<KD>::B5::PFLOATS ? ChainW<KD>::B1::PFLOATS : ChainW<KD>::B5::PFLOATS;
+  static_assert(ChainW<KD>::B2::PFLOATS <= B_P && ChainW<KD>::B3::PFLOATS <= B_P && ChainW<KD>::B7::PFLOATS <= B_P, "partial sums fit");
   static constexpr int B_FLOATS = 16 * SB + B_P + 16 * CH_S2 + 16 * CH_S3;
   static_assert(4 * 16 * CH_S1 <= 16 * SB, "the narrow rows alias the xbar rows");
 };
 
 template <int KD>
-__global__ __launch_bounds__(CH_T) void k_chain_a(orca_tgat_inputs in, int64_t Q, const float* __restrict__ Wq,
-                                                  const float* __restrict__ bq, const float* __restrict__ Wk,
-                                                  float* __restrict__ xq, float* __restrict__ x1, float* __restrict__ qs,
+__global__ __launch_bounds__(CH_T) void k_chain_a(orca_tgat_inputs in, int64_t Q, const float* __restrict__ wp,
+                                                  const float* __restrict__ bq, float* __restrict__ xq, float* __restrict__ x1, float* __restrict__ qs,
                                                   float* __restrict__ qt) {
   extern __shared__ __align__(16) float lds[];
   float* XQ = lds;
   float* QS = XQ + 16 * CH_S2;
   float* P = QS + 16 * CH_S2;
+  __shared__ float sbq[QD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * 16;
+  using W = ChainW<KD>;
+  const typename W::A1 g1{wp + W::a1 * 256};
+  const typename W::A2 g2{wp + W::a2 * 256};
+  Frag f;
+  g1.load(f, wave, 0);
+  if (threadIdx.x < QD) sbq[threadIdx.x] = bq[threadIdx.x];
   {   // wave = row: xq = [src | src_time], x1[:, 200:300] = src   (rows past Q repeat the last one and store nothing)
     const int64_t q = m0 + wave, qc = q < Q ? q : Q - 1;
     const int64_t row = in.src_idx ? (int64_t)in.src_idx[qc] : qc;
@@ -933,18 +1090,18 @@ __global__ __launch_bounds__(CH_T) void k_chain_a(orca_tgat_inputs in, int64_t Q
     }
   }
   __syncthreads();
-  chain_gemm<QD, QD, 1, true, 2>(XQ, CH_S2, 0, Wq, QD, 0, P, [&](int, int m, int n, float v) {
-    v = 0.1f * (v + bq[n]);
+  g1.run(f, XQ, CH_S2, 0, P, [&](int, int m, int n, float v) {
+    v = 0.1f * (v + sbq[n]);
     QS[m * CH_S2 + n] = v;
     if (m0 + m < Q) qs[(m0 + m) * QD + n] = v;
-  });
-  chain_gemm<KD, D, 2, false, 1>(QS, CH_S2, D, Wk, KD, D * KD, P, [&](int h, int m, int n, float v) {
+  }, [&](Frag& g) { g2.load(g, wave, 0); });
+  g2.run(f, QS, CH_S2, D, P, [&](int h, int m, int n, float v) {
     if (m0 + m < Q) qt[(m0 + m) * 2 * KD + h * KD + n] = v;
-  });
+  }, [](Frag&) {});
 }
 
 struct ChainB {
-  const float *v_w, *bv, *o_w, *o_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln_w;     // parameters
+  const float *wp, *bv, *o_b, *fc1_b, *fc2_b, *ln_w;                            // packed weights, biases
   const float *grad_out, *xbar, *invalid, *wsum;                                // inputs
   float *x1, *ocat, *h1, *dy, *gx, *dh1, *dx1, *docat, *dxbar, *scaled, *dsum;  // rows kept for the weight gradients
   int drop;
@@ -958,9 +1115,29 @@ __global__ __launch_bounds__(CH_T) void k_chain_b(ChainB c, int64_t Q) {
   float* OC = P + L::B_P;                  // ocat, later docat
   float* X1 = OC + 16 * CH_S2;             // x1, later dx1
   float *H1 = BIG, *Y = BIG + 16 * CH_S1, *DY = BIG + 2 * 16 * CH_S1, *DH = BIG + 3 * 16 * CH_S1;
-  __shared__ float inval[16], ws[32];
+  __shared__ float inval[16], ws[32], sbv[QD], sbo[QD], sb1[D], sb2[D], sg[D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * 16;
+  using W = ChainW<KD>;
+  const typename W::B1 g1{c.wp + W::b1 * 256};
+  const typename W::B2 g2{c.wp + W::b2 * 256};
+  const typename W::B3 g3{c.wp + W::b3 * 256};
+  const typename W::B4 g4{c.wp + W::b4 * 256};
+  const typename W::B5 g5{c.wp + W::b5 * 256};
+  const typename W::B6 g6{c.wp + W::b6 * 256};
+  const typename W::B7 g7{c.wp + W::b7 * 256};
+  const typename W::B8 g8{c.wp + W::b8 * 256};
+  Frag f;
+  g1.load(f, wave, 0);
+  if (threadIdx.x < QD) {
+    sbv[threadIdx.x] = c.bv[threadIdx.x];
+    sbo[threadIdx.x] = c.o_b[threadIdx.x];
+  } else if (threadIdx.x < QD + D) {
+    const int i = threadIdx.x - QD;
+    sb1[i] = c.fc1_b[i];
+    sb2[i] = c.fc2_b[i];
+    sg[i] = c.ln_w[i];
+  }
   for (int i = threadIdx.x; i < 16 * (2 * KD / 4); i += CH_T) {       // xbar rows, float4 at a time
     const int m = i / (2 * KD / 4), c4 = i % (2 * KD / 4);
     const int64_t q = m0 + m < Q ? m0 + m : Q - 1;
@@ -979,26 +1156,25 @@ __global__ __launch_bounds__(CH_T) void k_chain_b(ChainB c, int64_t Q) {
   }
   __syncthreads();
   // ocat_h = xbar_h Wv_h^T + bv_h (dropout: times the sum of the head's kept weights)
-  chain_gemm<D, KD, 2, true, 3>(BIG, L::SB, KD, c.v_w, KD, D * KD, P, [&](int h, int m, int n, float v) {
-    v += ws[2 * m + h] * c.bv[h * D + n];
+  g1.run(f, BIG, L::SB, KD, P, [&](int h, int m, int n, float v) {
+    v += ws[2 * m + h] * sbv[h * D + n];
     OC[m * CH_S2 + h * D + n] = v;
     if (m0 + m < Q) c.ocat[(m0 + m) * QD + h * D + n] = v;
-  });
+  }, [&](Frag& g) { g2.load(g, wave, 0); });
   // o = ocat Wo^T + bo, zero for a query without neighbours                          (temporal_attention.py:52)
-  chain_gemm<QD, QD, 1, true, 2>(OC, CH_S2, 0, c.o_w, QD, 0, P, [&](int, int m, int n, float v) {
-    v = inval[m] != 0.f ? 0.f : v + c.o_b[n];
+  g2.run(f, OC, CH_S2, 0, P, [&](int, int m, int n, float v) {
+    v = inval[m] != 0.f ? 0.f : v + sbo[n];
     X1[m * CH_S3 + n] = v;
     if (m0 + m < Q) c.x1[(m0 + m) * 3 * D + n] = v;
-  });
+  }, [&](Frag& g) { g3.load(g, wave, 0); });
   // h1 = relu(x1 W1^T + b1), y = h1 W2^T + b2                                         (utils/util.py:22-24)
-  chain_gemm<D, 3 * D, 1, true, 2>(X1, CH_S3, 0, c.fc1_w, 3 * D, 0, P, [&](int, int m, int n, float v) {
-    v = fmaxf(v + c.fc1_b[n], 0.f);
+  g3.run(f, X1, CH_S3, 0, P, [&](int, int m, int n, float v) {
+    v = fmaxf(v + sb1[n], 0.f);
     H1[m * CH_S1 + n] = v;
     if (m0 + m < Q) c.h1[(m0 + m) * D + n] = v;
-  });
-  chain_gemm<D, D, 1, true, 2>(H1, CH_S1, 0, c.fc2_w, D, 0, P, [&](int, int m, int n, float v) {
-    Y[m * CH_S1 + n] = v + c.fc2_b[n];
-  });
+  }, [&](Frag& g) { g4.load(g, wave, 0); });
+  g4.run(f, H1, CH_S1, 0, P, [&](int, int m, int n, float v) { Y[m * CH_S1 + n] = v + sb2[n]; },
+         [&](Frag& g) { g5.load(g, wave, 0); });
   {   // LayerNorm backward, wave = row (k_bwd_ln)
     const int m = wave, c1 = lane + 64;
     const int64_t q = m0 + m < Q ? m0 + m : Q - 1;
@@ -1009,7 +1185,7 @@ __global__ __launch_bounds__(CH_T) void k_chain_b(ChainB c, int64_t Q) {
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     const float xa = da * rstd, xb = db * rstd;
     const float ga = c.grad_out[q * D + lane], gb = c1 < D ? c.grad_out[q * D + c1] : 0.f;
-    const float ha = ga * c.ln_w[lane], hb = c1 < D ? gb * c.ln_w[c1] : 0.f;
+    const float ha = ga * sg[lane], hb = c1 < D ? gb * sg[c1] : 0.f;
     const float s1 = wave_sum(ha + hb) * (1.0f / D);
     const float s2 = wave_sum(ha * xa + hb * xb) * (1.0f / D);
     const float va = (ha - s1 - xa * s2) * rstd, vb = (hb - s1 - xb * s2) * rstd;
@@ -1026,42 +1202,42 @@ __global__ __launch_bounds__(CH_T) void k_chain_b(ChainB c, int64_t Q) {
   }
   __syncthreads();
   // fc2: dz1 = (dy W2) where h1 > 0;  fc1: dx1 = dz1 W1, its first 200 columns zero where the output was zeroed
-  chain_gemm<D, D, 1, false, 4>(DY, CH_S1, 0, c.fc2_w, D, 0, P, [&](int, int m, int n, float v) {
+  g5.run(f, DY, CH_S1, 0, P, [&](int, int m, int n, float v) {
     if (!(H1[m * CH_S1 + n] > 0.f)) v = 0.f;
     DH[m * CH_S1 + n] = v;
     if (m0 + m < Q) c.dh1[(m0 + m) * D + n] = v;
-  });
-  chain_gemm<3 * D, D, 1, false, 1>(DH, CH_S1, 0, c.fc1_w, 3 * D, 0, P, [&](int, int m, int n, float v) {
+  }, [&](Frag& g) { g6.load(g, wave, 0); });
+  g6.run(f, DH, CH_S1, 0, P, [&](int, int m, int n, float v) {
     if (n < QD && inval[m] != 0.f) v = 0.f;
     X1[m * CH_S3 + n] = v;
     if (m0 + m < Q) c.dx1[(m0 + m) * 3 * D + n] = v;
-  });
+  }, [&](Frag& g) { g7.load(g, wave, 0); });
   // out-proj: docat = do Wo
-  chain_gemm<QD, QD, 1, false, 2>(X1, CH_S3, 0, c.o_w, QD, 0, P, [&](int, int m, int n, float v) {
+  g7.run(f, X1, CH_S3, 0, P, [&](int, int m, int n, float v) {
     OC[m * CH_S2 + n] = v;
     if (m0 + m < Q) {
       c.docat[(m0 + m) * QD + n] = v;
       if (c.drop) c.scaled[(m0 + m) * QD + n] = v * ws[2 * m + n / D];      // the bv gradient's summand
     }
-  });
+  }, [&](Frag& g) { g8.load(g, wave, 0); });
   if (c.drop) {   // dsum_h = docat_h . bv_h, wave = row (k_bias_scale_bwd)
     const int m = wave;
     for (int h = 0; h < 2; ++h) {
       float acc = 0.f;
-      for (int n = lane; n < D; n += 64) acc += OC[m * CH_S2 + h * D + n] * c.bv[h * D + n];
+      for (int n = lane; n < D; n += 64) acc += OC[m * CH_S2 + h * D + n] * sbv[h * D + n];
       acc = wave_sum(acc);
       if (lane == 0 && m0 + m < Q) c.dsum[(m0 + m) * 2 + h] = acc;
     }
   }
   // value map: dxbar_h = docat_h Wv_h
-  chain_gemm<KD, D, 2, false, 1>(OC, CH_S2, D, c.v_w, KD, D * KD, P, [&](int h, int m, int n, float v) {
+  g8.run(f, OC, CH_S2, D, P, [&](int h, int m, int n, float v) {
     if (m0 + m < Q) c.dxbar[(m0 + m) * 2 * KD + h * KD + n] = v;
-  });
+  }, [](Frag&) {});
 }
 
 template <int KD>
-__global__ __launch_bounds__(CH_T) void k_chain_c(orca_tgat_inputs in, int64_t Q, const float* __restrict__ Wk,
-                                                  const float* __restrict__ Wq, const float* __restrict__ dqt,
+__global__ __launch_bounds__(CH_T) void k_chain_c(orca_tgat_inputs in, int64_t Q, const float* __restrict__ wp,
+                                                  const float* __restrict__ dqt,
                                                   const float* __restrict__ dx1, float* __restrict__ dq,
                                                   float* __restrict__ d_src, float* __restrict__ d_src_time,
                                                   float* __restrict__ tgrad) {
@@ -1072,6 +1248,12 @@ __global__ __launch_bounds__(CH_T) void k_chain_c(orca_tgat_inputs in, int64_t Q
   float* DXQ = DQ + 16 * CH_S2;
   float* P = DXQ + 16 * CH_S2;
   const int64_t m0 = (int64_t)blockIdx.x * 16;
+  const int wave = threadIdx.x >> 6;
+  using W = ChainW<KD>;
+  const typename W::C1 g1{wp + W::c1 * 256};
+  const typename W::C2 g2{wp + W::c2 * 256};
+  Frag f;
+  g1.load(f, wave, 0);
   for (int i = threadIdx.x; i < 16 * (2 * KD / 4); i += CH_T) {
     const int m = i / (2 * KD / 4), c4 = i % (2 * KD / 4);
     const int64_t q = m0 + m < Q ? m0 + m : Q - 1;
@@ -1079,12 +1261,12 @@ __global__ __launch_bounds__(CH_T) void k_chain_c(orca_tgat_inputs in, int64_t Q
   }
   __syncthreads();
   // key fold: dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs;  q projection: dxq = dq Wq
-  chain_gemm<D, KD, 2, true, 3>(BIG, L::SB, KD, Wk, KD, D * KD, P, [&](int h, int m, int n, float v) {
+  g1.run(f, BIG, L::SB, KD, P, [&](int h, int m, int n, float v) {
     v *= 0.1f;
     DQ[m * CH_S2 + h * D + n] = v;
     if (m0 + m < Q) dq[(m0 + m) * QD + h * D + n] = v;
-  });
-  chain_gemm<QD, QD, 1, false, 2>(DQ, CH_S2, 0, Wq, QD, 0, P, [&](int, int m, int n, float v) { DXQ[m * CH_S2 + n] = v; });
+  }, [&](Frag& g) { g2.load(g, wave, 0); });
+  g2.run(f, DQ, CH_S2, 0, P, [&](int, int m, int n, float v) { DXQ[m * CH_S2 + n] = v; }, [](Frag&) {});
   for (int i = threadIdx.x; i < 16 * D; i += CH_T) {     // k_bwd_finish
     const int m = i / D, n = i % D;
     const int64_t q = m0 + m;
@@ -1101,7 +1283,7 @@ __global__ __launch_bounds__(CH_T) void k_chain_c(orca_tgat_inputs in, int64_t Q
 
 struct Ws {   // float offsets of the per-query rows inside the workspace
   int64_t xq, qs, qt, a, xbar, ocat, x1, h1, y, dy, gx, dh1, dx1, docat, dxbar, dqt, dq, dxq, tgrad, invalid, wsum, dsum, scaled,
-      part, total;
+      wpack, part, total;
 };
 constexpr int SPLITS = 16;      // split-K pieces of the weight-gradient GEMMs (all of a layer's in one launch)
 Ws ws_layout(int d_e, int64_t Q, int K) {
@@ -1114,6 +1296,8 @@ Ws ws_layout(int d_e, int64_t Q, int K) {
   w.dh1 = take(D); w.dx1 = take(3 * D); w.docat = take(QD); w.dxbar = take(2 * kdim); w.dqt = take(2 * kdim);
   w.dq = take(QD); w.dxq = take(QD); w.tgrad = take(QD); w.invalid = take(1); w.wsum = take(2); w.dsum = take(2);
   w.scaled = take(QD);
+  w.wpack = o;      // fragment-order copies of the weights for the fused chains
+  if (d_e == 172) o += (int64_t)ChainW<QD + 172>::total * 256;
   w.part = o;
   // the eight weight-gradient problems with their bias columns (each rounded up to 64 floats), or a column sum's slices
   o += (int64_t)SPLITS * ((int64_t)D * (D + 1) + (int64_t)D * (3 * D + 1) + 2 * (int64_t)QD * (QD + 1) + 4 * (int64_t)D * (kdim + 1) + 2 * D)
@@ -1122,12 +1306,10 @@ Ws ws_layout(int d_e, int64_t Q, int K) {
   return w;
 }
 
-// the fused chains are built for d_e = 172 and take float4 rows: 16-byte aligned weights and workspace
-bool chain_usable(const orca_tgat_params* P, int d_e, const float* workspace) {
+// the fused chains are built for d_e = 172 and read float4 rows of the workspace
+bool chain_usable(int d_e, const float* workspace) {
   static const bool off = getenv("ORCA_BWD_CHAIN") && atoi(getenv("ORCA_BWD_CHAIN")) == 0;
-  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  return !off && d_e == 172 && al16(P->q_w) && al16(P->k_w) && al16(P->v_w) && al16(P->o_w) && al16(P->fc1_w) &&
-         al16(P->fc2_w) && al16(workspace);
+  return !off && d_e == 172 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
 }
 
 }  // namespace
@@ -1167,7 +1349,7 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
   float *xq = W + w.xq, *qs = W + w.qs, *qt = W + w.qt, *a = W + w.a, *xbar = W + w.xbar, *ocat = W + w.ocat,
         *x1 = W + w.x1, *h1 = W + w.h1, *y = W + w.y, *dy = W + w.dy, *gx = W + w.gx, *dh1 = W + w.dh1,
         *dx1 = W + w.dx1, *docat = W + w.docat, *dxbar = W + w.dxbar, *dqt = W + w.dqt, *dq = W + w.dq,
-        *dxq = W + w.dxq, *tgrad = W + w.tgrad, *invalid = W + w.invalid, *wsum = W + w.wsum, *dsum = W + w.dsum, *part = W + w.part;
+        *dxq = W + w.dxq, *tgrad = W + w.tgrad, *invalid = W + w.invalid, *wsum = W + w.wsum, *dsum = W + w.dsum, *part = W + w.part, *wpack = W + w.wpack;
   const bool drop = in->dropout_p > 0.f;
   ORCA_REQUIRE(in->dropout_p >= 0.f && in->dropout_p < 1.f, "orca_tgat_backward: dropout_p=%g outside [0,1)", (double)in->dropout_p);
   const unsigned qb = (unsigned)ceil_div64(Q, 4);
@@ -1180,17 +1362,39 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
     return OrcaGemm{M_, N_, K_, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, alpha, 0, 0, nullptr, nullptr, 0, nullptr, 1};
   };
   // ---- forward recompute, then the data gradients: a chain (fused per 16-row tile when the shapes are the built ones) --
-  const bool chain = chain_usable(P, d_e, workspace);
+  const bool chain = chain_usable(d_e, workspace);
   const unsigned tiles = (unsigned)ceil_div64(Q, 16);
   using CL = ChainLds<QD + 172>;
   if (chain) {
     static bool attr_set[64] = {};
     if (orca_first_use_on_device(attr_set)) {
-      const int lim = 160 * 1024 - 256;
-      const void* fns[] = {(const void*)k_chain_a<QD + 172>, (const void*)k_chain_b<QD + 172>, (const void*)k_chain_c<QD + 172>};
-      for (const void* f : fns) ORCA_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      // (the kernels also hold a few hundred static floats: ask for what each launch uses, not for the whole LDS)
+      ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_chain_a<QD + 172>, hipFuncAttributeMaxDynamicSharedMemorySize, CL::A_FLOATS * (int)sizeof(float)));
+      ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_chain_b<QD + 172>, hipFuncAttributeMaxDynamicSharedMemorySize, CL::B_FLOATS * (int)sizeof(float)));
+      ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_chain_c<QD + 172>, hipFuncAttributeMaxDynamicSharedMemorySize, CL::C_FLOATS * (int)sizeof(float)));
     }
-    k_chain_a<QD + 172><<<tiles, CH_T, CL::A_FLOATS * sizeof(float), s>>>(*in, Q, P->q_w, P->in_b, P->k_w, xq, x1, qs, qt);
+    {
+      using CW = ChainW<QD + 172>;
+      const int KDc = QD + 172;
+      ChainPack pk{};
+      int i = 0;
+      pk.j[i++] = chain_pack_job<CW::A1>(P->q_w, 1, QD, 0, QD, QD, true, CW::a1);
+      pk.j[i++] = chain_pack_job<CW::A2>(P->k_w, KDc, 1, D * KDc, KDc, D, false, CW::a2);
+      pk.j[i++] = chain_pack_job<CW::B1>(P->v_w, 1, KDc, D * KDc, D, KDc, true, CW::b1);
+      pk.j[i++] = chain_pack_job<CW::B2>(P->o_w, 1, QD, 0, QD, QD, true, CW::b2);
+      pk.j[i++] = chain_pack_job<CW::B3>(P->fc1_w, 1, 3 * D, 0, D, 3 * D, true, CW::b3);
+      pk.j[i++] = chain_pack_job<CW::B4>(P->fc2_w, 1, D, 0, D, D, true, CW::b4);
+      pk.j[i++] = chain_pack_job<CW::B5>(P->fc2_w, D, 1, 0, D, D, false, CW::b5);
+      pk.j[i++] = chain_pack_job<CW::B6>(P->fc1_w, 3 * D, 1, 0, 3 * D, D, false, CW::b6);
+      pk.j[i++] = chain_pack_job<CW::B7>(P->o_w, QD, 1, 0, QD, QD, false, CW::b7);
+      pk.j[i++] = chain_pack_job<CW::B8>(P->v_w, KDc, 1, D * KDc, KDc, D, false, CW::b8);
+      pk.j[i++] = chain_pack_job<CW::C1>(P->k_w, 1, KDc, D * KDc, D, KDc, true, CW::c1);
+      pk.j[i++] = chain_pack_job<CW::C2>(P->q_w, QD, 1, 0, QD, QD, false, CW::c2);
+      static_assert(CHAIN_PACK_JOBS == 12, "one job per stage");
+      pk.total = CW::total;
+      k_chain_pack<<<(unsigned)ceil_div64((int64_t)CW::total * 64, 256), 256, 0, s>>>(pk, wpack);
+    }
+    k_chain_a<QD + 172><<<tiles, CH_T, CL::A_FLOATS * sizeof(float), s>>>(*in, Q, wpack, P->in_b, xq, x1, qs, qt);
   } else {
     k_bwd_prep<<<qb, 256, 0, s>>>(*in, Q, xq, x1);
     // qs = 0.1 (xq Wq^T + bq)                                                    (scaling: head_dim^-0.5)
@@ -1201,9 +1405,10 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
       g[h] = G1(M, kdim, D, qs + h * D, QD, 1, P->k_w + (int64_t)h * D * kdim, kdim, 1, qt + h * kdim, 2 * kdim, 1, nullptr, 1.f);
     rc |= orca_sgemm_group(s, g, 2, nullptr);
   }
-  k_bwd_attn_fwd<<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
+  if (K <= 10) k_bwd_attn_fwd<10><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
+  else k_bwd_attn_fwd<ORCA_MAX_K><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
   if (chain) {
-    const ChainB c{P->v_w, P->in_b + 2 * QD, P->o_w, P->o_b, P->fc1_w, P->fc1_b, P->fc2_w, P->fc2_b, P->ln_w,
+    const ChainB c{wpack, P->in_b + 2 * QD, P->o_b, P->fc1_b, P->fc2_b, P->ln_w,
                    grad_out, xbar, invalid, wsum,
                    x1, ocat, h1, dy, gx, dh1, dx1, docat, dxbar, scaled, dsum, drop ? 1 : 0};
     k_chain_b<QD + 172><<<tiles, CH_T, CL::B_FLOATS * sizeof(float), s>>>(c, Q);
@@ -1254,7 +1459,7 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
   else
     k_bwd_attn_bwd<ORCA_MAX_K><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
   if (chain) {
-    k_chain_c<QD + 172><<<tiles, CH_T, CL::C_FLOATS * sizeof(float), s>>>(*in, Q, P->k_w, P->q_w, dqt, dx1, dq, d_src, d_src_time,
+    k_chain_c<QD + 172><<<tiles, CH_T, CL::C_FLOATS * sizeof(float), s>>>(*in, Q, wpack, dqt, dx1, dq, d_src, d_src_time,
                                                                        want_t ? tgrad : nullptr);
   } else {
     {   // key fold: dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs
