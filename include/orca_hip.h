@@ -198,6 +198,14 @@ int orca_tgat_backward(const orca_tgat_params* params, int d_e, const orca_tgat_
                        float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b, float* workspace,
                        void* stream);
 
+/* orca_tgat_pack (+ orca_tgat_pack_gather when time_b != NULL) for n_layers layers at once: params[l] are layer l's raw
+ * tensors, blobs[l] its blob.  The folds of all layers share launches (3 per two layers instead of 8 per layer): the
+ * re-pack after every optimizer step (train.py:238) is otherwise two dozen latency-bound launches.
+ * blobs_packed_before != 0: every blobs[l] already holds a packed layer of the same d_e (only the values change). */
+int orca_tgat_pack_layers(int n_layers, int d_e, const orca_tgat_params* params, const float* time_b,
+                          float* const* blobs, int blobs_packed_before, void* stream);
+
+
 /* Profiling aid (no counterpart in the reference): when buf != NULL (device int64 [ceil(Q/16) * 16]) later
  * orca_tgat_forward launches write the 100 MHz real-time counter at each internal phase boundary. */
 int orca_debug_tgat_phase_clock(void* buf);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "orca_tgat_blob_floats": (i64, [i32]),
     "orca_tgat_pack": (i32, [i32] + [vp] * 14),
     "orca_tgat_pack_gather": (i32, [i32] + [vp] * 6),
+    "orca_tgat_pack_layers": (i32, [i32, i32, vp, vp, vp, i32, vp]),
     "orca_index_positions": (i32, [vp, i64, vp, vp, i64, vp]),
     "orca_scatter_add_flagged": (i32, [vp, vp, vp, i64, vp, vp, i64, vp, vp]),
     "orca_gru_backward_workspace_floats": (i64, [i32, i64]),

@@ -279,7 +279,7 @@ struct OrcaPackJob {
   int64_t sn, sk;                   // kind 0
   int n, n_pad;                     // kind 1
 };
-constexpr int ORCA_PACK_GROUP_MAX = 16;
+constexpr int ORCA_PACK_GROUP_MAX = 32;
 inline OrcaPackJob orca_pack_job(float* dst, int KB, int n0, int n_cnt, int Kd, const float* src, int64_t sn, int64_t sk,
                                  bool tail1 = false) {
   return OrcaPackJob{0, dst, src, KB, n0, n_cnt, Kd, tail1 ? 1 : 0, sn, sk, 0, 0};

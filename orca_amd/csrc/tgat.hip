@@ -78,9 +78,9 @@ __host__ __device__ constexpr Blob blob_layout(int d_e) {
 // U[2*D*D + h*QD + j] = sum_{k in head h} Wo[j][k] bv[k]  (the out-projection of head h's value bias: it reaches the
 //                        output scaled by the sum of that head's attention weights -- 1 unless dropout is on)
 // U[2*D*D + 2*QD + j] = bo[j]
-__global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restrict__ o_w, const float* __restrict__ o_b,
-                         const float* __restrict__ bv, double* __restrict__ U) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void fold_u(int i, const float* __restrict__ fc1_w, const float* __restrict__ o_w,
+                                       const float* __restrict__ o_b, const float* __restrict__ bv, double* __restrict__ U) {
+  if (i >= 2 * D * D + 3 * QD) return;
   if (i >= 2 * D * D) {
     const int r = i - 2 * D * D, part = r / QD, j = r % QD;
     if (part < 2) {
@@ -99,13 +99,15 @@ __global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restric
   for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * (double)o_w[j * QD + h * D + d];
   U[i] = acc;
 }
+__global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restrict__ o_w, const float* __restrict__ o_b,
+                         const float* __restrict__ bv, double* __restrict__ U) {
+  fold_u(blockIdx.x * blockDim.x + threadIdx.x, fc1_w, o_w, o_b, bv, U);
+}
 // F [100, KBT*16]: columns h*KP + c (c < kdim) = sum_d U[h][n][d] Wv[h*100 + d][c];  column h*KP + kdim = the
 // constant W1a Wo_h bv_h of head h (multiplied by that head's weight sum);  columns 2*KP + k (k < 100) =
 // W1[n][200 + k];  column 2*KP + 100 = W1a bo (multiplied by 1 for a valid query);  zero elsewhere.
-__global__ void k_fold_f(const double* __restrict__ U, const float* __restrict__ v_w, const float* __restrict__ in_b,
-                         const float* __restrict__ o_w, const float* __restrict__ o_b, const float* __restrict__ fc1_w,
-                         int kdim, int KP, int width, float* __restrict__ F) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void fold_f(int i, const double* __restrict__ U, const float* __restrict__ v_w,
+                                       const float* __restrict__ fc1_w, int kdim, int KP, int width, float* __restrict__ F) {
   if (i >= D * width) return;
   const int n = i / width, col = i % width;
   double acc = 0.0;
@@ -124,13 +126,17 @@ __global__ void k_fold_f(const double* __restrict__ U, const float* __restrict__
   }
   F[i] = (float)acc;
 }
+__global__ void k_fold_f(const double* __restrict__ U, const float* __restrict__ v_w, const float* __restrict__ in_b,
+                         const float* __restrict__ o_w, const float* __restrict__ o_b, const float* __restrict__ fc1_w,
+                         int kdim, int KP, int width, float* __restrict__ F) {
+  fold_f(blockIdx.x * blockDim.x + threadIdx.x, U, v_w, fc1_w, kdim, KP, width, F);
+}
 
 // ---- folding the q projection into the key map (gather mode: the source's time encoding is the constant
 // cos(time_b), embedding_module.py:126) ---------------------------------------------------------------------
 // t[j] = bq[j] + sum_i Wq[j][100 + i] cos(time_b[i])          (q_w [200, 200] row-major, j < 200)
-__global__ void k_fold_qt(const float* __restrict__ q_w, const float* __restrict__ in_b,
-                          const float* __restrict__ time_b, double* __restrict__ t) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void fold_qt(int j, const float* __restrict__ q_w, const float* __restrict__ in_b,
+                                        const float* __restrict__ time_b, double* __restrict__ t) {
   if (j >= QD) return;
   double acc = (double)in_b[j];
 #pragma unroll 4
@@ -138,12 +144,15 @@ __global__ void k_fold_qt(const float* __restrict__ q_w, const float* __restrict
     acc += (double)q_w[j * QD + D + i] * (double)orca_cosf(orca_time_arg(0.0f, 0.0f, time_b[i]));
   t[j] = acc;
 }
+__global__ void k_fold_qt(const float* __restrict__ q_w, const float* __restrict__ in_b,
+                          const float* __restrict__ time_b, double* __restrict__ t) {
+  fold_qt(blockIdx.x * blockDim.x + threadIdx.x, q_w, in_b, time_b, t);
+}
 // A [2][kdim+1][100]: A[h][c][s] = 0.1 sum_d Wk'[h][d][c] Wq[h*100 + d][s], with Wk'[h][d][kdim] = bk[h*100 + d];
 // a [2][KP]: a[h][c] = 0.1 sum_d Wk'[h][d][c] t[h*100 + d]    (zero beyond kdim)
-__global__ void k_fold_qk(const float* __restrict__ q_w, const float* __restrict__ k_w, const float* __restrict__ in_b,
-                          const double* __restrict__ t, int kdim, int KP, float* __restrict__ A,
-                          float* __restrict__ a) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void fold_qk(int i, const float* __restrict__ q_w, const float* __restrict__ k_w,
+                                        const float* __restrict__ in_b, const double* __restrict__ t, int kdim, int KP,
+                                        float* __restrict__ A, float* __restrict__ a) {
   const int per = (kdim + 1) * (D + 1);
   if (i >= 2 * per) return;
   const int h = i / per, c = (i % per) / (D + 1), s = i % (D + 1);
@@ -163,6 +172,36 @@ __global__ void k_fold_qk(const float* __restrict__ q_w, const float* __restrict
   }
   if (s < D) A[((int64_t)h * (kdim + 1) + c) * D + s] = (float)(scale * acc);
   else a[h * KP + c] = (float)(scale * acc);
+}
+__global__ void k_fold_qk(const float* __restrict__ q_w, const float* __restrict__ k_w, const float* __restrict__ in_b,
+                          const double* __restrict__ t, int kdim, int KP, float* __restrict__ A,
+                          float* __restrict__ a) {
+  fold_qk(blockIdx.x * blockDim.x + threadIdx.x, q_w, k_w, in_b, t, kdim, KP, A, a);
+}
+// The folds of SEVERAL layers, both kinds at once: a re-pack after every optimizer step was eight fold launches of
+// 8-23 us (each a few hundred blocks, latency-bound) -- here stage 1 is fold_u and fold_qt of every layer in one
+// launch, stage 2 fold_f and fold_qk.
+constexpr int FOLD_LAYERS = 4;
+struct FoldLayers {
+  int n, kdim, KP, width, gather;
+  const float *q_w[FOLD_LAYERS], *k_w[FOLD_LAYERS], *v_w[FOLD_LAYERS], *in_b[FOLD_LAYERS], *o_w[FOLD_LAYERS],
+      *o_b[FOLD_LAYERS], *fc1_w[FOLD_LAYERS];
+  const float* time_b;
+  double* U[FOLD_LAYERS];
+  float* F[FOLD_LAYERS];
+  double* t[FOLD_LAYERS];
+  float* A[FOLD_LAYERS];
+  float* a[FOLD_LAYERS];
+};
+__global__ __launch_bounds__(256) void k_fold_stage1(FoldLayers L, int bu) {
+  const int per = bu + 1, l = blockIdx.x / per, local = blockIdx.x % per;
+  if (local < bu) fold_u(local * 256 + threadIdx.x, L.fc1_w[l], L.o_w[l], L.o_b[l], L.in_b[l] + 2 * QD, L.U[l]);
+  else if (L.gather) fold_qt(threadIdx.x, L.q_w[l], L.in_b[l], L.time_b, L.t[l]);
+}
+__global__ __launch_bounds__(256) void k_fold_stage2(FoldLayers L, int bf, int bk) {
+  const int per = bf + bk, l = blockIdx.x / per, local = blockIdx.x % per;
+  if (local < bf) fold_f(local * 256 + threadIdx.x, L.U[l], L.v_w[l], L.fc1_w[l], L.kdim, L.KP, L.width, L.F[l]);
+  else if (L.gather) fold_qk((local - bf) * 256 + threadIdx.x, L.q_w[l], L.k_w[l], L.in_b[l], L.t[l], L.kdim, L.KP, L.A[l], L.a[l]);
 }
 __global__ void k_pack(float* __restrict__ dst, int KB, int n0, int n_cnt, int Kd, const float* __restrict__ src,
                        int64_t sn, int64_t sk, int tail1) {
@@ -254,6 +293,42 @@ int orca_pack_matrix(float* dst, int NT_total, int KB, int n0, int n_cnt, int Kd
   return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
 }
 
+namespace {
+// the pack jobs of one layer's blob (after its folds): 11 for the dense boundary, 3 more for gather mode
+int tgat_pack_jobs(OrcaPackJob* jobs, const Blob& L, const float* q_w, const float* k_w, const float* in_b,
+                   const float* fc1_b, const float* fc2_w, const float* fc2_b, const float* ln_w, const float* ln_b,
+                   float* blob) {
+  const int kdim = L.kdim, width = L.KBT * 16, KB100 = pw_tiles(D);
+  const float* F = blob + L.scr_f;
+  int nj = 0;
+  // q projection: out n = row of q_proj_weight [200,200]
+  jobs[nj++] = orca_pack_job(blob + L.pw_q, pw_tiles(QD), 0, QD, QD, q_w, QD, 1);
+  jobs[nj++] = orca_copy_pad_job(blob + L.b_q, in_b, QD, 208);
+  for (int h = 0; h < 2; ++h) {
+    // folded key map of head h: out n = key column c (< kdim), reduction k = d (< 100):  Wk[h*100+d][c]
+    float* kt = blob + L.pw_kt + (int64_t)h * pw_floats(kdim + 1, D);
+    jobs[nj++] = orca_pack_job(kt, KB100, 0, kdim, D, k_w + (int64_t)h * D * kdim, 1, kdim, true);
+    // extra output column n = kdim: bk[h*100+d]  (gives the (0.1 q_h).bk_h score offset)
+    jobs[nj++] = orca_pack_job(kt, KB100, kdim, 1, D, in_b + QD + h * D, 0, 1, true);
+  }
+  jobs[nj++] = orca_pack_job(blob + L.pw_t, L.KBT, 0, D, width, F, width, 1);
+  jobs[nj++] = orca_copy_pad_job(blob + L.b_1, fc1_b, D, 112);
+  jobs[nj++] = orca_pack_job(blob + L.pw_2, pw_tiles(D), 0, D, D, fc2_w, D, 1);
+  jobs[nj++] = orca_copy_pad_job(blob + L.b_2, fc2_b, D, 112);
+  jobs[nj++] = orca_copy_pad_job(blob + L.ln_w, ln_w, D, 112);
+  jobs[nj++] = orca_copy_pad_job(blob + L.ln_b, ln_b, D, 112);
+  return nj;
+}
+int tgat_pack_gather_jobs(OrcaPackJob* jobs, const Blob& L, float* blob) {
+  const float* A = blob + L.scr_a;
+  for (int h = 0; h < 2; ++h)
+    jobs[h] = orca_pack_job(blob + L.pw_qk + (int64_t)h * pw_floats(L.kdim + 1, D), pw_tiles(D), 0, L.kdim + 1, D,
+                            A + (int64_t)h * (L.kdim + 1) * D, D, 1, true);
+  jobs[2] = orca_flag_job(blob + L.qk_flag);
+  return 3;
+}
+}  // namespace
+
 ORCA_API int64_t orca_tgat_blob_floats(int d_e) {
   if (d_e < 1 || d_e > ORCA_MAX_DE) return -1;
   return blob_layout(d_e).total;
@@ -278,25 +353,8 @@ ORCA_API int orca_tgat_pack(int d_e, const float* q_w, const float* k_w, const f
   k_fold_u<<<(2 * D * D + 3 * QD + 255) / 256, 256, 0, s>>>(fc1_w, o_w, o_b, in_b + 2 * QD, U);
   k_fold_f<<<(D * width + 255) / 256, 256, 0, s>>>(U, v_w, in_b, o_w, o_b, fc1_w, kdim, L.KP, width, F);
   if (hipGetLastError() != hipSuccess) rc = ORCA_EHIP;
-  const int KB100 = pw_tiles(D);
   OrcaPackJob jobs[ORCA_PACK_GROUP_MAX];
-  int nj = 0;
-  // q projection: out n = row of q_proj_weight [200,200]
-  jobs[nj++] = orca_pack_job(blob + L.pw_q, pw_tiles(QD), 0, QD, QD, q_w, QD, 1);
-  jobs[nj++] = orca_copy_pad_job(blob + L.b_q, in_b, QD, 208);
-  for (int h = 0; h < 2; ++h) {
-    // folded key map of head h: out n = key column c (< kdim), reduction k = d (< 100):  Wk[h*100+d][c]
-    float* kt = blob + L.pw_kt + (int64_t)h * pw_floats(kdim + 1, D);
-    jobs[nj++] = orca_pack_job(kt, KB100, 0, kdim, D, k_w + (int64_t)h * D * kdim, 1, kdim, true);
-    // extra output column n = kdim: bk[h*100+d]  (gives the (0.1 q_h).bk_h score offset)
-    jobs[nj++] = orca_pack_job(kt, KB100, kdim, 1, D, in_b + QD + h * D, 0, 1, true);
-  }
-  jobs[nj++] = orca_pack_job(blob + L.pw_t, L.KBT, 0, D, width, F, width, 1);
-  jobs[nj++] = orca_copy_pad_job(blob + L.b_1, fc1_b, D, 112);
-  jobs[nj++] = orca_pack_job(blob + L.pw_2, pw_tiles(D), 0, D, D, fc2_w, D, 1);
-  jobs[nj++] = orca_copy_pad_job(blob + L.b_2, fc2_b, D, 112);
-  jobs[nj++] = orca_copy_pad_job(blob + L.ln_w, ln_w, D, 112);
-  jobs[nj++] = orca_copy_pad_job(blob + L.ln_b, ln_b, D, 112);
+  int nj = tgat_pack_jobs(jobs, L, q_w, k_w, in_b, fc1_b, fc2_w, fc2_b, ln_w, ln_b, blob);
   rc |= orca_pack_group(jobs, nj, s);
   if (rc != ORCA_OK) {
     orca_set_error("orca_tgat_pack: kernel launch failed");
@@ -320,15 +378,56 @@ ORCA_API int orca_tgat_pack_gather(int d_e, const float* q_w, const float* k_w, 
   k_fold_qk<<<(2 * (kdim + 1) * (D + 1) + 255) / 256, 256, 0, s>>>(q_w, k_w, in_b, t, kdim, L.KP, A, blob + L.b_qk);
   if (hipGetLastError() != hipSuccess) rc = ORCA_EHIP;
   OrcaPackJob jobs[3];
-  for (int h = 0; h < 2; ++h)
-    jobs[h] = orca_pack_job(blob + L.pw_qk + (int64_t)h * pw_floats(kdim + 1, D), pw_tiles(D), 0, kdim + 1, D,
-                            A + (int64_t)h * (kdim + 1) * D, D, 1, true);
-  jobs[2] = orca_flag_job(blob + L.qk_flag);
+  tgat_pack_gather_jobs(jobs, L, blob);
   rc |= orca_pack_group(jobs, 3, s);
   ORCA_HIP_TRY(e0);
   if (rc != ORCA_OK) {
     orca_set_error("orca_tgat_pack_gather: kernel launch failed");
     return ORCA_EHIP;
+  }
+  return ORCA_OK;
+}
+
+ORCA_API int orca_tgat_pack_layers(int n_layers, int d_e, const orca_tgat_params* P, const float* time_b,
+                                   float* const* blobs, int blobs_packed_before, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  ORCA_REQUIRE(d_e >= 1 && d_e <= ORCA_MAX_DE, "orca_tgat_pack_layers: d_e=%d outside [1,%d]", d_e, ORCA_MAX_DE);
+  ORCA_REQUIRE(n_layers >= 0 && (n_layers == 0 || (P && blobs)), "orca_tgat_pack_layers: null pointer");
+  const Blob L = blob_layout(d_e);
+  const int width = L.KBT * 16;
+  for (int l0 = 0; l0 < n_layers; l0 += 2) {        // two layers per group of launches (the pack launch holds 32 jobs)
+    const int n = n_layers - l0 < 2 ? n_layers - l0 : 2;
+    FoldLayers F{};
+    F.n = n; F.kdim = L.kdim; F.KP = L.KP; F.width = width; F.gather = time_b ? 1 : 0; F.time_b = time_b;
+    OrcaPackJob jobs[ORCA_PACK_GROUP_MAX];
+    static_assert(ORCA_PACK_GROUP_MAX >= 2 * 14, "two layers' jobs in one launch");
+    int nj = 0;
+    for (int i = 0; i < n; ++i) {
+      const orca_tgat_params& p = P[l0 + i];
+      float* blob = blobs[l0 + i];
+      ORCA_REQUIRE(p.q_w && p.k_w && p.v_w && p.in_b && p.o_w && p.o_b && p.fc1_w && p.fc1_b && p.fc2_w && p.fc2_b && p.ln_w &&
+                   p.ln_b && blob, "orca_tgat_pack_layers: null pointer (layer %d)", l0 + i);
+      if (!blobs_packed_before) {     // the padding of the blob is written once; a re-pack leaves it alone
+        ORCA_HIP_TRY(hipMemsetAsync(blob, 0, (size_t)L.total * sizeof(float), s));
+      }
+      F.q_w[i] = p.q_w; F.k_w[i] = p.k_w; F.v_w[i] = p.v_w; F.in_b[i] = p.in_b; F.o_w[i] = p.o_w; F.o_b[i] = p.o_b;
+      F.fc1_w[i] = p.fc1_w;
+      F.U[i] = reinterpret_cast<double*>(blob + L.scr_u);
+      F.F[i] = blob + L.scr_f;
+      F.t[i] = reinterpret_cast<double*>(blob + L.scr_t);
+      F.A[i] = blob + L.scr_a;
+      F.a[i] = blob + L.b_qk;
+      nj += tgat_pack_jobs(jobs + nj, L, p.q_w, p.k_w, p.in_b, p.fc1_b, p.fc2_w, p.fc2_b, p.ln_w, p.ln_b, blob);
+      if (time_b) nj += tgat_pack_gather_jobs(jobs + nj, L, blob);
+    }
+    const int bu = (2 * D * D + 3 * QD + 255) / 256, bf = (D * width + 255) / 256,
+              bk = (2 * (L.kdim + 1) * (D + 1) + 255) / 256;
+    k_fold_stage1<<<(unsigned)(n * (bu + 1)), 256, 0, s>>>(F, bu);
+    k_fold_stage2<<<(unsigned)(n * (bf + bk)), 256, 0, s>>>(F, bf, bk);
+    if (hipGetLastError() != hipSuccess || orca_pack_group(jobs, nj, s) != ORCA_OK) {
+      orca_set_error("orca_tgat_pack_layers: kernel launch failed");
+      return ORCA_EHIP;
+    }
   }
   return ORCA_OK;
 }

@@ -140,10 +140,10 @@ class OrcaEngine:
     else:                      # re-pack in place: the native driver holds these addresses
       self.time_w.copy_(tw)
       self.time_b.copy_(tb)
-    for i in range(self.L):
-      p = f"embedding_module.attention_models.{i}."
-      self.att_blobs[i] = ops.tgat_pack({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, self.d_e, dev,
-                                        blob=self.att_blobs[i], time_b=self.time_b)
+    pre = "embedding_module.attention_models."
+    sds = [{k[len(f"{pre}{i}."):]: v for k, v in sd.items() if k.startswith(f"{pre}{i}.")} for i in range(self.L)]
+    # in place when they exist (the native driver holds the addresses); all layers' folds in shared launches
+    self.att_blobs = ops.tgat_pack_layers(sds, self.d_e, dev, blobs=None if first else self.att_blobs, time_b=self.time_b)
     p = "memory_updater.memory_updater."
     self.gru_blob = ops.gru_pack(sd[p + "weight_ih"], sd[p + "weight_hh"], sd[p + "bias_ih"], sd[p + "bias_hh"], dev,
                                  blob=self.gru_blob)

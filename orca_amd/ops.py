@@ -199,6 +199,37 @@ def tgat_pack(sd, d_e, device, blob=None, time_b=None):
   return blob
 
 
+def tgat_pack_layers(sds, d_e, device, blobs=None, time_b=None):
+  """tgat_pack for several layers at once (orca_tgat_pack_layers): the folds of all layers share launches.  sds: one
+  TGAT_KEYS state_dict per layer; blobs: their blobs from an earlier pack (re-packed in place) or None."""
+  lib = _lib.load()
+  n = lib.orca_tgat_blob_floats(int(d_e))
+  if n < 0:
+    raise ValueError(f"tgat_pack_layers: unsupported edge width {d_e}")
+  L = len(sds)
+  before = blobs is not None and all(b is not None for b in blobs)
+  if not before:
+    blobs = [torch.empty(n, dtype=torch.float32, device=device) for _ in range(L)]
+  P = (_lib.TgatParams * L)()
+  keep = []
+  for i, sd in enumerate(sds):
+    ts = [sd[k].detach().to(device=device, dtype=torch.float32).contiguous() for k in TGAT_KEYS]
+    if ts[1].shape != (2 * D, 2 * D + d_e):
+      raise ValueError(f"tgat_pack_layers: k_proj_weight has shape {tuple(ts[1].shape)}, expected {(2 * D, 2 * D + d_e)}")
+    keep.append(ts)
+    for (name, _), t in zip(_lib.TgatParams._fields_, ts):
+      setattr(P[i], name, ptr(t))
+  tb = None
+  if time_b is not None:
+    tb = time_b.detach().to(device=device, dtype=torch.float32).contiguous()
+    if tb.numel() != D:
+      raise ValueError(f"tgat_pack_layers: time_b has {tb.numel()} values, expected {D}")
+  B = (ctypes.c_void_p * L)(*[ptr(b) for b in blobs])
+  check(lib.orca_tgat_pack_layers(L, int(d_e), ctypes.cast(P, ctypes.c_void_p), ptr(tb), ctypes.cast(B, ctypes.c_void_p),
+                                  1 if before else 0, stream()), "orca_tgat_pack_layers")
+  return list(blobs)
+
+
 def tgat_forward(blob, d_e, Q, K, out=None, want_weights=False, **kw):
   """orca_tgat_forward.  kw: the fields of orca_tgat_inputs (tensors or None; q_folded: bool; dropout_p, dropout_seed,
   dropout_q0: attention-weight dropout, off by default)."""

@@ -165,6 +165,31 @@ def test_attention_dense_boundary(ops, golden, tag):
     assert_close_fp32(w.cpu().numpy(), g[tag + "weights"], 1e-5, tag + "weights")
 
 
+@pytest.mark.parametrize("d_e,gather", [(172, True), (172, False), (64, True)])
+def test_pack_layers_equals_pack(ops, d_e, gather):
+  """orca_tgat_pack_layers (all layers' folds in shared launches) writes bit for bit the blobs that orca_tgat_pack +
+  orca_tgat_pack_gather write layer by layer -- on fresh blobs and again as an in-place re-pack after the parameters
+  changed (three layers: two launch groups)."""
+  from orca_amd import synth
+  L = 3
+  pre = "embedding_module.attention_models."
+  def layers(seed):
+    sd = synth.tgn_state_dict(d_e, L, seed=seed)
+    return [{k[len(f"{pre}{i}."):]: v.to(DEV) for k, v in sd.items() if k.startswith(f"{pre}{i}.")} for i in range(L)]
+  tb = torch.from_numpy(np.random.RandomState(3).uniform(-1, 1, 100).astype(np.float32)).to(DEV) if gather else None
+  def same_bits(a, b):     # (the blob's fp64 scratch read as fp32 holds NaN patterns: compare the bits)
+    return torch.equal(a.view(torch.int32), b.view(torch.int32))
+  sds = layers(1)
+  blobs = ops.tgat_pack_layers(sds, d_e, DEV, time_b=tb)
+  for i in range(L):
+    assert same_bits(blobs[i], ops.tgat_pack(sds[i], d_e, DEV, time_b=tb)), f"layer {i}"
+  sds = layers(2)
+  again = ops.tgat_pack_layers(sds, d_e, DEV, blobs=blobs, time_b=tb)
+  for i in range(L):
+    assert again[i].data_ptr() == blobs[i].data_ptr()
+    assert same_bits(again[i], ops.tgat_pack(sds[i], d_e, DEV, time_b=tb)), f"re-packed layer {i}"
+
+
 @pytest.mark.parametrize("folded", [False, True])
 @pytest.mark.parametrize("d_e,K,Q", [(172, 10, 1000), (1, 10, 333), (172, 20, 130), (64, 7, 17)])
 def test_attention_gather_mode_vs_oracle(ops, golden, d_e, K, Q, folded):
