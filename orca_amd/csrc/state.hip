@@ -198,19 +198,23 @@ __global__ void k_index_positions(const int32_t* __restrict__ list, int64_t n, c
 // one global atomic per chunk instead of one per occurrence.  Ids beyond the chunk's SCAT_ROWS go to dst directly.
 // A wave takes 16 positions, four at a time with their loads in flight together (a loop over single rows pays a
 // memory round trip per row: measured 125 us that way).
-constexpr int SCAT_CHUNK = 256, SCAT_ROWS = 128, SCAT_HASH = 512, SCAT_U = 4;
+// CHUNK = positions per workgroup: 256, or 64 for short lists (4095 positions in chunks of 256 are 16 workgroups on a
+// 256-CU chip).  The LDS and the global adds are separate instructions (one pointer for both is a flat atomic).
+constexpr int SCAT_ROWS = 128, SCAT_HASH = 512, SCAT_U = 4;
+template <int SCAT_CHUNK>
 __global__ __launch_bounds__(1024) void k_scatter_add_flagged(const float* __restrict__ rows, const int64_t* __restrict__ idx64,
                                                               const int32_t* __restrict__ idx32, int64_t n,
                                                               const uint8_t* __restrict__ flags,
                                                               const int32_t* __restrict__ pos, int64_t n_nodes,
                                                               float* __restrict__ dst) {
-  __shared__ float acc[SCAT_ROWS][D];
-  __shared__ int keys[SCAT_HASH], vals[SCAT_HASH], key_of[SCAT_ROWS], n_rows;
+  constexpr int ROWS = SCAT_CHUNK < SCAT_ROWS ? SCAT_CHUNK : SCAT_ROWS;     // accumulator rows
+  __shared__ float acc[ROWS][D];
+  __shared__ int keys[SCAT_HASH], vals[SCAT_HASH], key_of[ROWS], n_rows;
   __shared__ int local[SCAT_CHUNK];     // accumulator row of a position, SCAT_ROWS + its dst row when it has none, -1: skip
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t base = (int64_t)blockIdx.x * SCAT_CHUNK;
   for (int i = t; i < SCAT_HASH; i += 1024) keys[i] = -1;
-  for (int i = t; i < SCAT_ROWS * D; i += 1024) (&acc[0][0])[i] = 0.f;
+  for (int i = t; i < ROWS * D; i += 1024) (&acc[0][0])[i] = 0.f;
   if (t == 0) n_rows = 0;
   __syncthreads();
   // the key of this thread's position: the row of dst it adds to, or -1
@@ -234,10 +238,10 @@ __global__ __launch_bounds__(1024) void k_scatter_add_flagged(const float* __res
   if (t < SCAT_HASH && keys[t] >= 0) {
     const int r = atomicAdd(&n_rows, 1);
     vals[t] = r;
-    if (r < SCAT_ROWS) key_of[r] = keys[t];
+    if (r < ROWS) key_of[r] = keys[t];
   }
   __syncthreads();
-  if (t < SCAT_CHUNK) local[t] = key < 0 ? -1 : (vals[h] < SCAT_ROWS ? vals[h] : SCAT_ROWS + key);
+  if (t < SCAT_CHUNK) local[t] = key < 0 ? -1 : (vals[h] < ROWS ? vals[h] : ROWS + key);
   __syncthreads();
   const int c1 = lane + 64;
   for (int i0 = wave * (SCAT_CHUNK / 16); i0 < (wave + 1) * (SCAT_CHUNK / 16); i0 += SCAT_U) {
@@ -253,13 +257,18 @@ __global__ __launch_bounds__(1024) void k_scatter_add_flagged(const float* __res
 #pragma unroll
     for (int u = 0; u < SCAT_U; ++u) {
       if (r[u] < 0) continue;
-      float* d = r[u] < SCAT_ROWS ? &acc[r[u]][0] : dst + (int64_t)(r[u] - SCAT_ROWS) * D;
-      atomicAdd(d + lane, va[u]);
-      if (c1 < D) atomicAdd(d + c1, vb[u]);
+      if (r[u] < ROWS) {          // wave-uniform
+        atomicAdd(&acc[r[u]][lane], va[u]);
+        if (c1 < D) atomicAdd(&acc[r[u]][c1], vb[u]);
+      } else {
+        float* d = dst + (int64_t)(r[u] - ROWS) * D;
+        atomicAdd(d + lane, va[u]);
+        if (c1 < D) atomicAdd(d + c1, vb[u]);
+      }
     }
   }
   __syncthreads();
-  const int nr = n_rows < SCAT_ROWS ? n_rows : SCAT_ROWS;
+  const int nr = n_rows < ROWS ? n_rows : ROWS;
   for (int r = wave; r < nr; r += 16) {
     float* d = dst + (int64_t)key_of[r] * D;
     atomicAdd(d + lane, acc[r][lane]);
@@ -564,7 +573,12 @@ ORCA_API int orca_scatter_add_flagged(const float* rows, const int64_t* idx64, c
   ORCA_REQUIRE(n >= 0 && (n == 0 || (rows && (idx64 || idx32) && flags && pos && dst)),
                "orca_scatter_add_flagged: bad arguments");
   if (n == 0) return ORCA_OK;
-  k_scatter_add_flagged<<<blocks(n, SCAT_CHUNK), 1024, 0, (hipStream_t)stream>>>(rows, idx64, idx32, n, flags, pos, n_nodes, dst);
+  if (n <= 16384)
+    k_scatter_add_flagged<64><<<blocks(n, 64), 1024, 0, (hipStream_t)stream>>>(rows, idx64, idx32, n, flags, pos, n_nodes, dst);
+  else if (n <= 131072)      // (41 k positions: 29 us in chunks of 128, 35 in chunks of 64, 40 in chunks of 256)
+    k_scatter_add_flagged<128><<<blocks(n, 128), 1024, 0, (hipStream_t)stream>>>(rows, idx64, idx32, n, flags, pos, n_nodes, dst);
+  else
+    k_scatter_add_flagged<256><<<blocks(n, 256), 1024, 0, (hipStream_t)stream>>>(rows, idx64, idx32, n, flags, pos, n_nodes, dst);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
