@@ -10,6 +10,8 @@
 // (q~_h = Wk_h^T 0.1 q_h, x-bar_h = sum_j a_hj x_j), so the K x k_dim key matrix is never projected.
 // Intermediates live in a caller-provided workspace (orca_tgat_backward_workspace_floats).
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -241,6 +243,141 @@ __global__ __launch_bounds__(256) void k_sgemm_rows(GemmGroup grp) {
     }
 }
 
+// ---- weight gradients: C [M x N] = A^T B, a reduction over the queries -------------------------------------------
+// A [K x M] and B [K x N] are both row-major with the reduction index k slowest (activations and their gradients, one
+// row per query).  No LDS staging: lane (c = lane & 15, kq = lane >> 4) loads V consecutive floats of row k0 + kq of A
+// and four of B -- V m-tiles and four n-tiles of 16 whose rows / columns are interleaved (tile t holds the rows
+// m0 + V i + t) -- so one pair of fully coalesced vector loads feeds 4 V MFMAs of a (16 V) x 64 wave tile, and nothing
+// is shared between waves.  M is cut into 64-row pieces (V = 4) and a remainder of 32 (V = 2) and / or 16 (V = 1):
+// 100 rows are 64 + 32 + 16, not two thirds-empty 64 x 64 tiles.  The four waves of a workgroup take a quarter of the
+// block's k range each and meet in LDS in a fixed order (deterministic); the block-level split-K partials then go
+// through k_splitk_reduce as before.  The virtual ones column (bias gradients) is a select on B.
+constexpr int WG_SPLITS = 8;
+__device__ __forceinline__ int wgrad_m_items(int M) {
+  const int r = M & 63;
+  return (M >> 6) + (r == 0 ? 0 : (r > 32 && r <= 48) ? 2 : 1);
+}
+template <int V>
+__device__ __forceinline__ void wgrad_tile(const GemmArgs& g, int m0, int n0, int bz, f32x4* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kq = lane >> 4;
+  const int Nr = g.ones_out ? g.N - 1 : g.N;
+  const int kbeg = bz * g.kchunk;
+  const int kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
+  const int sub = (g.kchunk / 4 + 3) / 4 * 4;            // this wave's share of the block's k range
+  const int kb = kbeg + wave * sub;
+  const int ke = kb + sub < kend ? kb + sub : kend;
+  const int ma = m0 + V * c, nb = n0 + 4 * c;
+  const bool mok = ma < g.M, nok = nb < Nr, one = nb == Nr;
+  const float* ap = g.A + (mok ? ma : 0);
+  const float* bp = g.B + (nok ? nb : 0);
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[V][4];
+#pragma unroll
+  for (int t = 0; t < V; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[t][u] = zero4;
+  // Out-of-range lanes load from clamped addresses and are masked ARITHMETICALLY (times 0 or 1: the data is finite): a
+  // select lets the compiler sink the load under a branch, and behind a branch every load is waited for on the spot --
+  // the loop then alternates between waiting and multiplying instead of overlapping them.  Rows m >= M need no mask
+  // at all: their accumulators are never stored.
+  const float nokf = nok ? 1.f : 0.f, onef = one ? 1.f : 0.f;
+  struct Ops { float a[V]; f32x4 b; };
+  auto load = [&](int k0) {          // the raw operands of step k0 (requested, not yet looked at)
+    Ops o;
+    const int k = k0 + kq;
+    const int kc = k < ke ? k : kbeg;                    // clamped, never skipped
+    const float* pa = ap + (int64_t)kc * g.sak;
+    if constexpr (V == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(pa); o.a[0] = v[0]; o.a[1] = v[1]; o.a[2] = v[2]; o.a[3] = v[3]; }
+    else if constexpr (V == 2) { const float2 v = *reinterpret_cast<const float2*>(pa); o.a[0] = v.x; o.a[1] = v.y; }
+    else o.a[0] = *pa;
+    o.b = *reinterpret_cast<const f32x4*>(bp + (int64_t)kc * g.sbk);
+    return o;
+  };
+  auto mask = [&](Ops& o, int k0) {
+    const float kokf = k0 + kq < ke ? 1.f : 0.f;
+#pragma unroll
+    for (int t = 0; t < V; ++t) o.a[t] *= kokf;
+    o.b = o.b * nokf;
+    o.b[0] += onef;
+  };
+  auto mma = [&](const Ops& o) {
+#pragma unroll
+    for (int t = 0; t < V; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[t], o.b[u], acc[t][u], 0, 0, 0);
+  };
+  if (kb < ke) {
+    Ops r0 = load(kb), r1 = load(kb + 4);
+    for (int k0 = kb; k0 < ke; k0 += 8) {
+      Ops c0 = r0, c1 = r1;
+      mask(c0, k0);                      // (the wait for this step's operands, requested one iteration ago)
+      mask(c1, k0 + 4);
+      r0 = load(k0 + 8);                 // the next iteration's: in flight under the 8 V MFMAs below
+      r1 = load(k0 + 12);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(c0);
+      mma(c1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // waves 2, 3 -> LDS; waves 0, 1 add them; wave 1 -> LDS; wave 0 adds it and stores the block's partial sums
+  auto put = [&](f32x4* dst) {
+#pragma unroll
+    for (int t = 0; t < V; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dst[(t * 4 + u) * 64 + lane] = acc[t][u];
+  };
+  auto add = [&](const f32x4* src) {
+#pragma unroll
+    for (int t = 0; t < V; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u] += src[(t * 4 + u) * 64 + lane];
+  };
+  if (wave >= 2) put(red + (wave - 2) * 1024);
+  __syncthreads();
+  if (wave < 2) add(red + wave * 1024);
+  __syncthreads();
+  if (wave == 1) put(red);
+  __syncthreads();
+  if (wave == 0) {
+    add(red);
+#pragma unroll
+    for (int t = 0; t < V; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + V * (4 * kq + r) + t, n = n0 + 4 * c + u;
+          if (m < g.M && n < g.N) g.part[((int64_t)bz * g.M + m) * g.N + n] = acc[t][u][r];
+        }
+  }
+}
+// The tiles of a launch differ in cost (V = 4, 2, 1) and the whole launch is resident at once -- about one round of
+// workgroups -- so the ORDER of the blocks decides how evenly the CUs are loaded: the host lists the (problem, m piece,
+// n block) tiles heaviest first, and every tile's k pieces are consecutive blocks.
+constexpr int WG_ITEMS_MAX = 448;
+struct WgItems {
+  int n, gz;
+  uint16_t code[WG_ITEMS_MAX];      // problem << 8 | m piece << 4 | n block
+};
+__global__ __launch_bounds__(256, 4) void k_wgrad(GemmGroup grp, WgItems items) {
+  __shared__ f32x4 red[2 * 1024];
+  const int item = (int)blockIdx.x / items.gz, bz = (int)blockIdx.x % items.gz;
+  const int code = items.code[item];
+  const int p = code >> 8, mi = (code >> 4) & 15, bx = code & 15;
+  const GemmArgs g = grp.g[p];
+  // the mi-th piece of M: full 64-row pieces first, then the remainder as 32 + 16, 32 or 16 rows
+  const int full = g.M >> 6, r = g.M & 63;
+  int m0 = mi * 64, V = 4;
+  if (mi >= full && r <= 48) {
+    if (r > 32) { V = mi == full ? 2 : 1; m0 = full * 64 + (mi == full ? 0 : 32); }
+    else V = r > 16 ? 2 : 1;
+  }
+  if (V == 4) wgrad_tile<4>(g, m0, bx * 64, bz, red);
+  else if (V == 2) wgrad_tile<2>(g, m0, bx * 64, bz, red);
+  else wgrad_tile<1>(g, m0, bx * 64, bz, red);
+}
+
 // the split-K sums of every problem of a group that has them
 __global__ __launch_bounds__(256) void k_splitk_reduce(GemmGroup grp) {
   int p = 0;
@@ -394,6 +531,58 @@ int orca_sgemm_group(hipStream_t s, const OrcaGemm* in, int n, float* part) {
       if (kfast) k_sgemm_rows<true><<<(unsigned)first, 256, 0, s>>>(grp);
       else k_sgemm_rows<false><<<(unsigned)first, 256, 0, s>>>(grp);
       return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
+    }
+  }
+  {   // weight gradients (see k_wgrad): every problem split, reduction index slowest in both operands, float4-able
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    bool wg = any_split;
+    for (int i = 0; i < np && wg; ++i) {
+      const GemmArgs& g = grp.g[i];
+      const int Nr = g.ones_out ? g.N - 1 : g.N;
+      wg = g.gz > 1 && g.sam == 1 && g.sbn == 1 && g.M % 4 == 0 && Nr % 4 == 0 && g.sak % 4 == 0 && g.sbk % 4 == 0 &&
+           al16(g.A) && al16(g.B) && g.scn == 1 && !g.bias && !g.relu && !g.gate && !g.rowzero;
+    }
+    static const bool off = getenv("ORCA_GEMM_WGRAD") && atoi(getenv("ORCA_GEMM_WGRAD")) == 0;
+    if (wg && !off) {
+      GemmGroup w = grp;
+      int64_t po2 = 0;
+      struct It { int v, code; };
+      std::vector<It> list;
+      bool fits = true;
+      for (int i = 0; i < np; ++i) {
+        GemmArgs& g = w.g[i];
+        const int kc = (g.K + WG_SPLITS - 1) / WG_SPLITS;
+        g.kchunk = (kc + 15) / 16 * 16;
+        g.gz = (g.K + g.kchunk - 1) / g.kchunk;
+        if (g.gz != w.g[0].gz) fits = false;       // (one k split for the whole launch: the problems share K)
+        g.part = part + po2;              // (never more than the 16 or 32 pieces the caller sized `part` for)
+        po2 += ((int64_t)g.gz * g.M * g.N + 63) / 64 * 64;
+        g.gx = (g.N + 63) / 64;
+        const int full = g.M >> 6, r = g.M & 63;
+        g.gy = full + (r == 0 ? 0 : (r > 32 && r <= 48) ? 2 : 1);
+        if (g.gx > 16 || g.gy > 16) fits = false;
+        for (int mi = 0; mi < g.gy; ++mi) {
+          int v = 4;
+          if (mi >= full && r <= 48) v = r > 32 ? (mi == full ? 2 : 1) : (r > 16 ? 2 : 1);
+          for (int bx = 0; bx < g.gx; ++bx) list.push_back(It{v, i << 8 | mi << 4 | bx});
+        }
+      }
+      if (fits && (int)list.size() <= WG_ITEMS_MAX) {
+        std::stable_sort(list.begin(), list.end(), [](const It& x, const It& y) { return x.v > y.v; });
+        WgItems items{};
+        items.n = (int)list.size();
+        items.gz = w.g[0].gz;
+        for (int i = 0; i < items.n; ++i) items.code[i] = (uint16_t)list[i].code;
+        k_wgrad<<<(unsigned)(items.n * items.gz), 256, 0, s>>>(w, items);
+        int fb = 0;
+        for (int i = 0; i < np; ++i) {
+          w.first[i] = fb;
+          fb += (int)(((int64_t)w.g[i].M * w.g[i].N + 255) / 256);
+        }
+        w.first[np] = fb;
+        k_splitk_reduce<<<(unsigned)fb, 256, 0, s>>>(w);
+        return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
+      }
     }
   }
   // under two blocks per CU: halve the tile, double the blocks (a block is one wave per SIMD: its chain of slabs is
