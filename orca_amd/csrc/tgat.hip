@@ -78,45 +78,72 @@ __host__ __device__ constexpr Blob blob_layout(int d_e) {
 // U[2*D*D + h*QD + j] = sum_{k in head h} Wo[j][k] bv[k]  (the out-projection of head h's value bias: it reaches the
 //                        output scaled by the sum of that head's attention weights -- 1 unless dropout is on)
 // U[2*D*D + 2*QD + j] = bo[j]
-__device__ __forceinline__ void fold_u(int i, const float* __restrict__ fc1_w, const float* __restrict__ o_w,
-                                       const float* __restrict__ o_b, const float* __restrict__ bv, double* __restrict__ U) {
-  if (i >= 2 * D * D + 3 * QD) return;
-  if (i >= 2 * D * D) {
-    const int r = i - 2 * D * D, part = r / QD, j = r % QD;
-    if (part < 2) {
-      double t = 0.0;
-#pragma unroll 10
-      for (int k = 0; k < D; ++k) t += (double)o_w[j * QD + part * D + k] * (double)bv[part * D + k];
-      U[i] = t;
-    } else if (part == 2) {
-      U[i] = (double)o_b[j];
-    }
-    return;
-  }
-  const int h = i / (D * D), n = (i / D) % D, d = i % D;
-  double acc = 0.0;
-#pragma unroll 10
-  for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * (double)o_w[j * QD + h * D + d];
-  U[i] = acc;
+// The products themselves run on the fp64 matrix pipe, one wave per 16 x 16 tile: as one thread per element with a
+// 100- or 200-step loop these folds were latency chains of 12-23 us per kernel (a re-pack follows every optimizer
+// step).  C tile (rows m0.., columns n0..) of A [M x K] B [K x N] on v_mfma_f64_16x16x4f64: lane (r = lane & 15,
+// kq = lane >> 4) supplies A(m0 + r, k0 + kq) and B(k0 + kq, n0 + r) and receives C(m0 + 4 i + kq, n0 + r), i < 4.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <int K, class GA, class GB, class ST>
+__device__ __forceinline__ void fold_tile(int m0, int n0, int M, int N, GA A, GB B, ST store) {
+  const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+  const int m = m0 + r < M ? m0 + r : M - 1, n = n0 + r < N ? n0 + r : N - 1;     // clamped, never skipped
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  // (fully unrolled: every operand is requested before the first product; with a loop left over, each load is waited
+  // for where it is issued -- 29 us for the K = 200 product instead of 4)
+#pragma unroll
+  for (int k0 = 0; k0 < K; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A(m, k0 + kq), B(k0 + kq, n), acc, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (m0 + 4 * i + kq < M && n0 + r < N) store(m0 + 4 * i + kq, n0 + r, acc[i]);
 }
-__global__ void k_fold_u(const float* __restrict__ fc1_w, const float* __restrict__ o_w, const float* __restrict__ o_b,
-                         const float* __restrict__ bv, double* __restrict__ U) {
-  fold_u(blockIdx.x * blockDim.x + threadIdx.x, fc1_w, o_w, o_b, bv, U);
+constexpr int FOLD_T100 = (D + 15) / 16;     // 16-wide tiles of a 100-long index
+// tile w of U[h][n][d] = sum_j W1[n][j] Wo[j][h*100 + d]
+__device__ __forceinline__ void fold_u_tile(int w, const float* __restrict__ fc1_w, const float* __restrict__ o_w,
+                                            double* __restrict__ U) {
+  if (w >= 2 * FOLD_T100 * FOLD_T100) return;
+  const int h = w / (FOLD_T100 * FOLD_T100), mt = (w / FOLD_T100) % FOLD_T100, nt = w % FOLD_T100;
+  fold_tile<QD>(mt * 16, nt * 16, D, D,
+                [&](int n, int j) { return (double)fc1_w[n * 3 * D + j]; },
+                [&](int j, int d) { return (double)o_w[j * QD + h * D + d]; },
+                [&](int n, int d, double v) { U[(h * D + n) * D + d] = v; });
+}
+// the rest of U: i >= 2*D*D
+__device__ __forceinline__ void fold_u_rest(int r, const float* __restrict__ o_w, const float* __restrict__ o_b,
+                                            const float* __restrict__ bv, double* __restrict__ U) {
+  if (r >= 3 * QD) return;
+  const int part = r / QD, j = r % QD;
+  if (part < 2) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) t += (double)o_w[j * QD + part * D + k] * (double)bv[part * D + k];
+    U[2 * D * D + r] = t;
+  } else {
+    U[2 * D * D + r] = (double)o_b[j];
+  }
 }
 // F [100, KBT*16]: columns h*KP + c (c < kdim) = sum_d U[h][n][d] Wv[h*100 + d][c];  column h*KP + kdim = the
 // constant W1a Wo_h bv_h of head h (multiplied by that head's weight sum);  columns 2*KP + k (k < 100) =
 // W1[n][200 + k];  column 2*KP + 100 = W1a bo (multiplied by 1 for a valid query);  zero elsewhere.
-__device__ __forceinline__ void fold_f(int i, const double* __restrict__ U, const float* __restrict__ v_w,
-                                       const float* __restrict__ fc1_w, int kdim, int KP, int width, float* __restrict__ F) {
+__device__ __forceinline__ void fold_f_tile(int w, const double* __restrict__ U, const float* __restrict__ v_w, int kdim,
+                                            int KP, int width, float* __restrict__ F) {
+  const int ntc = (kdim + 15) / 16;
+  if (w >= 2 * FOLD_T100 * ntc) return;
+  const int h = w / (FOLD_T100 * ntc), mt = (w / ntc) % FOLD_T100, nt = w % ntc;
+  fold_tile<D>(mt * 16, nt * 16, D, kdim,
+               [&](int n, int d) { return U[(h * D + n) * D + d]; },
+               [&](int d, int c) { return (double)v_w[(int64_t)(h * D + d) * kdim + c]; },
+               [&](int n, int c, double v) { F[n * width + h * KP + c] = (float)v; });
+}
+// every element of F outside the two [100 x kdim] products
+__device__ __forceinline__ void fold_f_rest(int i, const double* __restrict__ U, const float* __restrict__ fc1_w, int kdim,
+                                            int KP, int width, float* __restrict__ F) {
   if (i >= D * width) return;
   const int n = i / width, col = i % width;
   double acc = 0.0;
   if (col < 2 * KP) {
     const int h = col / KP, c = col - h * KP;
-    if (c < kdim) {
-#pragma unroll 10
-      for (int d = 0; d < D; ++d) acc += U[(h * D + n) * D + d] * (double)v_w[(int64_t)(h * D + d) * kdim + c];
-    } else if (c == kdim) {
+    if (c < kdim) return;                      // (fold_f_tile)
+    if (c == kdim) {
       for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * U[2 * D * D + h * QD + j];
     }
   } else if (col < 2 * KP + D) {
@@ -126,11 +153,6 @@ __device__ __forceinline__ void fold_f(int i, const double* __restrict__ U, cons
   }
   F[i] = (float)acc;
 }
-__global__ void k_fold_f(const double* __restrict__ U, const float* __restrict__ v_w, const float* __restrict__ in_b,
-                         const float* __restrict__ o_w, const float* __restrict__ o_b, const float* __restrict__ fc1_w,
-                         int kdim, int KP, int width, float* __restrict__ F) {
-  fold_f(blockIdx.x * blockDim.x + threadIdx.x, U, v_w, fc1_w, kdim, KP, width, F);
-}
 
 // ---- folding the q projection into the key map (gather mode: the source's time encoding is the constant
 // cos(time_b), embedding_module.py:126) ---------------------------------------------------------------------
@@ -139,51 +161,33 @@ __device__ __forceinline__ void fold_qt(int j, const float* __restrict__ q_w, co
                                         const float* __restrict__ time_b, double* __restrict__ t) {
   if (j >= QD) return;
   double acc = (double)in_b[j];
-#pragma unroll 4
+#pragma unroll
   for (int i = 0; i < D; ++i)
     acc += (double)q_w[j * QD + D + i] * (double)orca_cosf(orca_time_arg(0.0f, 0.0f, time_b[i]));
   t[j] = acc;
 }
-__global__ void k_fold_qt(const float* __restrict__ q_w, const float* __restrict__ in_b,
-                          const float* __restrict__ time_b, double* __restrict__ t) {
-  fold_qt(blockIdx.x * blockDim.x + threadIdx.x, q_w, in_b, time_b, t);
-}
 // A [2][kdim+1][100]: A[h][c][s] = 0.1 sum_d Wk'[h][d][c] Wq[h*100 + d][s], with Wk'[h][d][kdim] = bk[h*100 + d];
-// a [2][KP]: a[h][c] = 0.1 sum_d Wk'[h][d][c] t[h*100 + d]    (zero beyond kdim)
-__device__ __forceinline__ void fold_qk(int i, const float* __restrict__ q_w, const float* __restrict__ k_w,
-                                        const float* __restrict__ in_b, const double* __restrict__ t, int kdim, int KP,
-                                        float* __restrict__ A, float* __restrict__ a) {
-  const int per = (kdim + 1) * (D + 1);
-  if (i >= 2 * per) return;
-  const int h = i / per, c = (i % per) / (D + 1), s = i % (D + 1);
+// a [2][KP]: a[h][c] = 0.1 sum_d Wk'[h][d][c] t[h*100 + d]    (zero beyond kdim) -- column s = 100 of the same product
+__device__ __forceinline__ void fold_qk_tile(int w, const float* __restrict__ q_w, const float* __restrict__ k_w,
+                                             const float* __restrict__ in_b, const double* __restrict__ t, int kdim, int KP,
+                                             float* __restrict__ A, float* __restrict__ a) {
+  const int mtc = (kdim + 1 + 15) / 16;
+  if (w >= 2 * mtc * FOLD_T100) return;
+  const int h = w / (mtc * FOLD_T100), mt = (w / FOLD_T100) % mtc, nt = w % FOLD_T100;
   const double scale = (double)0.1f;
-  double acc = 0.0;
-  // branch-free operands (a select inside the loop keeps it from being unrolled into batched loads, and a loop that
-  // is not pays a memory round trip per step: 37 us for this kernel)
-  const float* wk = c < kdim ? k_w + (int64_t)h * D * kdim + c : in_b + QD + h * D;
-  const int64_t wks = c < kdim ? kdim : 1;
-  if (s < D) {
-    const float* wq = q_w + (int64_t)h * D * QD + s;
-#pragma unroll 20
-    for (int d = 0; d < D; ++d) acc += (double)wk[d * wks] * (double)wq[d * QD];
-  } else {
-#pragma unroll 20
-    for (int d = 0; d < D; ++d) acc += (double)wk[d * wks] * t[h * D + d];
-  }
-  if (s < D) A[((int64_t)h * (kdim + 1) + c) * D + s] = (float)(scale * acc);
-  else a[h * KP + c] = (float)(scale * acc);
+  fold_tile<D>(mt * 16, nt * 16, kdim + 1, D + 1,
+               [&](int c, int d) { return (double)(c < kdim ? k_w[(int64_t)(h * D + d) * kdim + c] : in_b[QD + h * D + d]); },
+               [&](int d, int s_) { return s_ < D ? (double)q_w[(int64_t)(h * D + d) * QD + s_] : t[h * D + d]; },
+               [&](int c, int s_, double v) {
+                 if (s_ < D) A[((int64_t)h * (kdim + 1) + c) * D + s_] = (float)(scale * v);
+                 else a[h * KP + c] = (float)(scale * v);
+               });
 }
-__global__ void k_fold_qk(const float* __restrict__ q_w, const float* __restrict__ k_w, const float* __restrict__ in_b,
-                          const double* __restrict__ t, int kdim, int KP, float* __restrict__ A,
-                          float* __restrict__ a) {
-  fold_qk(blockIdx.x * blockDim.x + threadIdx.x, q_w, k_w, in_b, t, kdim, KP, A, a);
-}
-// The folds of SEVERAL layers, both kinds at once: a re-pack after every optimizer step was eight fold launches of
-// 8-23 us (each a few hundred blocks, latency-bound) -- here stage 1 is fold_u and fold_qt of every layer in one
-// launch, stage 2 fold_f and fold_qk.
+// The folds of one or several layers, both kinds at once (a re-pack after every optimizer step was eight fold launches
+// per layer pair): stage 1 is U and t of every layer in one launch, stage 2 F and A.  Block roles by index.
 constexpr int FOLD_LAYERS = 4;
 struct FoldLayers {
-  int n, kdim, KP, width, gather;
+  int n, kdim, KP, width, tail, gather;      // tail: the folded tail (orca_tgat_pack); gather: the q fold (orca_tgat_pack_gather)
   const float *q_w[FOLD_LAYERS], *k_w[FOLD_LAYERS], *v_w[FOLD_LAYERS], *in_b[FOLD_LAYERS], *o_w[FOLD_LAYERS],
       *o_b[FOLD_LAYERS], *fc1_w[FOLD_LAYERS];
   const float* time_b;
@@ -193,15 +197,34 @@ struct FoldLayers {
   float* A[FOLD_LAYERS];
   float* a[FOLD_LAYERS];
 };
-__global__ __launch_bounds__(256) void k_fold_stage1(FoldLayers L, int bu) {
-  const int per = bu + 1, l = blockIdx.x / per, local = blockIdx.x % per;
-  if (local < bu) fold_u(local * 256 + threadIdx.x, L.fc1_w[l], L.o_w[l], L.o_b[l], L.in_b[l] + 2 * QD, L.U[l]);
-  else if (L.gather) fold_qt(threadIdx.x, L.q_w[l], L.in_b[l], L.time_b, L.t[l]);
+constexpr int FOLD_BU = (2 * FOLD_T100 * FOLD_T100 + 3) / 4, FOLD_BR = (3 * QD + 255) / 256;
+__global__ __launch_bounds__(256) void k_fold_stage1(FoldLayers L) {
+  const int per = FOLD_BU + FOLD_BR + 1, l = blockIdx.x / per, local = blockIdx.x % per;
+  if (local < FOLD_BU) {
+    if (L.tail) fold_u_tile(local * 4 + (threadIdx.x >> 6), L.fc1_w[l], L.o_w[l], L.U[l]);
+  } else if (local < FOLD_BU + FOLD_BR) {
+    if (L.tail) fold_u_rest((local - FOLD_BU) * 256 + threadIdx.x, L.o_w[l], L.o_b[l], L.in_b[l] + 2 * QD, L.U[l]);
+  } else if (L.gather) {
+    fold_qt(threadIdx.x, L.q_w[l], L.in_b[l], L.time_b, L.t[l]);
+  }
 }
-__global__ __launch_bounds__(256) void k_fold_stage2(FoldLayers L, int bf, int bk) {
-  const int per = bf + bk, l = blockIdx.x / per, local = blockIdx.x % per;
-  if (local < bf) fold_f(local * 256 + threadIdx.x, L.U[l], L.v_w[l], L.fc1_w[l], L.kdim, L.KP, L.width, L.F[l]);
-  else if (L.gather) fold_qk((local - bf) * 256 + threadIdx.x, L.q_w[l], L.k_w[l], L.in_b[l], L.t[l], L.kdim, L.KP, L.A[l], L.a[l]);
+__global__ __launch_bounds__(256) void k_fold_stage2(FoldLayers L, int bft, int bfr, int bk) {
+  const int per = bft + bfr + bk, l = blockIdx.x / per, local = blockIdx.x % per;
+  if (local < bft) {
+    if (L.tail) fold_f_tile(local * 4 + (threadIdx.x >> 6), L.U[l], L.v_w[l], L.kdim, L.KP, L.width, L.F[l]);
+  } else if (local < bft + bfr) {
+    if (L.tail) fold_f_rest((local - bft) * 256 + threadIdx.x, L.U[l], L.fc1_w[l], L.kdim, L.KP, L.width, L.F[l]);
+  } else if (L.gather) {
+    fold_qk_tile((local - bft - bfr) * 4 + (threadIdx.x >> 6), L.q_w[l], L.k_w[l], L.in_b[l], L.t[l], L.kdim, L.KP, L.A[l], L.a[l]);
+  }
+}
+// launches both stages for the layers described by F (host side)
+int fold_launch(const FoldLayers& F, hipStream_t s) {
+  const int bft = (2 * FOLD_T100 * ((F.kdim + 15) / 16) + 3) / 4, bfr = (D * F.width + 255) / 256,
+            bk = (2 * ((F.kdim + 1 + 15) / 16) * FOLD_T100 + 3) / 4;
+  k_fold_stage1<<<(unsigned)(F.n * (FOLD_BU + FOLD_BR + 1)), 256, 0, s>>>(F);
+  k_fold_stage2<<<(unsigned)(F.n * (bft + bfr + bk)), 256, 0, s>>>(F, bft, bfr, bk);
+  return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
 }
 __global__ void k_pack(float* __restrict__ dst, int KB, int n0, int n_cnt, int Kd, const float* __restrict__ src,
                        int64_t sn, int64_t sk, int tail1) {
@@ -348,11 +371,14 @@ ORCA_API int orca_tgat_pack(int d_e, const float* q_w, const float* k_w, const f
   int rc = ORCA_OK;
   // the folded tail (see the head of this file): multiplied out in fp64 in scratch memory first
   const int width = L.KBT * 16;
-  double* U = reinterpret_cast<double*>(blob + L.scr_u);
-  float* F = blob + L.scr_f;
-  k_fold_u<<<(2 * D * D + 3 * QD + 255) / 256, 256, 0, s>>>(fc1_w, o_w, o_b, in_b + 2 * QD, U);
-  k_fold_f<<<(D * width + 255) / 256, 256, 0, s>>>(U, v_w, in_b, o_w, o_b, fc1_w, kdim, L.KP, width, F);
-  if (hipGetLastError() != hipSuccess) rc = ORCA_EHIP;
+  {
+    FoldLayers F{};
+    F.n = 1; F.kdim = kdim; F.KP = L.KP; F.width = width; F.tail = 1; F.gather = 0;
+    F.q_w[0] = q_w; F.k_w[0] = k_w; F.v_w[0] = v_w; F.in_b[0] = in_b; F.o_w[0] = o_w; F.o_b[0] = o_b; F.fc1_w[0] = fc1_w;
+    F.U[0] = reinterpret_cast<double*>(blob + L.scr_u);
+    F.F[0] = blob + L.scr_f;
+    rc |= fold_launch(F, s);
+  }
   OrcaPackJob jobs[ORCA_PACK_GROUP_MAX];
   int nj = tgat_pack_jobs(jobs, L, q_w, k_w, in_b, fc1_b, fc2_w, fc2_b, ln_w, ln_b, blob);
   rc |= orca_pack_group(jobs, nj, s);
@@ -370,13 +396,17 @@ ORCA_API int orca_tgat_pack_gather(int d_e, const float* q_w, const float* k_w, 
   ORCA_REQUIRE(q_w && k_w && in_b && time_b && blob, "orca_tgat_pack_gather: null pointer");
   Blob L = blob_layout(d_e);
   const int kdim = L.kdim;
-  double* t = reinterpret_cast<double*>(blob + L.scr_t);
-  float* A = blob + L.scr_a;
   int rc = ORCA_OK;
   hipError_t e0 = hipMemsetAsync(blob + L.b_qk, 0, sizeof(float) * 2 * L.KP, s);
-  k_fold_qt<<<1, 256, 0, s>>>(q_w, in_b, time_b, t);
-  k_fold_qk<<<(2 * (kdim + 1) * (D + 1) + 255) / 256, 256, 0, s>>>(q_w, k_w, in_b, t, kdim, L.KP, A, blob + L.b_qk);
-  if (hipGetLastError() != hipSuccess) rc = ORCA_EHIP;
+  {
+    FoldLayers F{};
+    F.n = 1; F.kdim = kdim; F.KP = L.KP; F.width = L.KBT * 16; F.tail = 0; F.gather = 1; F.time_b = time_b;
+    F.q_w[0] = q_w; F.k_w[0] = k_w; F.in_b[0] = in_b;
+    F.t[0] = reinterpret_cast<double*>(blob + L.scr_t);
+    F.A[0] = blob + L.scr_a;
+    F.a[0] = blob + L.b_qk;
+    rc |= fold_launch(F, s);
+  }
   OrcaPackJob jobs[3];
   tgat_pack_gather_jobs(jobs, L, blob);
   rc |= orca_pack_group(jobs, 3, s);
@@ -398,7 +428,7 @@ ORCA_API int orca_tgat_pack_layers(int n_layers, int d_e, const orca_tgat_params
   for (int l0 = 0; l0 < n_layers; l0 += 2) {        // two layers per group of launches (the pack launch holds 32 jobs)
     const int n = n_layers - l0 < 2 ? n_layers - l0 : 2;
     FoldLayers F{};
-    F.n = n; F.kdim = L.kdim; F.KP = L.KP; F.width = width; F.gather = time_b ? 1 : 0; F.time_b = time_b;
+    F.n = n; F.kdim = L.kdim; F.KP = L.KP; F.width = width; F.tail = 1; F.gather = time_b ? 1 : 0; F.time_b = time_b;
     OrcaPackJob jobs[ORCA_PACK_GROUP_MAX];
     static_assert(ORCA_PACK_GROUP_MAX >= 2 * 14, "two layers' jobs in one launch");
     int nj = 0;
@@ -420,11 +450,7 @@ ORCA_API int orca_tgat_pack_layers(int n_layers, int d_e, const orca_tgat_params
       nj += tgat_pack_jobs(jobs + nj, L, p.q_w, p.k_w, p.in_b, p.fc1_b, p.fc2_w, p.fc2_b, p.ln_w, p.ln_b, blob);
       if (time_b) nj += tgat_pack_gather_jobs(jobs + nj, L, blob);
     }
-    const int bu = (2 * D * D + 3 * QD + 255) / 256, bf = (D * width + 255) / 256,
-              bk = (2 * (L.kdim + 1) * (D + 1) + 255) / 256;
-    k_fold_stage1<<<(unsigned)(n * (bu + 1)), 256, 0, s>>>(F, bu);
-    k_fold_stage2<<<(unsigned)(n * (bf + bk)), 256, 0, s>>>(F, bf, bk);
-    if (hipGetLastError() != hipSuccess || orca_pack_group(jobs, nj, s) != ORCA_OK) {
+    if (fold_launch(F, s) != ORCA_OK || orca_pack_group(jobs, nj, s) != ORCA_OK) {
       orca_set_error("orca_tgat_pack_layers: kernel launch failed");
       return ORCA_EHIP;
     }

@@ -1125,6 +1125,7 @@ struct ChainStage {
         if (ch + 1 < CPI) load(g, itc, ch + 1);
         else if (rr + 1 < R) load(g, item + CH_WAVES, 0);
         else next(g);
+        __builtin_amdgcn_sched_barrier(0);     // the requests stay ahead of the MFMAs (the scheduler sinks them to their use)
         if (active) {
 #pragma unroll
           for (int i = 0; i < CB; ++i) {

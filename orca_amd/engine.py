@@ -764,8 +764,10 @@ class OrcaEngine:
     if out is None:
       out = self._all_gather_rows(emb, Q, per)
     # ---- link decoder + loss, forward and backward (tgn_model.py:150-157, train.py:231-233): orca_decoder_train ----
+    # (every gradient buffer of the step out of one zero fill, sized by what the previous step asked for)
+    pool = ops.ZeroPool(getattr(self, "_grad_pool_floats", 0), dev)
     loss, d_out, ga, _ = ops.decoder_train(out, self.aff["fc1.weight"], self.aff["fc1.bias"], self.aff["fc2.weight"],
-                                           self.aff["fc2.bias"])
+                                           self.aff["fc2.bias"], pool=pool)
     loss = loss.reshape(())
     grads = {"affinity_score." + k: v for k, v in ga.items()}
     # ---- backward through the attention calls, last to first (this rank's slice) ----
@@ -780,7 +782,7 @@ class OrcaEngine:
       kw.update(tables)
       if layer == 1:
         kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
-      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, m, K, d, want_time_param_grads=want_t, **kw)
+      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, m, K, d, want_time_param_grads=want_t, pool=pool, **kw)
       for k, v in g.items():                           # Path A evaluates a layer once per batch, like Path B
         grads[p + k] = v
       if want_t:
@@ -812,12 +814,13 @@ class OrcaEngine:
       ops.scatter_add_flagged(d_src, ids_src, self.pending, self._pos, d_upd)
       ops.scatter_add_flagged(d_nbr, ids_nbr, self.pending, self._pos, d_upd)
       gg = ops.gru_backward(self.params[p + "weight_ih"], self.params[p + "weight_hh"], self.params[p + "bias_ih"],
-                            self.params[p + "bias_hh"], wl, self.messages, self.memory, d_upd)
+                            self.params[p + "bias_hh"], wl, self.messages, self.memory, d_upd, pool=pool)
       for k, v in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), gg[:4]):
         grads[p + k] = v
     else:
       for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
         grads[p + k] = torch.zeros_like(self.params[p + k])
+    self._grad_pool_floats = pool.asked
     if want_t:
       grads["time_encoder.w.weight"] = d_time[0].view(D, 1)
       if "time_encoder.w.bias" in self.params:

@@ -274,7 +274,32 @@ def _tgat_inputs(kw, who):
   return inp, keep
 
 
-def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, **kw):
+class ZeroPool:
+  """One zero-filled buffer handed out in pieces: the gradient buffers of a training step (decoder, every attention
+  layer, GRU) start at zero, and one fill of their total is one launch instead of one per call.  take() falls back to
+  a fill of its own when the pool is used up; `asked` is what a step needed (the next pool's size)."""
+
+  def __init__(self, n, device):
+    self.buf = torch.zeros(int(n), dtype=torch.float32, device=device) if n > 0 else None
+    self.used = 0
+    self.asked = 0
+    self.device = device
+
+  def take(self, n):
+    n = int(n)
+    self.asked += n
+    if self.buf is not None and self.used + n <= self.buf.numel():
+      v = self.buf[self.used:self.used + n]
+      self.used += n
+      return v
+    return torch.zeros(n, dtype=torch.float32, device=self.device)
+
+
+def _zeros(n, dev, pool):
+  return pool.take(n) if pool is not None else torch.zeros(n, dtype=torch.float32, device=dev)
+
+
+def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=None, **kw):
   """orca_tgat_backward.  sd: the layer's raw parameters (keys TGAT_KEYS, fp32 on the device); kw: the fields of
   orca_tgat_inputs of the forward call (mask = the mask BEFORE the forward).  Returns (grads: dict like sd,
   d_src [Q,D], d_nbr [Q*K,D], d_src_time, d_nbr_time, d_time_w, d_time_b) -- the time entries that do not apply
@@ -283,7 +308,7 @@ def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, **kw):
   ps = [sd[k].detach().to(device=dev, dtype=torch.float32).contiguous() for k in TGAT_KEYS]
   gather = kw.get("dt") is not None
   sizes = [p.numel() for p in ps] + ([D, D] if gather and want_time_param_grads else [])
-  flat = torch.zeros(sum(-(-n // 64) * 64 for n in sizes), dtype=torch.float32, device=dev)   # one fill for all of them
+  flat = _zeros(sum(-(-n // 64) * 64 for n in sizes), dev, pool)   # one fill for all of them (pool: for the whole step)
   views, o = [], 0
   for n in sizes:
     views.append(flat[o:o + n])
@@ -329,12 +354,12 @@ def gru_pack(weight_ih, weight_hh, bias_ih, bias_hh, device, blob=None):
   return blob
 
 
-def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_inputs=False):
+def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_inputs=False, pool=None):
   """orca_gru_backward.  ids int32 [n] or None (dense rows).  Returns (g_weight_ih, g_weight_hh, g_bias_ih,
   g_bias_hh, d_x, d_h) -- the last two None unless want_inputs."""
   dev = d_out.device
   ps = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
-  flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in ps), dtype=torch.float32, device=dev)    # one fill for the four
+  flat = _zeros(sum(-(-p.numel() // 64) * 64 for p in ps), dev, pool)    # one fill for the four
   gs, o = [], 0
   for p in ps:
     gs.append(flat[o:o + p.numel()].view(p.shape))
@@ -454,14 +479,14 @@ def scatter_rows(table, ids, x):
         "orca_scatter_rows")
 
 
-def decoder_train(emb, fc1_w, fc1_b, fc2_w, fc2_b, want_prob=False):
+def decoder_train(emb, fc1_w, fc1_b, fc2_w, fc2_b, want_prob=False, pool=None):
   """orca_decoder_train: link decoder + BCE loss of a training step, forward and backward.  emb [3*bs, D] = embeddings
   of [src; dst; neg].  Returns (loss [1], d_emb [3*bs, D], grads {fc1.weight, fc1.bias, fc2.weight, fc2.bias}, prob
   [2*bs] or None)."""
   dev = emb.device
   bs = emb.shape[0] // 3
   ps = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in (fc1_w, fc1_b, fc2_w, fc2_b)]
-  flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in ps) + 64, dtype=torch.float32, device=dev)
+  flat = _zeros(sum(-(-p.numel() // 64) * 64 for p in ps) + 64, dev, pool)
   gs, o = [], 0
   for p in ps:
     gs.append(flat[o:o + p.numel()].view(p.shape))
