@@ -214,25 +214,38 @@ __global__ __launch_bounds__(256) void k_sgemm_rows(GemmGroup grp) {
     bcol[j] = B_KFAST ? g.B + (int64_t)nc * g.sbn + 4 * kq : g.B + (int64_t)(4 * kq) * g.sbk + nc;
   }
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto load_a = [&](int k0) { return k0 + 4 * kq < g.K ? *reinterpret_cast<const f32x4*>(arow + k0) : zero4; };
-  auto load_b = [&](int j, int k0) {
-    if (!nok[j] || k0 + 4 * kq >= g.K) return zero4;
-    if (B_KFAST) return *reinterpret_cast<const f32x4*>(bcol[j] + k0);
-    const float* b = bcol[j] + (int64_t)k0 * g.sbk;
-    return f32x4{b[0], b[g.sbk], b[2 * g.sbk], b[3 * g.sbk]};
+  // Loads are unconditional from clamped addresses and masked by a multiplication (the data is finite): behind a
+  // select the compiler puts the load under a branch, and a load behind a branch is waited for where it is issued.
+  // The next block's operands are requested before the current block's MFMAs and pinned there (sched_barrier).
+  const float nf0 = nok[0] ? 1.f : 0.f, nf1 = nok[1] ? 1.f : 0.f;
+  struct Ops { f32x4 a, b0, b1; };
+  auto load = [&](int k0) {
+    Ops o;
+    const int kc = k0 + 4 * kq < g.K ? k0 : 0;
+    o.a = *reinterpret_cast<const f32x4*>(arow + kc);
+    if (B_KFAST) {
+      o.b0 = *reinterpret_cast<const f32x4*>(bcol[0] + kc);
+      o.b1 = *reinterpret_cast<const f32x4*>(bcol[1] + kc);
+    } else {
+      const float* p0 = bcol[0] + (int64_t)kc * g.sbk;
+      const float* p1 = bcol[1] + (int64_t)kc * g.sbk;
+      o.b0 = f32x4{p0[0], p0[g.sbk], p0[2 * g.sbk], p0[3 * g.sbk]};
+      o.b1 = f32x4{p1[0], p1[g.sbk], p1[2 * g.sbk], p1[3 * g.sbk]};
+    }
+    return o;
   };
-  // (four blocks per step with twelve loads in flight measured no faster, and slower where its 116-170 VGPRs cost
-  // occupancy: these launches are not bound by the latency of their own load chain)
-  f32x4 a = load_a(0), b0 = load_b(0, 0), b1 = load_b(1, 0);
+  Ops raw = load(0);
   for (int k0 = 0; k0 < g.K; k0 += 16) {
-    const f32x4 an = load_a(k0 + 16), b0n = load_b(0, k0 + 16), b1n = load_b(1, k0 + 16);   // (past K: zeros, no loads)
+    const float kf = k0 + 4 * kq < g.K ? 1.f : 0.f;
+    const f32x4 a = raw.a * kf, b0 = raw.b0 * nf0, b1 = raw.b1 * nf1;      // (the wait for this block's operands)
+    raw = load(k0 + 16);                                                      // (past K: the clamped block, unused)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], acc[1], 0, 0, 0);
     }
-    a = an; b0 = b0n; b1 = b1n;
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j)
