@@ -604,17 +604,20 @@ __device__ __forceinline__ void load_key_rows(KeyRows& R, KeyTimes& T, const orc
       const int ov = __builtin_amdgcn_readlane(S.ovl, j0 + j);
       const float* np = (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D;
       const float* ep = in.edge_table + (int64_t)er * d_e;
+      // Columns past the row's width load a clamped (finite) element instead of being skipped: a lane-conditional load
+      // is a branch, and behind a branch every load is waited for where it is issued -- the ten slots became ten
+      // dependent round trips.  The surplus values meet zero weights (q~ is zero there) and are never stored.
       R.na[j] = np[lane];
-      R.nb[j] = c1 < D ? np[c1] : 0.f;
+      R.nb[j] = np[c1 < D ? c1 : 0];
 #pragma unroll
       for (int i = 0; i < MAXE; ++i) {
         const int c = lane + 64 * i;
-        R.e[j][i] = c < d_e ? ep[c] : 0.f;
+        R.e[j][i] = ep[c < d_e ? c : 0];
       }
       if (!in.dt) {     // dense boundary: time features are given
         const float* tp = in.nbr_time + (q * K + j0 + j) * D;
         T.ta[j] = tp[lane];
-        T.tb[j] = c1 < D ? tp[c1] : 0.f;
+        T.tb[j] = tp[c1 < D ? c1 : 0];
       }
     } else {
       R.na[j] = R.nb[j] = 0.f;
@@ -630,14 +633,15 @@ __device__ __forceinline__ void encode_key_times(KeyTimes& T, const orca_tgat_in
                                                  int K, int lane) {
   if (!in.dt) return;
   const int c1 = lane + 64;
+  const int cb = c1 < D ? c1 : 0;      // (lanes past the width compute a surplus value: no lane-conditional code)
   const float wa = in.time_w[lane], ba = in.time_b[lane];
-  const float wb = c1 < D ? in.time_w[c1] : 0.f, bb = c1 < D ? in.time_b[c1] : 0.f;
+  const float wb = in.time_w[cb], bb = in.time_b[cb];
 #pragma unroll
   for (int j = 0; j < KC; ++j) {
     if (j0 + j < K) {
       const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.dt), j0 + j));
       T.ta[j] = orca_cosf(orca_time_arg(d, wa, ba));
-      T.tb[j] = c1 < D ? orca_cosf(orca_time_arg(d, wb, bb)) : 0.f;
+      T.tb[j] = orca_cosf(orca_time_arg(d, wb, bb));
     } else {
       T.ta[j] = T.tb[j] = 0.f;
     }
@@ -762,10 +766,22 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   float sa = 0.f, sb = 0.f, sta = 0.f, stb = 0.f;
   if (live_q) {
     const int64_t row = in.src_idx ? (int64_t)in.src_idx[q] : q;
-    const float* tab = (in.src_flags && in.src_flags[row]) ? in.src_overlay : in.src_table;
-    sa = tab[row * D + lane];
-    sb = c1 < D ? tab[row * D + c1] : 0.f;
-    if (side.persist_memory && q < side.persist_n && tab == in.src_overlay) {   // fused memory persist (common.h)
+    const int cb = c1 < D ? c1 : 0;               // (column c1 is stored only where c1 < D)
+    bool from_overlay = false;
+    if (in.src_flags) {
+      // the flag and BOTH candidate rows are requested together and blended bit-wise afterwards: flag -> table -> row is
+      // one dependent round trip more on the critical path of this stage
+      const unsigned m = in.src_flags[row] ? ~0u : 0u;
+      const float ta_ = in.src_table[row * D + lane], tb_ = in.src_table[row * D + cb];
+      const float oa_ = in.src_overlay[row * D + lane], ob_ = in.src_overlay[row * D + cb];
+      sa = __uint_as_float((__float_as_uint(oa_) & m) | (__float_as_uint(ta_) & ~m));
+      sb = __uint_as_float((__float_as_uint(ob_) & m) | (__float_as_uint(tb_) & ~m));
+      from_overlay = m != 0u;
+    } else {
+      sa = in.src_table[row * D + lane];
+      sb = in.src_table[row * D + cb];
+    }
+    if (side.persist_memory && q < side.persist_n && from_overlay) {   // fused memory persist (common.h)
       side.persist_memory[row * D + lane] = sa;
       if (c1 < D) side.persist_memory[row * D + c1] = sb;
       if (lane == 0) side.persist_last_update[row] = side.persist_msg_ts[row];
