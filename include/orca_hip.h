@@ -198,6 +198,18 @@ int orca_tgat_backward(const orca_tgat_params* params, int d_e, const orca_tgat_
                        float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b, float* workspace,
                        void* stream);
 
+/* A forward call that keeps what the backward would otherwise recompute (the attention core: q~, the softmax weights,
+ * the weighted key sums; train.py:225-237 keeps the same tensors alive in the autograd graph): `saved` is
+ * orca_tgat_saved_floats(d_e, Q, K) floats, written by orca_tgat_forward_saving and read by orca_tgat_backward_saved,
+ * which is orca_tgat_backward without its recompute of those (same inputs, same results to rounding). */
+int64_t orca_tgat_saved_floats(int d_e, int64_t Q, int K);
+int orca_tgat_forward_saving(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
+                             float* out_weights, float* saved, void* stream);
+int orca_tgat_backward_saved(const orca_tgat_params* params, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
+                             const float* grad_out, const orca_tgat_params* grads, float* d_src, float* d_nbr,
+                             float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b, float* workspace,
+                             const float* saved, void* stream);
+
 /* orca_tgat_pack (+ orca_tgat_pack_gather when time_b != NULL) for n_layers layers at once: params[l] are layer l's raw
  * tensors, blobs[l] its blob.  The folds of all layers share launches (3 per two layers instead of 8 per layer): the
  * re-pack after every optimizer step (train.py:238) is otherwise two dozen latency-bound launches.

@@ -76,6 +76,9 @@ SIGNATURES = {
     "orca_gru_backward": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 11),
     "orca_tgat_backward_workspace_floats": (i64, [i32, i64, i32]),
     "orca_tgat_backward": (i32, [vp, i32, vp, i64, i32] + [vp] * 10),
+    "orca_tgat_backward_saved": (i32, [vp, i32, vp, i64, i32] + [vp] * 11),
+    "orca_tgat_saved_floats": (i64, [i32, i64, i32]),
+    "orca_tgat_forward_saving": (i32, [vp, i32, ctypes.POINTER(TgatInputs), i64, i32, vp, vp, vp, vp]),
     "orca_tgat_dropout_mask": (i32, [u64, i64, i64, i32, ctypes.c_float, vp, vp]),
     "orca_tgat_forward": (i32, [vp, i32, ctypes.POINTER(TgatInputs), i64, i32, vp, vp, vp]),
     "orca_debug_tgat_phase_clock": (i32, [vp]),

@@ -91,10 +91,29 @@ struct orca_tgat_side {
   float* store_msg_ts;
   uint8_t* store_pending;
   int32_t* zero_word;               // or null: a device counter this launch resets to 0
+  // or null (all five together): what the backward pass would otherwise recompute (orca_tgat_forward_saving) --
+  // q~ [Q, 2, kdim], the softmax weights before dropout [Q, 2, K], the weighted key sums x-bar [Q, 2, kdim], each
+  // head's sum of kept weights [Q, 2] and the all-padded marker [Q]
+  float* save_qt;
+  float* save_a;
+  float* save_xbar;
+  float* save_wsum;
+  float* save_invalid;
   float* src_rows_out;              // [Q, ORCA_D] or null: the (overlay-resolved) source row of every query, i.e. the
                                     // root's memory after its pending message is applied -- what a multi-rank step
                                     // all-gathers so that no rank has to redo the GRU of another rank's positives
 };
+// float offsets of the pieces of a `saved` buffer (orca_tgat_forward_saving -> orca_tgat_backward_saved)
+struct orca_saved_layout { int64_t qt, a, xbar, wsum, invalid, total; };
+static inline orca_saved_layout orca_saved(int d_e, int64_t Q, int K) {
+  const int64_t kdim = 2 * ORCA_D + d_e;
+  orca_saved_layout L{};
+  int64_t o = 0;
+  auto take = [&](int64_t per) { const int64_t r = o; o += (Q * per + 63) / 64 * 64; return r; };
+  L.qt = take(2 * kdim); L.a = take(2 * K); L.xbar = take(2 * kdim); L.wsum = take(2); L.invalid = take(1);
+  L.total = o;
+  return L;
+}
 int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
                            float* out_weights, const orca_tgat_side* side, void* stream);
 

@@ -900,6 +900,23 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       const float qt0a = xb0[tb + lane], qt1a = xb1[tb + lane];
       const float qt0b = c1 < D ? xb0[tb + c1] : 0.f, qt1b = c1 < D ? xb1[tb + c1] : 0.f;
       const float off = (lane & 32) ? xb1[kdim] : xb0[kdim];
+      // (orca_tgat_forward_saving) this wave's row of q~ / x-bar, LDS -> [Q][2][kdim], three 16-byte stores per lane
+      auto save_row = [&](float* dst) {
+        float* g = dst + q * 2 * kdim;
+        if ((kdim & 3) == 0) {
+          const int n4 = kdim >> 2;
+          for (int i = lane; i < 2 * n4; i += 64) {
+            const int h = i >= n4 ? 1 : 0, c = i - h * n4;
+            *reinterpret_cast<f32x4*>(g + h * kdim + 4 * c) = *reinterpret_cast<const f32x4*>(xb0 + h * KPS + 4 * c);
+          }
+        } else {
+          for (int i = lane; i < 2 * kdim; i += 64) {
+            const int h = i >= kdim ? 1 : 0, c = i - h * kdim;
+            g[h * kdim + c] = xb0[h * KPS + c];
+          }
+        }
+      };
+      if (side.save_qt) save_row(side.save_qt);      // wave-uniform
       // per-lane partial dot products of the chunk's rows with q~, reduced 20 at a time; afterwards the
       // lanes holder_lane(h, j) | {0,1} hold score(h, j0 + j)
       auto scores = [&]() {
@@ -934,6 +951,22 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       // an all-padded neighbourhood has attn = 0 (:52): its weights, hence x-bar, are zeroed (out_w too, below)
       const float inv = invalid ? 0.f : 1.0f / (half_sum(e0 + e1) * 0.5f);
       float a_c0 = e0 * inv, a_c1 = e1 * inv;            // attention weight of (head = lane>>5, slot hs [+KC])
+      if (side.save_a) {             // the softmax output itself, before dropout: [q][head][slot]
+        const int jj = lane < K ? (lane < KC ? lane : lane - KC) : 0;
+        int hl = 0;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) hl = (jj == j) ? holder_lane(0, j) : hl;
+        float w0 = __shfl(a_c0, hl, 64), w1 = __shfl(a_c0, hl + 32, 64);
+        if (K > KC) {
+          const float v0 = __shfl(a_c1, hl, 64), v1 = __shfl(a_c1, hl + 32, 64);
+          if (lane >= KC) { w0 = v0; w1 = v1; }
+        }
+        if (lane < K) {
+          side.save_a[(q * 2 + 0) * K + lane] = w0;
+          side.save_a[(q * 2 + 1) * K + lane] = w1;
+        }
+        if (lane == 0) side.save_invalid[q] = invalid ? 1.f : 0.f;
+      }
       float wsum = invalid ? 0.f : 1.f;                  // sum of this head's weights: 1 without dropout
       if (in.dropout_p > 0.f) {                          // nn.MultiheadAttention's dropout on the softmax output
         const float sc_ = 1.0f / (1.0f - in.dropout_p);
@@ -989,6 +1022,10 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       // constant columns of the tail: each head's value-bias term times its weight sum, the out-projection bias once
       const float ws1 = __shfl(wsum, 32, 64);
       if (lane == 0) { xb0[kdim] = wsum; xb1[kdim] = ws1; xb0[2 * KPS + D] = invalid ? 0.f : 1.f; }
+      if (side.save_xbar) {
+        if (lane == 0) { side.save_wsum[q * 2] = wsum; side.save_wsum[q * 2 + 1] = ws1; }
+        save_row(side.save_xbar);      // (same wave wrote the row: LDS operations of a wave complete in order)
+      }
     }
   }
   // ---- P4: h1 = relu(F [x-bar_0 | x-bar_1 | src] + b1), F = the folded value map / out-proj / fc1 ----------
@@ -1079,6 +1116,24 @@ ORCA_API int orca_tgat_dropout_mask(uint64_t seed, int64_t q0, int64_t Q, int K,
   k_dropout_mask<<<(unsigned)ceil_div64(Q * ORCA_HEADS * K, 256), 256, 0, (hipStream_t)stream>>>(seed, q0, Q, K, p, mult);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
+}
+
+ORCA_API int64_t orca_tgat_saved_floats(int d_e, int64_t Q, int K) {
+  if (d_e < 1 || d_e > ORCA_MAX_DE || Q < 0 || K < 1 || K > ORCA_MAX_K) return -1;
+  return orca_saved(d_e, Q, K).total;
+}
+ORCA_API int orca_tgat_forward_saving(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
+                                      float* out_weights, float* saved, void* stream) {
+  ORCA_REQUIRE(saved, "orca_tgat_forward_saving: null buffer");
+  ORCA_REQUIRE(d_e >= 1 && d_e <= ORCA_MAX_DE && K >= 1 && K <= ORCA_MAX_K && Q >= 0, "orca_tgat_forward_saving: bad sizes");
+  const orca_saved_layout L = orca_saved(d_e, Q, K);
+  orca_tgat_side side{};
+  side.save_qt = saved + L.qt;
+  side.save_a = saved + L.a;
+  side.save_xbar = saved + L.xbar;
+  side.save_wsum = saved + L.wsum;
+  side.save_invalid = saved + L.invalid;
+  return orca_tgat_forward_side(blob, d_e, in, Q, K, out, out_weights, &side, stream);
 }
 
 ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,

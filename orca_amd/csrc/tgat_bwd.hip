@@ -1298,6 +1298,7 @@ __global__ __launch_bounds__(CH_T) void k_chain_a(orca_tgat_inputs in, int64_t Q
     QS[m * CH_S2 + n] = v;
     if (m0 + m < Q) qs[(m0 + m) * QD + n] = v;
   }, [&](Frag& g) { g2.load(g, wave, 0); });
+  if (!qt) return;       // (block-uniform: the forward kept q~, orca_tgat_backward_saved)
   g2.run(f, QS, CH_S2, D, P, [&](int h, int m, int n, float v) {
     if (m0 + m < Q) qt[(m0 + m) * 2 * KD + h * KD + n] = v;
   }, [](Frag&) {});
@@ -1522,10 +1523,32 @@ ORCA_API int64_t orca_tgat_backward_workspace_floats(int d_e, int64_t Q, int K) 
   return ws_layout(d_e, Q, K).total;
 }
 
+namespace {
+int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
+                       const float* grad_out, const orca_tgat_params* G, float* d_src, float* d_nbr,
+                       float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b,
+                       float* workspace, const float* saved, void* stream_);
+}
 ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
                                 const float* grad_out, const orca_tgat_params* G, float* d_src, float* d_nbr,
                                 float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b,
                                 float* workspace, void* stream_) {
+  return tgat_backward_impl(P, d_e, in, Q, K, grad_out, G, d_src, d_nbr, d_src_time, d_nbr_time, d_time_w, d_time_b, workspace,
+                            nullptr, stream_);
+}
+ORCA_API int orca_tgat_backward_saved(const orca_tgat_params* P, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
+                                      const float* grad_out, const orca_tgat_params* G, float* d_src, float* d_nbr,
+                                      float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b,
+                                      float* workspace, const float* saved, void* stream_) {
+  ORCA_REQUIRE(saved, "orca_tgat_backward_saved: null buffer");
+  return tgat_backward_impl(P, d_e, in, Q, K, grad_out, G, d_src, d_nbr, d_src_time, d_nbr_time, d_time_w, d_time_b, workspace,
+                            saved, stream_);
+}
+namespace {
+int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
+                       const float* grad_out, const orca_tgat_params* G, float* d_src, float* d_nbr,
+                       float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b,
+                       float* workspace, const float* saved, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   ORCA_REQUIRE(Q >= 0, "orca_tgat_backward: negative Q");
   if (Q == 0) return ORCA_OK;
@@ -1555,6 +1578,11 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
         *dxq = W + w.dxq, *tgrad = W + w.tgrad, *invalid = W + w.invalid, *wsum = W + w.wsum, *dsum = W + w.dsum, *part = W + w.part, *wpack = W + w.wpack;
   const bool drop = in->dropout_p > 0.f;
   ORCA_REQUIRE(in->dropout_p >= 0.f && in->dropout_p < 1.f, "orca_tgat_backward: dropout_p=%g outside [0,1)", (double)in->dropout_p);
+  if (saved) {     // what the forward kept (orca_tgat_forward_saving): neither q~ nor the attention core is recomputed
+    const orca_saved_layout SL = orca_saved(d_e, Q, K);
+    float* sv = const_cast<float*>(saved);      // (read only below)
+    qt = sv + SL.qt; a = sv + SL.a; xbar = sv + SL.xbar; wsum = sv + SL.wsum; invalid = sv + SL.invalid;
+  }
   const unsigned qb = (unsigned)ceil_div64(Q, 4);
   int rc = ORCA_OK;
   auto ew = [&](int64_t n) { return (unsigned)ceil_div64(n, 256); };
@@ -1597,18 +1625,20 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
       pk.total = CW::total;
       k_chain_pack<<<(unsigned)ceil_div64((int64_t)CW::total * 64, 256), 256, 0, s>>>(pk, wpack);
     }
-    k_chain_a<QD + 172><<<tiles, CH_T, CL::A_FLOATS * sizeof(float), s>>>(*in, Q, wpack, P->in_b, xq, x1, qs, qt);
+    k_chain_a<QD + 172><<<tiles, CH_T, CL::A_FLOATS * sizeof(float), s>>>(*in, Q, wpack, P->in_b, xq, x1, qs, saved ? nullptr : qt);
   } else {
     k_bwd_prep<<<qb, 256, 0, s>>>(*in, Q, xq, x1);
     // qs = 0.1 (xq Wq^T + bq)                                                    (scaling: head_dim^-0.5)
     rc |= sgemm(s, M, QD, QD, xq, QD, 1, P->q_w, 1, QD, qs, QD, 1, P->in_b, 0.1f, false, false);
-    // q~_h = qs_h Wk_h   [Q,100] x [100,kdim], both heads in one launch
-    OrcaGemm g[2];
-    for (int h = 0; h < 2; ++h)
-      g[h] = G1(M, kdim, D, qs + h * D, QD, 1, P->k_w + (int64_t)h * D * kdim, kdim, 1, qt + h * kdim, 2 * kdim, 1, nullptr, 1.f);
-    rc |= orca_sgemm_group(s, g, 2, nullptr);
+    if (!saved) {   // q~_h = qs_h Wk_h   [Q,100] x [100,kdim], both heads in one launch
+      OrcaGemm g[2];
+      for (int h = 0; h < 2; ++h)
+        g[h] = G1(M, kdim, D, qs + h * D, QD, 1, P->k_w + (int64_t)h * D * kdim, kdim, 1, qt + h * kdim, 2 * kdim, 1, nullptr, 1.f);
+      rc |= orca_sgemm_group(s, g, 2, nullptr);
+    }
   }
-  if (K <= 10) k_bwd_attn_fwd<10><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
+  if (saved) {
+  } else if (K <= 10) k_bwd_attn_fwd<10><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
   else k_bwd_attn_fwd<ORCA_MAX_K><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
   if (chain) {
     const ChainB c{wpack, P->in_b + 2 * QD, P->o_b, P->fc1_b, P->fc2_b, P->ln_w,
@@ -1719,3 +1749,4 @@ ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_t
   }
   return ORCA_OK;
 }
+}  // namespace

@@ -472,7 +472,7 @@ class OrcaEngine:
     return dict(dropout_p=self.dropout, dropout_q0=int(q0),
                 dropout_seed=(self.seed * 0x2545F4914F6CDD1D + self.batch_counter * 0x9E3779B97F4A7C15 + layer) & 0xFFFFFFFFFFFFFFFF)
 
-  def _attend(self, layer, Q, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr_idx, from_memory, drop=None):
+  def _attend(self, layer, Q, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr_idx, from_memory, drop=None, save=None):
     """embedding_module.py:318-329 (aggregate) fused with the gathers of :123,133,172-174 and the
     time encodings of :126,132."""
     kw = dict(src_table=src_table, src_idx=src_idx, nbr_table=nbr_table, nbr_idx=nbr_idx, nbr_ids=nbr,
@@ -482,7 +482,7 @@ class OrcaEngine:
       kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
     if drop:
       kw.update(drop)
-    out, _ = self._timed("tgat_forward", ops.tgat_forward, self.att_blobs[layer - 1], self.d_e, Q, self.K, **kw)
+    out, _ = self._timed("tgat_forward", ops.tgat_forward, self.att_blobs[layer - 1], self.d_e, Q, self.K, save=save, **kw)
     return out
 
   # -------------------------------------------------------------------------------------------
@@ -718,8 +718,10 @@ class OrcaEngine:
       cnt_ready = self._fetch_count()
       my32 = my_nodes.to(torch.int32)
       dk = self._dropout_kw(1, lo)
-      emb = self._attend(1, n, nbr, eid, dt, True, self.memory, my32, self.memory, nbr, True, drop=dk)
-      steps.append((1, n, (nbr, eid, dt), dict(src_table=self.memory, src_idx=my32, nbr_table=self.memory, nbr_idx=nbr, **dk),
+      sv = []       # (the forward keeps q~, the softmax weights and the key sums for the backward: ops.tgat_forward(save=))
+      emb = self._attend(1, n, nbr, eid, dt, True, self.memory, my32, self.memory, nbr, True, drop=dk, save=sv)
+      steps.append((1, n, (nbr, eid, dt), dict(src_table=self.memory, src_idx=my32, nbr_table=self.memory, nbr_idx=nbr,
+                                               saved=sv[0] if sv else None, **dk),
                     (my_nodes, nbr.view(-1))))
       for layer in range(2, self.L + 1):
         full = self._all_gather_rows(emb, Q, per)
@@ -734,8 +736,10 @@ class OrcaEngine:
           self._wpos[nodes] = (self.slot[nodes] - ep).to(torch.int32)
         prev = emb
         dk = self._dropout_kw(layer, lo)
-        emb = self._attend(layer, n, nbr, eid, dt, True, prev, None, self.hist[layer - 2], nbr, False, drop=dk)
-        steps.append((layer, n, (nbr, eid, dt), dict(src_table=prev, nbr_table=self.hist[layer - 2], nbr_idx=nbr, **dk), None))
+        sv = []
+        emb = self._attend(layer, n, nbr, eid, dt, True, prev, None, self.hist[layer - 2], nbr, False, drop=dk, save=sv)
+        steps.append((layer, n, (nbr, eid, dt), dict(src_table=prev, nbr_table=self.hist[layer - 2], nbr_idx=nbr,
+                                                     saved=sv[0] if sv else None, **dk), None))
     else:                                                # embedding_module.py:116-147
       f_nodes, f_ts, samples = [my_nodes], [t3[lo:hi]], []
       for _ in range(self.L):
@@ -753,14 +757,17 @@ class OrcaEngine:
         if layer == 1:
           i32 = f_nodes[lvl].to(torch.int32)
           dk = self._dropout_kw(1, 0)      # (the exact recursion numbers its frontier per rank)
-          emb = self._attend(1, m, nbr, eid, dt, True, self.memory, i32, self.memory, nbr, True, drop=dk)
-          steps.append((1, m, samples[lvl], dict(src_table=self.memory, src_idx=i32, nbr_table=self.memory, nbr_idx=nbr, **dk),
+          sv = []
+          emb = self._attend(1, m, nbr, eid, dt, True, self.memory, i32, self.memory, nbr, True, drop=dk, save=sv)
+          steps.append((1, m, samples[lvl], dict(src_table=self.memory, src_idx=i32, nbr_table=self.memory, nbr_idx=nbr,
+                                                 saved=sv[0] if sv else None, **dk),
                         (f_nodes[lvl], nbr.view(-1))))
         else:
           prev = emb
           dk = self._dropout_kw(layer, 0)
-          emb = self._attend(layer, m, nbr, eid, dt, True, prev, None, prev[m:], None, False, drop=dk)
-          steps.append((layer, m, samples[lvl], dict(src_table=prev, nbr_table=prev[m:], **dk), "cat"))
+          sv = []
+          emb = self._attend(layer, m, nbr, eid, dt, True, prev, None, prev[m:], None, False, drop=dk, save=sv)
+          steps.append((layer, m, samples[lvl], dict(src_table=prev, nbr_table=prev[m:], saved=sv[0] if sv else None, **dk), "cat"))
     if out is None:
       out = self._all_gather_rows(emb, Q, per)
     # ---- link decoder + loss, forward and backward (tgn_model.py:150-157, train.py:231-233): orca_decoder_train ----
@@ -780,9 +787,10 @@ class OrcaEngine:
       sd = {k[len(p):]: v for k, v in self.params.items() if k.startswith(p)}
       kw = dict(nbr_ids=nbr, edge_table=self.edge_feats, edge_idx=eid, dt=dt, time_w=self.time_w, time_b=self.time_b)
       kw.update(tables)
+      saved = kw.pop("saved", None)
       if layer == 1:
         kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
-      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, m, K, d, want_time_param_grads=want_t, pool=pool, **kw)
+      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, m, K, d, want_time_param_grads=want_t, pool=pool, saved=saved, **kw)
       for k, v in g.items():                           # Path A evaluates a layer once per batch, like Path B
         grads[p + k] = v
       if want_t:

@@ -230,14 +230,24 @@ def tgat_pack_layers(sds, d_e, device, blobs=None, time_b=None):
   return list(blobs)
 
 
-def tgat_forward(blob, d_e, Q, K, out=None, want_weights=False, **kw):
+def tgat_forward(blob, d_e, Q, K, out=None, want_weights=False, save=None, **kw):
   """orca_tgat_forward.  kw: the fields of orca_tgat_inputs (tensors or None; q_folded: bool; dropout_p, dropout_seed,
-  dropout_q0: attention-weight dropout, off by default)."""
+  dropout_q0: attention-weight dropout, off by default).  save: a one-element list that receives the buffer of
+  orca_tgat_forward_saving (what tgat_backward(saved=...) then does not recompute)."""
   inp, keep = _tgat_inputs(kw, "tgat_forward")
   dev = blob.device
   if out is None:
     out = torch.empty((Q, D), dtype=torch.float32, device=dev)
   w = torch.empty((Q, K), dtype=torch.float32, device=dev) if want_weights else None
+  if save is not None and Q > 0:
+    n = _lib.load().orca_tgat_saved_floats(int(d_e), int(Q), int(K))
+    if n < 0:
+      raise ValueError(f"tgat_forward: unsupported sizes d_e={d_e} K={K}")
+    buf = torch.empty(n, dtype=torch.float32, device=dev)
+    check(_lib.load().orca_tgat_forward_saving(ptr(blob), int(d_e), ctypes.byref(inp), int(Q), int(K), ptr(out), ptr(w),
+                                               ptr(buf), stream()), "orca_tgat_forward_saving")
+    save.append(buf)
+    return out, w
   check(_lib.load().orca_tgat_forward(ptr(blob), int(d_e), ctypes.byref(inp), int(Q), int(K), ptr(out), ptr(w),
                                       stream()), "orca_tgat_forward")
   return out, w
@@ -299,7 +309,7 @@ def _zeros(n, dev, pool):
   return pool.take(n) if pool is not None else torch.zeros(n, dtype=torch.float32, device=dev)
 
 
-def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=None, **kw):
+def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=None, saved=None, **kw):
   """orca_tgat_backward.  sd: the layer's raw parameters (keys TGAT_KEYS, fp32 on the device); kw: the fields of
   orca_tgat_inputs of the forward call (mask = the mask BEFORE the forward).  Returns (grads: dict like sd,
   d_src [Q,D], d_nbr [Q*K,D], d_src_time, d_nbr_time, d_time_w, d_time_b) -- the time entries that do not apply
@@ -333,9 +343,14 @@ def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=Non
   else:
     d_st = torch.empty((Q, D), dtype=torch.float32, device=dev)
     d_nt = torch.empty((Q * K, D), dtype=torch.float32, device=dev)
-  check(_lib.load().orca_tgat_backward(ctypes.byref(P), int(d_e), ctypes.byref(inp), int(Q), int(K), ptr(go),
-                                       ctypes.byref(G), ptr(d_src), ptr(d_nbr), ptr(d_st), ptr(d_nt), ptr(d_tw),
-                                       ptr(d_tb), ptr(wsp), stream()), "orca_tgat_backward")
+  if saved is not None:
+    check(_lib.load().orca_tgat_backward_saved(ctypes.byref(P), int(d_e), ctypes.byref(inp), int(Q), int(K), ptr(go),
+                                               ctypes.byref(G), ptr(d_src), ptr(d_nbr), ptr(d_st), ptr(d_nt), ptr(d_tw),
+                                               ptr(d_tb), ptr(wsp), ptr(saved), stream()), "orca_tgat_backward_saved")
+  else:
+    check(_lib.load().orca_tgat_backward(ctypes.byref(P), int(d_e), ctypes.byref(inp), int(Q), int(K), ptr(go),
+                                         ctypes.byref(G), ptr(d_src), ptr(d_nbr), ptr(d_st), ptr(d_nt), ptr(d_tw),
+                                         ptr(d_tb), ptr(wsp), stream()), "orca_tgat_backward")
   return dict(zip(TGAT_KEYS, gs)), d_src, d_nbr, d_st, d_nt, d_tw, d_tb
 
 

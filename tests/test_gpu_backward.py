@@ -109,23 +109,34 @@ def test_attention_backward_gather_mode(ops, golden, d_e, K, Q):
   # product
   _t = lambda a: torch.from_numpy(a).to(DEV)
   dsd = {k: v.to(DEV) for k, v in sd.items()}
-  grads, d_src, d_nbr, d_st, d_nt, d_tw, d_tb = ops.tgat_backward(
-      dsd, d_e, Q, K, R.to(DEV), want_time_param_grads=True, src_table=_t(table), src_idx=_t(nodes),
-      src_overlay=_t(overlay), src_flags=_t(flags), nbr_table=_t(table), nbr_idx=_t(nbr), nbr_overlay=_t(overlay),
-      nbr_flags=_t(flags), nbr_ids=_t(nbr), edge_table=_t(edge_feats), edge_idx=_t(eid), dt=_t(dt),
-      time_w=w_time.to(DEV), time_b=b_time.to(DEV))
-  assert d_st is None and d_nt is None
-  for k in sd:
-    ref = P[k].grad.numpy().copy()
-    if k == "multi_head_target.in_proj_bias":
-      ref[200:400] = 0.0
-    assert_close_fp32(grads[k].cpu().numpy(), ref, TOL, "gather grad " + k)
-  assert_close_fp32(d_src.cpu().numpy(), src_rows.grad.numpy(), TOL, "gather d_src")
-  assert_close_fp32(d_nbr.view(Q, K, 100).cpu().numpy(), nbr_rows.grad.numpy(), TOL, "gather d_nbr")
-  assert_close_fp32(d_tw.cpu().numpy(), wt.grad.numpy(), TOL, "gather d_time_w")
-  assert_close_fp32(d_tb.cpu().numpy(), bt.grad.numpy(), TOL, "gather d_time_b")
-  # padded slots get exactly zero
-  assert float(d_nbr.view(Q, K, 100)[torch.from_numpy(nbr == 0).to(DEV)].abs().max()) == 0.0
+  inputs = dict(src_table=_t(table), src_idx=_t(nodes), src_overlay=_t(overlay), src_flags=_t(flags), nbr_table=_t(table),
+                nbr_idx=_t(nbr), nbr_overlay=_t(overlay), nbr_flags=_t(flags), nbr_ids=_t(nbr), edge_table=_t(edge_feats),
+                edge_idx=_t(eid), dt=_t(dt), time_w=w_time.to(DEV), time_b=b_time.to(DEV))
+  # twice: the backward recomputing the attention core, and reading what a forward call kept for it
+  # (orca_tgat_forward_saving -> orca_tgat_backward_saved; with the q projection folded into the blob and without)
+  for mode in ("recompute", "saved folded", "saved"):
+    saved = None
+    if mode != "recompute":
+      folded = mode == "saved folded"
+      blob = ops.tgat_pack(dsd, d_e, DEV, time_b=b_time.to(DEV) if folded else None)
+      sv = []
+      got, _ = ops.tgat_forward(blob, d_e, Q, K, save=sv, q_folded=folded, **inputs)
+      assert_close_fp32(got.cpu().numpy(), out.detach().numpy(), TOL, mode + " forward")
+      saved = sv[0]
+    grads, d_src, d_nbr, d_st, d_nt, d_tw, d_tb = ops.tgat_backward(dsd, d_e, Q, K, R.to(DEV), want_time_param_grads=True,
+                                                                    saved=saved, **inputs)
+    assert d_st is None and d_nt is None
+    for k in sd:
+      ref = P[k].grad.numpy().copy()
+      if k == "multi_head_target.in_proj_bias":
+        ref[200:400] = 0.0
+      assert_close_fp32(grads[k].cpu().numpy(), ref, TOL, f"gather grad {k} ({mode})")
+    assert_close_fp32(d_src.cpu().numpy(), src_rows.grad.numpy(), TOL, f"gather d_src ({mode})")
+    assert_close_fp32(d_nbr.view(Q, K, 100).cpu().numpy(), nbr_rows.grad.numpy(), TOL, f"gather d_nbr ({mode})")
+    assert_close_fp32(d_tw.cpu().numpy(), wt.grad.numpy(), TOL, f"gather d_time_w ({mode})")
+    assert_close_fp32(d_tb.cpu().numpy(), bt.grad.numpy(), TOL, f"gather d_time_b ({mode})")
+    # padded slots get exactly zero
+    assert float(d_nbr.view(Q, K, 100)[torch.from_numpy(nbr == 0).to(DEV)].abs().max()) == 0.0
 
 
 def test_attention_backward_errors(ops, golden):
