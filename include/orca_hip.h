@@ -474,6 +474,20 @@ int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst,
 /* owner-computes step: after the xm all-gather, overlay[id] = row and pending[id] = 1 for every id any rank sent */
 int orca_engine_apply(orca_engine_t* e, void* stream);
 
+/* One whole batch step of Path C (modules/embedding_module.py:215-285: --reuse with --budget B; two layers, one rank)
+ * issued from C++ with no host round trip: roots -> their neighbours (nbr_top .. dt_top [3*bs*K]) -> the neighbours
+ * without a cached layer-1 embedding (embedding_module.py:200-212; `unc` [cap], *unc_count on the device) -> layer 1
+ * over [roots; uncached] (a launch sized for 3*bs + cap queries that evaluates 3*bs + *unc_count of them) -> history
+ * push, cache flags (history.py:25-30: the plan's ids when plan_n >= 0, else every evaluated id) -> layer 2 over the
+ * roots -> memory persist + raw-message store (tgn_model.py:127-145, order by `train`).  out [3*bs, ORCA_D].  Uses the
+ * tables and work buffers of the engine's descriptor (3*bs + cap <= q_max); cache_flag uint8 [n_nodes]; bitmap as in
+ * orca_find_uncached; tmax device double [1].  More uncached ids than `cap` set bit 1 of *err (device int, may be
+ * NULL): the step then evaluated only the first `cap` of them. */
+int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                            const double* ts, const int64_t* eidx, int64_t bs, int train, const int64_t* plan,
+                            int64_t plan_n, uint8_t* cache_flag, uint32_t* bitmap, int64_t* unc, int64_t cap,
+                            int32_t* unc_count, double* tmax, int32_t* nbr_top, int32_t* eid_top, float* et_top,
+                            float* dt_top, float* out, int32_t* err, void* stream);
 /* Eager overlay.  While the state is "overlay complete" -- overlay[id] == GRU(messages[id], memory[id]) for every id
  * with a pending message, save those the last step stored -- a train-ordered orca_engine_begin over the whole
  * batch needs no per-batch work-list: it applies the GRU to the ids the previous step stored and nothing else.

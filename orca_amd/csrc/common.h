@@ -99,6 +99,8 @@ struct orca_tgat_side {
   float* save_xbar;
   float* save_wsum;
   float* save_invalid;
+  const int32_t* q_extra;           // or null: only the first q_base + *q_extra (<= Q) queries are evaluated -- a launch
+  int64_t q_base;                   // sized for a bound whose actual length is a device-side count (Path C's uncached set)
   float* src_rows_out;              // [Q, ORCA_D] or null: the (overlay-resolved) source row of every query, i.e. the
                                     // root's memory after its pending message is applied -- what a multi-rank step
                                     // all-gathers so that no rank has to redo the GRU of another rank's positives

@@ -780,6 +780,132 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
   return orca_tgat_forward_side(d.att_blob[layer - 1], d.d_e, &in, hi - lo, d.K, next + lo * ORCA_D, nullptr, &side, stream_);
 }
 
+// ---- Path C (modules/embedding_module.py:215-285, --reuse --budget B) issued from C++ without a host round trip ------
+namespace {
+// nodes = [src;dst;neg], qts = [t;t;t], nodes32 = the same ids; *tmax = max t (the time at which the uncached
+// neighbours are evaluated, embedding_module.py:256-259).  One workgroup.
+__global__ __launch_bounds__(1024) void k_budget_roots(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                                       const int64_t* __restrict__ neg, const double* __restrict__ ts,
+                                                       int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
+                                                       int32_t* __restrict__ nodes32, double* __restrict__ tmax) {
+  __shared__ double red[16];
+  double m = -1.0e300;
+  for (int64_t i = threadIdx.x; i < 3 * bs; i += blockDim.x) {
+    const int64_t b = i % bs;
+    const int64_t id = i < bs ? src[b] : i < 2 * bs ? dst[b] : neg[b];
+    const double t = ts[b];
+    nodes[i] = id;
+    nodes32[i] = (int32_t)id;
+    qts[i] = t;
+    m = t > m ? t : m;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const double v = __shfl_xor(m, o, 64); m = v > m ? v : m; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = red[w] > m ? red[w] : m;
+    *tmax = m;
+  }
+}
+// the evaluated set behind the roots: entries Q .. Q+cap-1 = the uncached ids (device count), then padding -- id -1 for
+// the lists that write state (every id-indexed kernel skips it), id 0 (the padding node) where a row is gathered
+__global__ void k_budget_cnodes(const int64_t* __restrict__ unc, const int32_t* __restrict__ count, int64_t cap, int64_t Q,
+                                const double* __restrict__ tmax, int64_t* __restrict__ nodes, int32_t* __restrict__ nodes32,
+                                double* __restrict__ qts, int32_t* __restrict__ err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && *count > cap && err) atomicOr(err, 2);        // more uncached neighbours than the launch bound
+  if (i >= cap) return;
+  const bool ok = i < *count;
+  const int64_t id = ok ? unc[i] : -1;
+  nodes[Q + i] = id;
+  nodes32[Q + i] = ok ? (int32_t)id : 0;
+  qts[Q + i] = *tmax;
+}
+}  // namespace
+
+ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                                     const double* ts, const int64_t* eidx, int64_t bs, int train,
+                                     const int64_t* plan, int64_t plan_n, uint8_t* cache_flag, uint32_t* bitmap,
+                                     int64_t* unc, int64_t cap, int32_t* unc_count, double* tmax,
+                                     int32_t* nbr_top, int32_t* eid_top, float* et_top, float* dt_top, float* out,
+                                     int32_t* err, void* stream_) {
+  ORCA_REQUIRE(e, "orca_engine_step_budget: null handle");
+  const orca_engine_desc& d = e->d;
+  hipStream_t s = (hipStream_t)stream_;
+  ORCA_REQUIRE(d.n_layers == 2 && d.world <= 1, "orca_engine_step_budget: two layers on one rank (others take the dispatched path)");
+  ORCA_REQUIRE(bs >= 0 && cap >= 1 && 3 * bs + cap <= d.q_max, "orca_engine_step_budget: 3*bs + cap = %lld exceeds q_max = %lld",
+               (long long)(3 * bs + cap), (long long)d.q_max);
+  if (bs == 0) return ORCA_OK;
+  ORCA_REQUIRE(src && dst && neg && ts && eidx && cache_flag && bitmap && unc && unc_count && tmax && nbr_top && eid_top &&
+               et_top && dt_top && out && d.csr && d.hist[0], "orca_engine_step_budget: null pointer");
+  const int64_t Q = 3 * bs, Qc = Q + cap;
+  const int K = d.K;
+#define STEP(expr) do { const int rc_ = (expr); if (rc_ != ORCA_OK) return rc_; } while (0)
+  // roots, their neighbours (the layer-2 keys), and which of those have no cached layer-1 embedding (:251)
+  (void)hipGetLastError();      // (a status left behind by an earlier runtime call is not this step's)
+  k_budget_roots<<<1, 1024, 0, s>>>(src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32, tmax);
+  ORCA_LAUNCH_CHECK();
+  STEP(orca_sample_recent(d.csr, d.nodes, d.qts, Q, K, nbr_top, eid_top, et_top, dt_top, nullptr, stream_));
+  STEP(orca_find_uncached(nbr_top, Q * K, d.nodes, Q, cache_flag, d.slot, take_epochs(e, 1), d.n_nodes, bitmap, unc, cap,
+                          unc_count, stream_));
+  k_budget_cnodes<<<(unsigned)ceil_div64(cap, 256), 256, 0, s>>>(unc, unc_count, cap, Q, tmax, d.nodes, d.nodes32, d.qts, err);
+  ORCA_LAUNCH_CHECK();
+  // layer 1 over [roots; uncached]: neighbours, updated memory of what they read (:224-246), attention
+  STEP(orca_sample_recent(d.csr, d.nodes, d.qts, Qc, K, d.nbr, d.eid, d.et, d.dt, nullptr, stream_));
+  orca_tgat_inputs in{};
+  in.src_table = d.memory; in.src_idx = d.nodes32;
+  in.nbr_table = d.memory; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;
+  in.edge_table = d.edge_feats; in.edge_idx = d.eid;
+  in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b; in.q_folded = d.att_q_folded;
+  if (train) {
+    STEP(orca_worklist_build(d.nbr, Qc * K, d.nodes, Qc, d.pending, d.slot, take_epochs(e, Qc * (K + 1)), d.n_nodes,
+                             d.worklist, d.count, stream_));
+    const int64_t bound = Qc * (K + 1) < d.n_nodes ? Qc * (K + 1) : d.n_nodes;
+    STEP(orca_gru_update(d.gru_blob, 300 + d.d_e, d.worklist, bound, d.count, d.messages, d.memory, d.overlay, nullptr,
+                         nullptr, stream_));
+    in.src_overlay = d.overlay; in.src_flags = d.pending; in.nbr_overlay = d.overlay; in.nbr_flags = d.pending;
+  }
+  float* comb = d.emb[0];
+  {
+    orca_tgat_side side{};
+    side.q_extra = unc_count;
+    side.q_base = Q;
+    STEP(orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, Qc, K, comb, nullptr, &side, stream_));
+  }
+  // push them (last occurrence wins, H7) and move the cache flags on (history.py:25-30)
+  STEP(orca_history_push(d.hist[0], comb, d.nodes, Qc, d.slot, take_epochs(e, Qc), d.n_nodes, stream_));
+  if (plan_n >= 0) {
+    STEP(orca_fill_u8(cache_flag, d.n_nodes, 0, stream_));
+    if (plan_n > 0) STEP(orca_set_flags(cache_flag, plan, nullptr, plan_n, nullptr, 1, d.n_nodes, stream_));
+  } else {
+    STEP(orca_set_flags(cache_flag, d.nodes, nullptr, Qc, nullptr, 1, d.n_nodes, stream_));
+  }
+  // layer 2 over the roots: their own layer-1 rows, neighbours pulled from the history table (:273-285)
+  orca_tgat_inputs in2{};
+  in2.src_table = comb;
+  in2.nbr_table = d.hist[0]; in2.nbr_idx = nbr_top; in2.nbr_ids = nbr_top;
+  in2.edge_table = d.edge_feats; in2.edge_idx = eid_top;
+  in2.dt = dt_top; in2.time_w = d.time_w; in2.time_b = d.time_b; in2.q_folded = d.att_q_folded;
+  STEP(orca_tgat_forward_side(d.att_blob[1], d.d_e, &in2, Q, K, out, nullptr, nullptr, stream_));
+  // the state moves on (tgn_model.py:127-145): persist the positives' memory, store the raw messages -- in that order
+  // when training, the other way round in evaluation
+  auto persist = [&]() -> int {
+    STEP(orca_worklist_build(nullptr, 0, d.nodes, 2 * bs, d.pending, d.slot, take_epochs(e, 2 * bs), d.n_nodes, d.worklist,
+                             d.count, stream_));
+    const int64_t bound = 2 * bs < d.n_nodes ? 2 * bs : d.n_nodes;
+    STEP(orca_gru_update(d.gru_blob, 300 + d.d_e, d.worklist, bound, d.count, d.messages, d.memory, d.memory, d.last_update,
+                         d.msg_ts, stream_));
+    return orca_set_flags(d.pending, d.nodes, nullptr, 2 * bs, nullptr, 0, d.n_nodes, stream_);
+  };
+  if (train) STEP(persist());
+  STEP(orca_message_store(src, dst, eidx, ts, bs, d.memory, d.last_update, d.edge_feats, d.d_e, d.time_w, d.time_b, d.slot,
+                          take_epochs(e, 2 * bs), d.n_nodes, d.messages, d.msg_ts, d.pending, stream_));
+  if (!train) STEP(persist());
+#undef STEP
+  e->overlay_complete = false;      // messages were stored without their overlay rows
+  return ORCA_OK;
+}
+
 ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* eidx,
                                 const double* ts, void* stream_) {
   ORCA_REQUIRE(e, "orca_engine_finish: null handle");

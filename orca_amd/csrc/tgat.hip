@@ -712,6 +712,11 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     ++phase_no;
   };
   stamp();
+  if (side.q_extra) {               // block-uniform, ahead of every barrier
+    const int64_t lim = side.q_base + *side.q_extra;
+    Q = lim < Q ? lim : Q;
+    if ((int64_t)blockIdx.x * TQ >= Q) return;
+  }
   if (side.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *side.zero_word = 0;
   const int K = KT ? KT : K_rt;
   const int d_e = DE ? DE : d_e_rt;

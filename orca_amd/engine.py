@@ -48,6 +48,9 @@ class OrcaEngine:
       raise OrcaError("OrcaEngine needs a HIP device (there is no CPU fallback)")
     self.N, self.L, self.K = int(n_nodes), int(n_layers), int(n_neighbors)
     self.reuse, self.budget = bool(reuse), int(budget)
+    # Path C through the native driver (two layers, one rank): its launches are sized for this many uncached
+    # out-of-batch neighbours per batch (their actual number is a device-side count; budget_overflow() reports excess)
+    self.native_budget, self.budget_cap = True, 1024
     self.group = group
     if group is not None:
       import torch.distributed as dist
@@ -338,6 +341,38 @@ class OrcaEngine:
     check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
     return out[:Q] if gather_output else out[lo:hi]
 
+  def _step_budget_native(self, src, dst, neg, ts, eidx, train, plan):
+    """Path C through the C++ driver (orca_engine_step_budget): the whole batch step on the stream, no host round trip --
+    the size of the uncached set stays on the device (the launches are sized for `budget_cap` of them)."""
+    L = _lib.load()
+    bs = src.numel()
+    Q, K, dev = 3 * bs, self.K, self.device
+    cap = self.budget_cap
+    self._ensure_native(Q + cap)
+    b = getattr(self, "_bw", None)
+    if b is None or b["cap"] != cap or b["Q"] < Q:
+      b = self._bw = dict(cap=cap, Q=Q, unc=torch.zeros(cap, dtype=torch.int64, device=dev),
+                          cnt=torch.zeros(1, dtype=torch.int32, device=dev), tmax=torch.zeros(1, dtype=torch.float64, device=dev),
+                          nbr=torch.zeros(Q * K, dtype=torch.int32, device=dev), eid=torch.zeros(Q * K, dtype=torch.int32, device=dev),
+                          et=torch.zeros(Q * K, dtype=torch.float32, device=dev), dt=torch.zeros(Q * K, dtype=torch.float32, device=dev),
+                          err=torch.zeros(1, dtype=torch.int32, device=dev))
+    if getattr(self, "_bitmap", None) is None:
+      self._bitmap = torch.zeros((self.N + 31) // 32, dtype=torch.int32, device=dev)
+    out = torch.empty(Q, D, dtype=torch.float32, device=dev)
+    check(L.orca_engine_step_budget(self._native, ptr(src), ptr(dst), ptr(neg), ptr(ts), ptr(eidx), bs, int(train),
+                                    ptr(plan) if plan is not None and plan.numel() else None,
+                                    int(plan.numel()) if plan is not None else -1, ptr(self.cache_flag[0]), ptr(self._bitmap),
+                                    ptr(b["unc"]), cap, ptr(b["cnt"]), ptr(b["tmax"]), ptr(b["nbr"]), ptr(b["eid"]), ptr(b["et"]),
+                                    ptr(b["dt"]), ptr(out), ptr(b["err"]), stream()), "orca_engine_step_budget")
+    self._overlay_complete = False
+    return out
+
+  def budget_overflow(self):
+    """True if a native Path C step met more uncached neighbours than `budget_cap` (it then evaluated the first
+    budget_cap of them: raise the cap, or set native_budget = False); reads a device flag (one sync)."""
+    b = getattr(self, "_bw", None)
+    return bool(b is not None and int(b["err"].item()) & 2)
+
   def _step_owner_computes(self, L, src, dst, neg, ts, eidx, bs, st, gather_output):
     """Train-ordered step of several ranks (include/orca_hip.h, orca_engine_desc): this rank embeds the src, dst
     and neg roots of its share of the batch's interactions and does the batch's row writes for the ids it owns;
@@ -620,6 +655,11 @@ class OrcaEngine:
       return self._step_reuse_native(src, dst, neg, ts, eidx, train, gather_output)
     if self.sampling == "uniform" and not (self.reuse and self.budget == 0):
       raise OrcaError("OrcaEngine: uniform sampling is wired into Path B (--reuse) and the one-layer exact path only")
+    if (self.reuse and self.budget != 0 and self.L == 2 and self.world == 1 and self.prof is None and self.native_budget):
+      # Path C end to end in the native driver (embedding_module.py:215-285 + tgn_model.py:127-145)
+      self.sync_replicas()
+      plan = self._dev(cache_plan, torch.int64) if cache_plan is not None else None
+      return self._step_budget_native(src, dst, neg, ts, eidx, train, plan)
     self.sync_replicas()
     self._set_overlay_complete(False)      # the Python-dispatched paths store messages without overlay rows
     nodes = torch.cat([src, dst, neg])

@@ -367,3 +367,44 @@ def test_refresh_with_new_gru_weights_drops_stale_overlay(golden):
   exp = fresh.compute_temporal_embeddings(*batch(3), True)
   assert_close_fp32(got.cpu().numpy(), exp.cpu().numpy(), 1e-6, "embeddings after refresh")
   assert_close_fp32(eng.memory.cpu().numpy(), fresh.memory.cpu().numpy(), 1e-6, "memory after refresh")
+
+
+@pytest.mark.gpu
+def test_budget_step_native_equals_dispatched():
+  """Path C issued by the native driver (orca_engine_step_budget: the size of the uncached set stays on the device, the
+  layer-1 launch is sized for a bound) against the Python-dispatched sequence of the same kernels (which the goldens
+  of test_tgn_paths_vs_reference_golden pin to the reference): embeddings, every state table and the cache flags bit
+  for bit over train-ordered batches with a plan, without one, and an evaluation batch; and the overflow flag when the
+  bound is too small."""
+  from orca_amd import ops, synth
+  from orca_amd.engine import OrcaEngine
+  N, E, K, d_e, bs = 3000, 60000, 10, 172, 200
+  src, dst, eidx, ts = synth.powerlaw_graph(N, E, DEV, seed=3)
+  ef = synth.edge_features(E, d_e, DEV)
+  sd = synth.tgn_state_dict(d_e, 2, seed=4)
+  csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
+  engs = []
+  for native in (True, False):
+    e = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=300, device=DEV)
+    e.native_budget = native
+    e.set_neighbor_finder(csr)
+    engs.append(e)
+  A, B = engs
+  rs = np.random.RandomState(1)
+  for b in range(8):
+    s = 30000 + b * bs
+    neg = torch.from_numpy(rs.randint(1, N + 1, bs).astype(np.int64)).to(DEV)
+    plan = torch.from_numpy(rs.choice(np.arange(1, N + 1), 300, replace=False).astype(np.int64)).to(DEV) if b % 3 != 2 else None
+    train = b != 6
+    args = (src[s:s + bs], dst[s:s + bs], neg, ts[s:s + bs], eidx[s:s + bs], train, plan)
+    ea = A.compute_temporal_embeddings(*args)
+    eb = B.compute_temporal_embeddings(*args)
+    assert torch.equal(ea, eb), f"batch {b}: embeddings"
+    for name in ("memory", "last_update", "messages", "msg_ts", "pending"):
+      assert torch.equal(getattr(A, name), getattr(B, name)), f"batch {b}: {name}"
+    assert torch.equal(A.hist[0], B.hist[0]) and torch.equal(A.cache_flag[0], B.cache_flag[0]), f"batch {b}: history"
+  assert not A.budget_overflow()
+  A.budget_cap = 1                       # one uncached neighbour per batch cannot be enough here
+  A.compute_temporal_embeddings(src[40000:40000 + bs], dst[40000:40000 + bs], neg, ts[40000:40000 + bs], eidx[40000:40000 + bs],
+                                True, None)
+  assert A.budget_overflow()

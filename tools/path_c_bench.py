@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Path C (Orca-R, --reuse --budget 1000) at BASELINE config 3's shape on one GPU: a Wiki-Talk-like graph (1.14 M nodes,
 7.83 M interactions, zero-feature edges: d_e = 1), bs = 200, 2 layers, K = 10.  Plans the first `--batches` training
-batches with the device MRD planner, then runs them through OrcaEngine (Python-dispatched budgeted-reuse path:
-device find_uncached, partitioned attention) in train order and reports temporal edges/s next to Path B on the same
-batches."""
+batches with the device MRD planner, then runs them through OrcaEngine in train order -- the budgeted-reuse step issued by
+the native driver (orca_engine_step_budget) and, for comparison, Python-dispatched -- and reports temporal edges/s next to
+Path B on the same batches."""
 import argparse
 import os
 import sys
@@ -42,8 +42,11 @@ def main():
   g.manual_seed(5)
   neg = torch.randint(1, a.nodes + 1, (n,), generator=g, device=dev)
   res = {}
-  for name, budget in (("Path C (budget %d)" % a.budget, a.budget), ("Path B (budget 0)", 0)):
+  for name, budget, native in (("Path C (budget %d), native step driver" % a.budget, a.budget, True),
+                               ("Path C (budget %d), Python-dispatched" % a.budget, a.budget, False),
+                               ("Path B (budget 0)", 0, True)):
     eng = OrcaEngine(sd, ef, a.nodes + 1, 2, a.k, reuse=True, budget=budget, device=dev)
+    eng.native_budget = native
     eng.set_neighbor_finder(csr)
     warm = a.batches // 6
     with torch.no_grad():
@@ -57,6 +60,8 @@ def main():
       torch.cuda.synchronize()
       dt = time.perf_counter() - t0
     res[name] = (a.batches - warm) * a.bs / dt
+    if budget and native:
+      assert not eng.budget_overflow(), "more uncached neighbours than budget_cap"
     print(f"{name}: {res[name] / 1e3:.1f} k temporal edges/s ({1e3 * dt / (a.batches - warm):.3f} ms per {a.bs}-interaction batch)", flush=True)
 
 
