@@ -306,38 +306,99 @@ __global__ void k_mark_uncached(const int32_t* __restrict__ nbr, int64_t n, cons
   if (i >= n) return;
   const int64_t v = nbr[i];
   if (v < 0 || v >= n_nodes || slot[v] == epoch || cache_flag[v]) return;
-  atomicOr(&bitmap[v >> 5], 1u << (v & 31));
+  // test before set: padded slots all name node 0 and hubs repeat -- thousands of atomics on one word serialise at L2
+  // (26 us for 6000 neighbours); a stale read only costs a redundant atomic
+  const uint32_t bit = 1u << (v & 31);
+  if (__hip_atomic_load(&bitmap[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) return;
+  atomicOr(&bitmap[v >> 5], bit);
 }
-__global__ __launch_bounds__(1024) void k_scan_bitmap(uint32_t* __restrict__ bitmap, int64_t n_words, int64_t* __restrict__ out,
-                                                      int64_t cap, int32_t* __restrict__ count) {
-  __shared__ int64_t wave_tot[16];
+// The ordered scan of the bitmap, two launches over up to SCAN_WGS workgroups: each thread owns SCAN_PER consecutive
+// words (thread order = id order), all loaded before the first is looked at (one workgroup walking 35 words per thread
+// in a loop paid a memory round trip per word: 37 us at 1.1 M nodes).  Pass 1 leaves each workgroup's population count,
+// pass 2 ranks every set bit (workgroup base + wave prefix), writes the ids past the first, clears the words.
+constexpr int SCAN_PER = 16, SCAN_WGS = 256;
+// the workgroup counts between the two passes: one array per GPU (calls that overlap on one GPU -- different streams --
+// would share it; every caller here issues its steps on one stream)
+__device__ int32_t g_scan_totals[SCAN_WGS];
+__device__ __forceinline__ void scan_load(const uint32_t* __restrict__ bitmap, int64_t n_words, int64_t w0, uint32_t (&w)[SCAN_PER]) {
+#pragma unroll
+  for (int i = 0; i < SCAN_PER; ++i) {
+    const uint32_t v = bitmap[w0 + i < n_words ? w0 + i : n_words - 1];     // clamped, never skipped
+    w[i] = w0 + i < n_words ? v : 0u;
+  }
+}
+__global__ __launch_bounds__(1024) void k_scan_count(const uint32_t* __restrict__ bitmap, int64_t n_words, int64_t per_wg) {
+  __shared__ int wave_tot[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t per = ceil_div64(n_words, 1024);          // consecutive words per thread: thread order = id order
-  const int64_t w0 = tid * per, w1 = w0 + per < n_words ? w0 + per : n_words;
-  int64_t mine = 0;
-  for (int64_t w = w0; w < w1; ++w) mine += __popc(bitmap[w]);
-  int64_t incl = mine;                                     // inclusive prefix over the wave
-  for (int o = 1; o < 64; o <<= 1) {
-    const int64_t up = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += up;
+  const int64_t lo = (int64_t)blockIdx.x * per_wg, hi = lo + per_wg < n_words ? lo + per_wg : n_words;
+  int mine = 0;
+  for (int64_t base = lo; base < hi; base += 1024 * SCAN_PER) {     // (one trip unless the table has > 134 M rows)
+    uint32_t w[SCAN_PER];
+    scan_load(bitmap, hi, base + (int64_t)tid * SCAN_PER, w);
+#pragma unroll
+    for (int i = 0; i < SCAN_PER; ++i) mine += __popc(w[i]);
   }
-  if (lane == 63) wave_tot[wave] = incl;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if (lane == 0) wave_tot[wave] = mine;
   __syncthreads();
-  int64_t base = 0, total = 0;
-  for (int w = 0; w < 16; ++w) { if (w < wave) base += wave_tot[w]; total += wave_tot[w]; }
-  int64_t k = base + incl - mine;                          // rank of this thread's first id
-  for (int64_t w = w0; w < w1; ++w) {
-    uint32_t bits = bitmap[w];
-    if (!bits) continue;
-    bitmap[w] = 0;                                         // the bitmap is clean again for the next call
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      if (k >= 1 && k - 1 < cap) out[k - 1] = w * 32 + b;  // [1:] drops the smallest id
-      ++k;
-    }
+  if (tid == 0) {
+    int t = 0;
+    for (int i = 0; i < 16; ++i) t += wave_tot[i];
+    g_scan_totals[blockIdx.x] = t;
   }
-  if (tid == 0) *count = (int32_t)(total > 0 ? total - 1 : 0);
+}
+__global__ __launch_bounds__(1024) void k_scan_write(uint32_t* __restrict__ bitmap, int64_t n_words, int64_t per_wg, int n_wg,
+                                                     int64_t* __restrict__ out, int64_t cap, int32_t* __restrict__ count) {
+  __shared__ int64_t wave_tot[16];
+  __shared__ int64_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t lo = (int64_t)blockIdx.x * per_wg, hi = lo + per_wg < n_words ? lo + per_wg : n_words;
+  int64_t before = 0, total = 0;                       // set bits of the workgroups before this one / of all
+  for (int i = lane; i < n_wg; i += 64) {
+    const int t = g_scan_totals[i];
+    total += t;
+    if (i < (int)blockIdx.x) before += t;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); total += __shfl_xor(total, o, 64); }
+  if (tid == 0) carry = before;
+  for (int64_t base = lo; base < hi; base += 1024 * SCAN_PER) {
+    uint32_t w[SCAN_PER];
+    const int64_t w0 = base + (int64_t)tid * SCAN_PER;
+    scan_load(bitmap, hi, w0, w);
+    int64_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER; ++i) mine += __popc(w[i]);
+    int64_t incl = mine;                                   // inclusive prefix over the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    __syncthreads();                                       // (carry of the previous trip is in place)
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int64_t wbase = carry, trip = 0;
+    for (int i = 0; i < 16; ++i) { if (i < wave) wbase += wave_tot[i]; trip += wave_tot[i]; }
+    int64_t k = wbase + incl - mine;                       // rank of this thread's first id
+    if (mine) {
+#pragma unroll
+      for (int i = 0; i < SCAN_PER; ++i) {
+        uint32_t bits = w[i];
+        if (!bits) continue;
+        bitmap[w0 + i] = 0;                                // the bitmap is clean again for the next call
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          if (k >= 1 && k - 1 < cap) out[k - 1] = (w0 + i) * 32 + b;   // [1:] drops the smallest id
+          ++k;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) carry += trip;
+  }
+  if (blockIdx.x == 0 && tid == 0) *count = (int32_t)(total > 0 ? total - 1 : 0);
 }
 
 inline unsigned blocks(int64_t n, int per) { return (unsigned)ceil_div64(n, per); }
@@ -352,7 +413,14 @@ ORCA_API int orca_find_uncached(const int32_t* nbr, int64_t n_nbr, const int64_t
   hipStream_t st = (hipStream_t)stream;
   if (n_batch) k_stamp_ids<<<blocks(n_batch, 256), 256, 0, st>>>(batch_nodes, n_batch, slot, epoch, n_nodes);
   if (n_nbr) k_mark_uncached<<<blocks(n_nbr, 256), 256, 0, st>>>(nbr, n_nbr, slot, epoch, cache_flag, n_nodes, bitmap);
-  k_scan_bitmap<<<1, 1024, 0, st>>>(bitmap, ceil_div64(n_nodes, 32), out, cap, count);
+  {
+    const int64_t n_words = ceil_div64(n_nodes, 32);
+    int n_wg = (int)ceil_div64(n_words, 1024 * SCAN_PER);
+    n_wg = n_wg > SCAN_WGS ? SCAN_WGS : n_wg;
+    const int64_t per_wg = ceil_div64(ceil_div64(n_words, n_wg), SCAN_PER) * SCAN_PER;
+    k_scan_count<<<(unsigned)n_wg, 1024, 0, st>>>(bitmap, n_words, per_wg);
+    k_scan_write<<<(unsigned)n_wg, 1024, 0, st>>>(bitmap, n_words, per_wg, n_wg, out, cap, count);
+  }
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
