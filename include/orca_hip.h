@@ -474,6 +474,10 @@ int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst,
 /* owner-computes step: after the xm all-gather, overlay[id] = row and pending[id] = 1 for every id any rank sent */
 int orca_engine_apply(orca_engine_t* e, void* stream);
 
+/* The root queries of a batch (model/tgn_model.py:99-102: nodes = [src; dst; neg], timestamps = [t; t; t]) in one launch:
+ * nodes int64 [3*bs], qts double [3*bs], nodes32 = the ids as int32; *tmax (device double, may be NULL) = max t. */
+int orca_build_roots(const int64_t* src, const int64_t* dst, const int64_t* neg, const double* ts, int64_t bs,
+                     int64_t* nodes, double* qts, int32_t* nodes32, double* tmax, void* stream);
 /* One whole batch step of Path C (modules/embedding_module.py:215-285: --reuse with --budget B; two layers, one rank)
  * issued from C++ with no host round trip: roots -> their neighbours (nbr_top .. dt_top [3*bs*K]) -> the neighbours
  * without a cached layer-1 embedding (embedding_module.py:200-212; `unc` [cap], *unc_count on the device) -> layer 1

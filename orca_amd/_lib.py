@@ -117,6 +117,7 @@ SIGNATURES = {
     "orca_engine_set_sampling": (i32, [vp, i32, u64]),
     "orca_engine_set_overlay_complete": (i32, [vp, i32]),
     "orca_engine_get_overlay_complete": (i32, [vp]),
+    "orca_build_roots": (i32, [vp] * 4 + [i64] + [vp] * 5),
     "orca_engine_step_budget": (i32, [vp] * 6 + [i64, i32, vp, i64, vp, vp, vp, i64] + [vp] * 9),
     "orca_engine_drain": (i32, [vp, vp]),
     "orca_mrd_plan_host": (i32, [i64, i64, i32, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]),

@@ -804,7 +804,7 @@ __global__ __launch_bounds__(1024) void k_budget_roots(const int64_t* __restrict
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = red[w] > m ? red[w] : m;
-    *tmax = m;
+    if (tmax) *tmax = m;
   }
 }
 // the evaluated set behind the roots: entries Q .. Q+cap-1 = the uncached ids (device count), then padding -- id -1 for
@@ -822,6 +822,15 @@ __global__ void k_budget_cnodes(const int64_t* __restrict__ unc, const int32_t* 
   qts[Q + i] = *tmax;
 }
 }  // namespace
+
+ORCA_API int orca_build_roots(const int64_t* src, const int64_t* dst, const int64_t* neg, const double* ts, int64_t bs,
+                              int64_t* nodes, double* qts, int32_t* nodes32, double* tmax, void* stream) {
+  ORCA_REQUIRE(bs >= 0 && (bs == 0 || (src && dst && neg && ts && nodes && qts && nodes32)), "orca_build_roots: bad arguments");
+  if (bs == 0) return ORCA_OK;
+  k_budget_roots<<<1, 1024, 0, (hipStream_t)stream>>>(src, dst, neg, ts, bs, nodes, qts, nodes32, tmax);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
 
 ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
                                      const double* ts, const int64_t* eidx, int64_t bs, int train,

@@ -720,8 +720,7 @@ class OrcaEngine:
     self.sync_replicas()
     self._set_overlay_complete(False)
     bs = src.numel()
-    nodes = torch.cat([src, dst, neg])
-    t3 = torch.cat([ts, ts, ts])
+    nodes, nodes32, t3 = ops.build_roots(src.contiguous(), dst.contiguous(), neg.contiguous(), ts.contiguous())
     Q = nodes.numel()
     lo, hi, per = self._slice(Q)
     my_nodes = nodes[lo:hi]
@@ -756,7 +755,7 @@ class OrcaEngine:
       nbr, eid, dt = self._sample(my_nodes, t3[lo:hi], q0=lo)
       self._overlay_updated_memory(nbr, my_nodes)
       cnt_ready = self._fetch_count()
-      my32 = my_nodes.to(torch.int32)
+      my32 = nodes32[lo:hi]
       dk = self._dropout_kw(1, lo)
       sv = []       # (the forward keeps q~, the softmax weights and the key sums for the backward: ops.tgat_forward(save=))
       emb = self._attend(1, n, nbr, eid, dt, True, self.memory, my32, self.memory, nbr, True, drop=dk, save=sv)

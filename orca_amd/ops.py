@@ -566,3 +566,15 @@ def find_uncached(nbr, batch_nodes, cache_flag, slot, epoch, bitmap):
                                        int(epoch), slot.numel(), ptr(bitmap), ptr(out), cap, ptr(count), stream()),
         "orca_find_uncached")
   return out[:int(count.item())]
+
+
+def build_roots(src, dst, neg, ts):
+  """orca_build_roots: ([src;dst;neg] int64, the same as int32, [t;t;t] float64) in one launch (tgn_model.py:99-102)."""
+  bs = src.numel()
+  dev = src.device
+  nodes = torch.empty(3 * bs, dtype=torch.int64, device=dev)
+  n32 = torch.empty(3 * bs, dtype=torch.int32, device=dev)
+  t3 = torch.empty(3 * bs, dtype=torch.float64, device=dev)
+  check(_lib.load().orca_build_roots(ptr(src), ptr(dst), ptr(neg), ptr(ts), bs, ptr(nodes), ptr(t3), ptr(n32), None, stream()),
+        "orca_build_roots")
+  return nodes, n32, t3
