@@ -279,7 +279,8 @@ def main():
     train = {"edges_per_s": args.train_steps * gbs / t1, "ms_per_step": 1e3 * t1 / args.train_steps,
              "steps": args.train_steps, "last_loss": float(loss),
              "what": "train-ordered forward + BCE loss + backward (attention x layers, GRU) + Adam + blob re-pack; "
-                     "backward = grouped MFMA GEMM launches + wave-per-query kernels, fused Adam, Python-dispatched"}
+                     "backward per layer = fused row-chain kernels + single-pass per-query kernels + one weight-gradient GEMM; "
+                     "fused Adam; Python-dispatched"}
 
   path_a = None
   if world == 1 and not args.no_reuse and args.layers > 1 and args.path_a_steps > 0 and args.sampling == "recent":

@@ -192,7 +192,8 @@ int64_t orca_tgat_backward_workspace_floats(int d_e, int64_t Q, int K);
  * d_nbr_time [Q*K,ORCA_D] (dense mode, may be NULL) or, in gather mode, ADDS into d_time_w / d_time_b [ORCA_D]
  * (time_encoding.py:14; both or neither).  Edge features are data upstream and get no gradient.  `in->mask`
  * must be the mask as it was BEFORE the forward call (the forward un-masks slot 0 of all-padded queries in
- * place, :46-47).  `params` are read, not modified.  workspace: orca_tgat_backward_workspace_floats floats. */
+ * place, :46-47).  `params` are read, not modified.  d_nbr may be NULL when nobody reads the neighbour rows' gradient (detached history
+ * rows, modules/history.py:32-40).  workspace: orca_tgat_backward_workspace_floats floats. */
 int orca_tgat_backward(const orca_tgat_params* params, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
                        const float* grad_out, const orca_tgat_params* grads, float* d_src, float* d_nbr,
                        float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b, float* workspace,

@@ -1004,6 +1004,9 @@ __global__ __launch_bounds__(256, 4) void k_bwd_attn_bwd(orca_tgat_inputs in, in
   load_slots2(q0, q1, qt + q * 2 * kdim, kdim, d_e, lane);
   float tw[2] = {0.f, 0.f}, tb[2] = {0.f, 0.f};
   const bool hi = lane + 64 < D;
+  // (nobody reads the key-row gradients when the neighbour rows are detached history rows and the time encoder is
+  // frozen: d_nbr == NULL skips 400 B of stores per slot)
+  if (!d_nbr && !d_nbr_time && !tgrad) return;
   for (int j = 0; j < K; ++j) {
     const float w0 = __shfl(aw0, j, 64), w1 = __shfl(aw1, j, 64), e0 = __shfl(s0, j, 64), e1 = __shfl(s1, j, 64);
     const float dt = __shfl(S.dt, j, 64);
@@ -1014,7 +1017,7 @@ __global__ __launch_bounds__(256, 4) void k_bwd_attn_bwd(orca_tgat_inputs in, in
       const float dxt = w0 * g0[st] + w1 * g1[st] + e0 * q0[st] + e1 * q1[st];
       if (h2 == 0 || hi) {
         const int c = lane + 64 * h2;
-        d_nbr[(q * K + j) * D + c] = dxn;
+        if (d_nbr) d_nbr[(q * K + j) * D + c] = dxn;
         if (in.dt) {
           if (tgrad) {
             const float dth = -orca_sinf(orca_time_arg(dt, h2 ? tc.w1 : tc.w0, h2 ? tc.b1 : tc.b0)) * dxt;
@@ -1552,7 +1555,7 @@ int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_input
   hipStream_t s = (hipStream_t)stream_;
   ORCA_REQUIRE(Q >= 0, "orca_tgat_backward: negative Q");
   if (Q == 0) return ORCA_OK;
-  ORCA_REQUIRE(P && G && in && grad_out && workspace && d_nbr, "orca_tgat_backward: null pointer");
+  ORCA_REQUIRE(P && G && in && grad_out && workspace, "orca_tgat_backward: null pointer");
   ORCA_REQUIRE(d_e >= 1 && d_e <= ORCA_MAX_DE, "orca_tgat_backward: d_e=%d outside [1,%d]", d_e, ORCA_MAX_DE);
   ORCA_REQUIRE(K >= 1 && K <= ORCA_MAX_K, "orca_tgat_backward: K=%d outside [1,%d]", K, ORCA_MAX_K);
   ORCA_REQUIRE(Q < (1LL << 31) / 1024, "orca_tgat_backward: Q too large for one call");

@@ -829,7 +829,9 @@ class OrcaEngine:
       saved = kw.pop("saved", None)
       if layer == 1:
         kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
-      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, m, K, d, want_time_param_grads=want_t, pool=pool, saved=saved, **kw)
+      # (sink None: the neighbour rows are detached history rows -- nobody reads their gradient unless --gradient)
+      g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, m, K, d, want_time_param_grads=want_t, pool=pool, saved=saved,
+                                                        want_d_nbr=sink is not None or self.gradient, **kw)
       for k, v in g.items():                           # Path A evaluates a layer once per batch, like Path B
         grads[p + k] = v
       if want_t:

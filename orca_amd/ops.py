@@ -309,7 +309,7 @@ def _zeros(n, dev, pool):
   return pool.take(n) if pool is not None else torch.zeros(n, dtype=torch.float32, device=dev)
 
 
-def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=None, saved=None, **kw):
+def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=None, saved=None, want_d_nbr=True, **kw):
   """orca_tgat_backward.  sd: the layer's raw parameters (keys TGAT_KEYS, fp32 on the device); kw: the fields of
   orca_tgat_inputs of the forward call (mask = the mask BEFORE the forward).  Returns (grads: dict like sd,
   d_src [Q,D], d_nbr [Q*K,D], d_src_time, d_nbr_time, d_time_w, d_time_b) -- the time entries that do not apply
@@ -335,7 +335,7 @@ def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=Non
   wsp = torch.empty(n, dtype=torch.float32, device=dev)
   go = grad_out.detach().to(torch.float32).contiguous()
   d_src = torch.empty((Q, D), dtype=torch.float32, device=dev)
-  d_nbr = torch.empty((Q * K, D), dtype=torch.float32, device=dev)
+  d_nbr = torch.empty((Q * K, D), dtype=torch.float32, device=dev) if want_d_nbr else None
   d_st = d_nt = d_tw = d_tb = None
   if gather:
     if want_time_param_grads:
