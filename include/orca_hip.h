@@ -210,6 +210,16 @@ int orca_tgat_backward_saved(const orca_tgat_params* params, int d_e, const orca
                              const float* grad_out, const orca_tgat_params* grads, float* d_src, float* d_nbr,
                              float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b, float* workspace,
                              const float* saved, void* stream);
+/* The same call in two parts (autograd's engine is free to order the parameter-gradient nodes of train.py:236
+ * loss.backward() after the data-gradient chain; here the caller does): phases 1 = the data gradients (d_src, d_nbr,
+ * the time gradients' per-query terms), 2 = the parameter gradients (grads, d_time_w/b), which read what phase 1 left in
+ * `workspace` -- same arguments, workspace untouched in between, any stream ordered after phase 1 (a second stream
+ * lets the reductions over the queries run beside the next layer's chain); 3 = both = orca_tgat_backward(_saved).
+ * saved may be NULL (recompute, as orca_tgat_backward). */
+int orca_tgat_backward_phase(const orca_tgat_params* params, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
+                             const float* grad_out, const orca_tgat_params* grads, float* d_src, float* d_nbr,
+                             float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b, float* workspace,
+                             const float* saved, int phases, void* stream);
 
 /* orca_tgat_pack (+ orca_tgat_pack_gather when time_b != NULL) for n_layers layers at once: params[l] are layer l's raw
  * tensors, blobs[l] its blob.  The folds of all layers share launches (3 per two layers instead of 8 per layer): the
@@ -231,6 +241,10 @@ int64_t orca_gru_blob_floats(int msg_dim);
 /* nn.GRUCell(msg_dim -> ORCA_D) parameters (weight_ih [300,msg_dim], weight_hh [300,100], biases) */
 int orca_gru_pack(int msg_dim, const float* weight_ih, const float* weight_hh, const float* bias_ih,
                   const float* bias_hh, float* blob, void* stream);
+/* the same for a blob that orca_gru_pack filled before with the same msg_dim (new values after optimizer.step(),
+ * train.py:238): skips the zero fill of the padding */
+int orca_gru_repack(int msg_dim, const float* weight_ih, const float* weight_hh, const float* bias_ih,
+                    const float* bias_hh, float* blob, void* stream);
 /* For r in [0, n): id = ids ? ids[r] : r;  out[id] = GRUCell(x[id], h[id]).  n is read from *n_dev
  * when n_dev != NULL (device-resident work-list length; rows >= *n_dev are skipped and `n` is
  * then the launch upper bound).  out may alias h (in-place persist, update_memory :25-39) or be the
@@ -250,6 +264,12 @@ int orca_gru_backward(int msg_dim, const float* weight_ih, const float* weight_h
                       const float* bias_hh, const int32_t* ids, int64_t n, const float* x, const float* h,
                       const float* d_out, float* g_weight_ih, float* g_weight_hh, float* g_bias_ih, float* g_bias_hh,
                       float* d_x, float* d_h, float* workspace, void* stream);
+/* in two parts like orca_tgat_backward_phase: phases 1 = row gathers, gate derivatives, d_x / d_h; 2 = the parameter
+ * gradients from what phase 1 left in `workspace`; 3 = both = orca_gru_backward */
+int orca_gru_backward_phase(int msg_dim, const float* weight_ih, const float* weight_hh, const float* bias_ih,
+                            const float* bias_hh, const int32_t* ids, int64_t n, const float* x, const float* h,
+                            const float* d_out, float* g_weight_ih, float* g_weight_hh, float* g_bias_ih, float* g_bias_hh,
+                            float* d_x, float* d_h, float* workspace, int phases, void* stream);
 
 /* dst_table[id] = src_table[id] (rows of ORCA_D floats) and, if last_update != NULL, last_update[id] =
  * msg_ts[id], for the first min(n, *n_dev) ids of a work-list: commits GRU rows held in the overlay into

@@ -74,9 +74,11 @@ SIGNATURES = {
     "orca_scatter_add_flagged": (i32, [vp, vp, vp, i64, vp, vp, i64, vp, vp]),
     "orca_gru_backward_workspace_floats": (i64, [i32, i64]),
     "orca_gru_backward": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 11),
+    "orca_gru_backward_phase": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 10 + [i32, vp]),
     "orca_tgat_backward_workspace_floats": (i64, [i32, i64, i32]),
     "orca_tgat_backward": (i32, [vp, i32, vp, i64, i32] + [vp] * 10),
     "orca_tgat_backward_saved": (i32, [vp, i32, vp, i64, i32] + [vp] * 11),
+    "orca_tgat_backward_phase": (i32, [vp, i32, vp, i64, i32] + [vp] * 10 + [i32, vp]),
     "orca_tgat_saved_floats": (i64, [i32, i64, i32]),
     "orca_tgat_forward_saving": (i32, [vp, i32, ctypes.POINTER(TgatInputs), i64, i32, vp, vp, vp, vp]),
     "orca_tgat_dropout_mask": (i32, [u64, i64, i64, i32, ctypes.c_float, vp, vp]),
@@ -85,6 +87,7 @@ SIGNATURES = {
     "orca_debug_gru_phase_clock": (i32, [vp]),
     "orca_gru_blob_floats": (i64, [i32]),
     "orca_gru_pack": (i32, [i32, vp, vp, vp, vp, vp, vp]),
+    "orca_gru_repack": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "orca_gru_update": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     "orca_commit_rows": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp]),
     "orca_persist_overlay": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp]),

@@ -352,13 +352,25 @@ ORCA_API int64_t orca_gru_blob_floats(int msg_dim) {
   return gru_layout(msg_dim).total;
 }
 
+static int gru_pack_impl(int msg_dim, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                         float* blob, bool packed_before, void* stream_);
 ORCA_API int orca_gru_pack(int msg_dim, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                            float* blob, void* stream_) {
+  return gru_pack_impl(msg_dim, w_ih, w_hh, b_ih, b_hh, blob, false, stream_);
+}
+ORCA_API int orca_gru_repack(int msg_dim, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                             float* blob, void* stream_) {
+  return gru_pack_impl(msg_dim, w_ih, w_hh, b_ih, b_hh, blob, true, stream_);
+}
+static int gru_pack_impl(int msg_dim, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                         float* blob, bool packed_before, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   ORCA_REQUIRE(msg_dim >= 1 && msg_dim <= 3 * D + ORCA_MAX_DE, "orca_gru_pack: msg_dim=%d unsupported", msg_dim);
   ORCA_REQUIRE(w_ih && w_hh && b_ih && b_hh && blob, "orca_gru_pack: null pointer");
   GBlob L = gru_layout(msg_dim);
-  ORCA_HIP_TRY(hipMemsetAsync(blob, 0, (size_t)L.total * sizeof(float), s));
+  if (!packed_before) {       // the padding between the packed tiles is written once; a re-pack rewrites every tile
+    ORCA_HIP_TRY(hipMemsetAsync(blob, 0, (size_t)L.total * sizeof(float), s));
+  }
   int rc = ORCA_OK;
   OrcaPackJob jobs[6];
   for (int g = 0; g < 3; ++g) {

@@ -53,7 +53,18 @@ ORCA_API int orca_gru_backward(int msg_dim, const float* weight_ih, const float*
                                const float* bias_hh, const int32_t* ids, int64_t n, const float* x, const float* h,
                                const float* d_out, float* g_weight_ih, float* g_weight_hh, float* g_bias_ih,
                                float* g_bias_hh, float* d_x, float* d_h, float* workspace, void* stream_) {
+  return orca_gru_backward_phase(msg_dim, weight_ih, weight_hh, bias_ih, bias_hh, ids, n, x, h, d_out, g_weight_ih, g_weight_hh,
+                                 g_bias_ih, g_bias_hh, d_x, d_h, workspace, 3, stream_);
+}
+
+// phases: 1 = the gathers, the gate derivatives and the input gradients; 2 = the parameter gradients (reads what phase 1
+// left in the workspace: a caller may issue it later, on another stream); 3 = both
+ORCA_API int orca_gru_backward_phase(int msg_dim, const float* weight_ih, const float* weight_hh, const float* bias_ih,
+                                     const float* bias_hh, const int32_t* ids, int64_t n, const float* x, const float* h,
+                                     const float* d_out, float* g_weight_ih, float* g_weight_hh, float* g_bias_ih,
+                                     float* g_bias_hh, float* d_x, float* d_h, float* workspace, int phases, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
+  ORCA_REQUIRE(phases >= 1 && phases <= 3, "orca_gru_backward_phase: phases=%d", phases);
   ORCA_REQUIRE(n >= 0, "orca_gru_backward: negative row count");
   if (n == 0) return ORCA_OK;
   ORCA_REQUIRE(msg_dim >= 1 && msg_dim <= 3 * ORCA_D + ORCA_MAX_DE, "orca_gru_backward: msg_dim=%d out of range", msg_dim);
@@ -68,20 +79,22 @@ ORCA_API int orca_gru_backward(int msg_dim, const float* weight_ih, const float*
   float* part = gh + n * G3;
   part += (64 - ((part - workspace) & 63)) & 63;
   auto ew = [&](int64_t k) { return (unsigned)ceil_div64(k, 256); };
-  k_gather_wide<<<ew(n * msg_dim), 256, 0, s>>>(x, ids, n, msg_dim, xg);
-  k_gather_wide<<<ew(n * D), 256, 0, s>>>(h, ids, n, D, hg);
   int rc = ORCA_OK;
+  if (phases & 1) {
+    k_gather_wide<<<ew(n * msg_dim), 256, 0, s>>>(x, ids, n, msg_dim, xg);
+    k_gather_wide<<<ew(n * D), 256, 0, s>>>(h, ids, n, D, hg);
+  }
   auto G1 = [&](int M_, int N_, int K_, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                 float* C, int64_t scm, int64_t scn, const float* bias, int accumulate) {
     return OrcaGemm{M_, N_, K_, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, 1.f, accumulate, 0, nullptr, nullptr, 0, nullptr, 1};
   };
-  {   // gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh: one launch
+  if (phases & 1) {   // gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh: one launch
     OrcaGemm g[2] = {G1(M, G3, msg_dim, xg, msg_dim, 1, weight_ih, 1, msg_dim, gi, G3, 1, bias_ih, 0),
                      G1(M, G3, D, hg, D, 1, weight_hh, 1, D, gh, G3, 1, bias_hh, 0)};
     rc |= orca_sgemm_group(s, g, 2, nullptr);
   }
-  k_gru_gates_bwd<<<ew(n * D), 256, 0, s>>>(gi, gh, hg, d_out, n, d_h);
-  {   // weight_ih [300,msg] += dgi^T x;  weight_hh [300,100] += dgh^T h;  the biases as a column of ones: one launch
+  if (phases & 1) k_gru_gates_bwd<<<ew(n * D), 256, 0, s>>>(gi, gh, hg, d_out, n, d_h);
+  if (phases & 2) {   // weight_ih [300,msg] += dgi^T x;  weight_hh [300,100] += dgh^T h;  the biases as a column of ones: one launch
     OrcaGemm g[2] = {G1(G3, msg_dim, M, gi, 1, G3, xg, msg_dim, 1, g_weight_ih, msg_dim, 1, nullptr, 1),
                      G1(G3, D, M, gh, 1, G3, hg, D, 1, g_weight_hh, D, 1, nullptr, 1)};
     g[0].ones_out = g_bias_ih;
@@ -89,7 +102,7 @@ ORCA_API int orca_gru_backward(int msg_dim, const float* weight_ih, const float*
     g[0].splits = g[1].splits = GRU_SPLITS;
     rc |= orca_sgemm_group(s, g, 2, part);
   }
-  if (d_x || d_h) {
+  if ((phases & 1) && (d_x || d_h)) {
     OrcaGemm g[2];
     int ng = 0;
     if (d_x) g[ng++] = G1(M, msg_dim, G3, gi, G3, 1, weight_ih, msg_dim, 1, d_x, msg_dim, 1, nullptr, 0);

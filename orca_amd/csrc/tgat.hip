@@ -134,24 +134,40 @@ __device__ __forceinline__ void fold_f_tile(int w, const double* __restrict__ U,
                [&](int d, int c) { return (double)v_w[(int64_t)(h * D + d) * kdim + c]; },
                [&](int n, int c, double v) { F[n * width + h * KP + c] = (float)v; });
 }
-// every element of F outside the two [100 x kdim] products
+// every element of F outside the two [100 x kdim] products and the three dot-product columns (fold_f_dot)
 __device__ __forceinline__ void fold_f_rest(int i, const double* __restrict__ U, const float* __restrict__ fc1_w, int kdim,
                                             int KP, int width, float* __restrict__ F) {
   if (i >= D * width) return;
   const int n = i / width, col = i % width;
-  double acc = 0.0;
+  float v = 0.0f;
   if (col < 2 * KP) {
     const int h = col / KP, c = col - h * KP;
-    if (c < kdim) return;                      // (fold_f_tile)
-    if (c == kdim) {
-      for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * U[2 * D * D + h * QD + j];
-    }
+    if (c <= kdim) return;                     // (fold_f_tile, fold_f_dot)
   } else if (col < 2 * KP + D) {
-    acc = (double)fc1_w[n * 3 * D + QD + (col - 2 * KP)];
+    v = fc1_w[n * 3 * D + QD + (col - 2 * KP)];
   } else if (col == 2 * KP + D) {
-    for (int j = 0; j < QD; ++j) acc += (double)fc1_w[n * 3 * D + j] * U[2 * D * D + 2 * QD + j];
+    return;                                    // (fold_f_dot)
   }
-  F[i] = (float)acc;
+  F[i] = v;
+}
+// The three columns of F that are dot products over j < 200 of row n of W1 with a vector of U: head h's value-bias
+// column (which = h) and the out-projection-bias column (which = 2).  One wave per (n, which), the lanes stride j:
+// as one thread per element these were 300 threads walking 200 dependent loads each -- 12 of stage 2's 18.6 us.
+__device__ __forceinline__ void fold_f_dot(int w, const double* __restrict__ U, const float* __restrict__ fc1_w, int kdim,
+                                           int KP, int width, float* __restrict__ F) {
+  if (w >= 3 * D) return;
+  const int n = w / 3, which = w % 3, lane = threadIdx.x & 63;
+  const double* u = U + 2 * D * D + which * QD;
+  double acc = 0.0;
+#pragma unroll
+  for (int j0 = 0; j0 < QD; j0 += 64) {
+    const int j = j0 + lane < QD ? j0 + lane : QD - 1;
+    const double t = (double)fc1_w[n * 3 * D + j] * u[j];
+    acc += j0 + lane < QD ? t : 0.0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) F[n * width + (which < 2 ? which * KP + kdim : 2 * KP + D)] = (float)acc;
 }
 
 // ---- folding the q projection into the key map (gather mode: the source's time encoding is the constant
@@ -208,14 +224,17 @@ __global__ __launch_bounds__(256) void k_fold_stage1(FoldLayers L) {
     fold_qt(threadIdx.x, L.q_w[l], L.in_b[l], L.time_b, L.t[l]);
   }
 }
+constexpr int FOLD_BD = (3 * D + 3) / 4;      // fold_f_dot: a wave per dot product
 __global__ __launch_bounds__(256) void k_fold_stage2(FoldLayers L, int bft, int bfr, int bk) {
-  const int per = bft + bfr + bk, l = blockIdx.x / per, local = blockIdx.x % per;
+  const int per = bft + bfr + FOLD_BD + bk, l = blockIdx.x / per, local = blockIdx.x % per;
   if (local < bft) {
     if (L.tail) fold_f_tile(local * 4 + (threadIdx.x >> 6), L.U[l], L.v_w[l], L.kdim, L.KP, L.width, L.F[l]);
   } else if (local < bft + bfr) {
     if (L.tail) fold_f_rest((local - bft) * 256 + threadIdx.x, L.U[l], L.fc1_w[l], L.kdim, L.KP, L.width, L.F[l]);
+  } else if (local < bft + bfr + FOLD_BD) {
+    if (L.tail) fold_f_dot((local - bft - bfr) * 4 + (threadIdx.x >> 6), L.U[l], L.fc1_w[l], L.kdim, L.KP, L.width, L.F[l]);
   } else if (L.gather) {
-    fold_qk_tile((local - bft - bfr) * 4 + (threadIdx.x >> 6), L.q_w[l], L.k_w[l], L.in_b[l], L.t[l], L.kdim, L.KP, L.A[l], L.a[l]);
+    fold_qk_tile((local - bft - bfr - FOLD_BD) * 4 + (threadIdx.x >> 6), L.q_w[l], L.k_w[l], L.in_b[l], L.t[l], L.kdim, L.KP, L.A[l], L.a[l]);
   }
 }
 // launches both stages for the layers described by F (host side)
@@ -223,7 +242,7 @@ int fold_launch(const FoldLayers& F, hipStream_t s) {
   const int bft = (2 * FOLD_T100 * ((F.kdim + 15) / 16) + 3) / 4, bfr = (D * F.width + 255) / 256,
             bk = (2 * ((F.kdim + 1 + 15) / 16) * FOLD_T100 + 3) / 4;
   k_fold_stage1<<<(unsigned)(F.n * (FOLD_BU + FOLD_BR + 1)), 256, 0, s>>>(F);
-  k_fold_stage2<<<(unsigned)(F.n * (bft + bfr + bk)), 256, 0, s>>>(F, bft, bfr, bk);
+  k_fold_stage2<<<(unsigned)(F.n * (bft + bfr + FOLD_BD + bk)), 256, 0, s>>>(F, bft, bfr, bk);
   return hipGetLastError() == hipSuccess ? ORCA_OK : ORCA_EHIP;
 }
 __global__ void k_pack(float* __restrict__ dst, int KB, int n0, int n_cnt, int Kd, const float* __restrict__ src,

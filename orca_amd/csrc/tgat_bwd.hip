@@ -1530,14 +1530,14 @@ namespace {
 int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
                        const float* grad_out, const orca_tgat_params* G, float* d_src, float* d_nbr,
                        float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b,
-                       float* workspace, const float* saved, void* stream_);
+                       float* workspace, const float* saved, int phases, void* stream_);
 }
 ORCA_API int orca_tgat_backward(const orca_tgat_params* P, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
                                 const float* grad_out, const orca_tgat_params* G, float* d_src, float* d_nbr,
                                 float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b,
                                 float* workspace, void* stream_) {
   return tgat_backward_impl(P, d_e, in, Q, K, grad_out, G, d_src, d_nbr, d_src_time, d_nbr_time, d_time_w, d_time_b, workspace,
-                            nullptr, stream_);
+                            nullptr, 3, stream_);
 }
 ORCA_API int orca_tgat_backward_saved(const orca_tgat_params* P, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
                                       const float* grad_out, const orca_tgat_params* G, float* d_src, float* d_nbr,
@@ -1545,13 +1545,22 @@ ORCA_API int orca_tgat_backward_saved(const orca_tgat_params* P, int d_e, const 
                                       float* workspace, const float* saved, void* stream_) {
   ORCA_REQUIRE(saved, "orca_tgat_backward_saved: null buffer");
   return tgat_backward_impl(P, d_e, in, Q, K, grad_out, G, d_src, d_nbr, d_src_time, d_nbr_time, d_time_w, d_time_b, workspace,
-                            saved, stream_);
+                            saved, 3, stream_);
+}
+ORCA_API int orca_tgat_backward_phase(const orca_tgat_params* P, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
+                                      const float* grad_out, const orca_tgat_params* G, float* d_src, float* d_nbr,
+                                      float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b,
+                                      float* workspace, const float* saved, int phases, void* stream_) {
+  ORCA_REQUIRE(phases == 1 || phases == 2 || phases == 3, "orca_tgat_backward_phase: phases=%d (1 data gradients, 2 parameter "
+               "gradients, 3 both)", phases);
+  return tgat_backward_impl(P, d_e, in, Q, K, grad_out, G, d_src, d_nbr, d_src_time, d_nbr_time, d_time_w, d_time_b, workspace,
+                            saved, phases, stream_);
 }
 namespace {
 int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_inputs* in, int64_t Q, int K,
                        const float* grad_out, const orca_tgat_params* G, float* d_src, float* d_nbr,
                        float* d_src_time, float* d_nbr_time, float* d_time_w, float* d_time_b,
-                       float* workspace, const float* saved, void* stream_) {
+                       float* workspace, const float* saved, int phases, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   ORCA_REQUIRE(Q >= 0, "orca_tgat_backward: negative Q");
   if (Q == 0) return ORCA_OK;
@@ -1595,118 +1604,127 @@ int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_input
                 float* C, int64_t scm, int64_t scn, const float* bias, float alpha) {
     return OrcaGemm{M_, N_, K_, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, alpha, 0, 0, nullptr, nullptr, 0, nullptr, 1};
   };
-  // ---- forward recompute, then the data gradients: a chain (fused per 16-row tile when the shapes are the built ones) --
-  const bool chain = chain_usable(d_e, workspace);
-  const unsigned tiles = (unsigned)ceil_div64(Q, 16);
-  using CL = ChainLds<QD + 172>;
-  if (chain) {
-    static bool attr_set[64] = {};
-    if (orca_first_use_on_device(attr_set)) {
-      // (the kernels also hold a few hundred static floats: ask for what each launch uses, not for the whole LDS)
-      ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_chain_a<QD + 172>, hipFuncAttributeMaxDynamicSharedMemorySize, CL::A_FLOATS * (int)sizeof(float)));
-      ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_chain_b<QD + 172>, hipFuncAttributeMaxDynamicSharedMemorySize, CL::B_FLOATS * (int)sizeof(float)));
-      ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_chain_c<QD + 172>, hipFuncAttributeMaxDynamicSharedMemorySize, CL::C_FLOATS * (int)sizeof(float)));
-    }
-    {
-      using CW = ChainW<QD + 172>;
-      const int KDc = QD + 172;
-      ChainPack pk{};
-      int i = 0;
-      pk.j[i++] = chain_pack_job<CW::A1>(P->q_w, 1, QD, 0, QD, QD, true, CW::a1);
-      pk.j[i++] = chain_pack_job<CW::A2>(P->k_w, KDc, 1, D * KDc, KDc, D, false, CW::a2);
-      pk.j[i++] = chain_pack_job<CW::B1>(P->v_w, 1, KDc, D * KDc, D, KDc, true, CW::b1);
-      pk.j[i++] = chain_pack_job<CW::B2>(P->o_w, 1, QD, 0, QD, QD, true, CW::b2);
-      pk.j[i++] = chain_pack_job<CW::B3>(P->fc1_w, 1, 3 * D, 0, D, 3 * D, true, CW::b3);
-      pk.j[i++] = chain_pack_job<CW::B4>(P->fc2_w, 1, D, 0, D, D, true, CW::b4);
-      pk.j[i++] = chain_pack_job<CW::B5>(P->fc2_w, D, 1, 0, D, D, false, CW::b5);
-      pk.j[i++] = chain_pack_job<CW::B6>(P->fc1_w, 3 * D, 1, 0, 3 * D, D, false, CW::b6);
-      pk.j[i++] = chain_pack_job<CW::B7>(P->o_w, QD, 1, 0, QD, QD, false, CW::b7);
-      pk.j[i++] = chain_pack_job<CW::B8>(P->v_w, KDc, 1, D * KDc, KDc, D, false, CW::b8);
-      pk.j[i++] = chain_pack_job<CW::C1>(P->k_w, 1, KDc, D * KDc, D, KDc, true, CW::c1);
-      pk.j[i++] = chain_pack_job<CW::C2>(P->q_w, QD, 1, 0, QD, QD, false, CW::c2);
-      static_assert(CHAIN_PACK_JOBS == 12, "one job per stage");
-      pk.total = CW::total;
-      k_chain_pack<<<(unsigned)ceil_div64((int64_t)CW::total * 64, 256), 256, 0, s>>>(pk, wpack);
-    }
-    k_chain_a<QD + 172><<<tiles, CH_T, CL::A_FLOATS * sizeof(float), s>>>(*in, Q, wpack, P->in_b, xq, x1, qs, saved ? nullptr : qt);
-  } else {
-    k_bwd_prep<<<qb, 256, 0, s>>>(*in, Q, xq, x1);
-    // qs = 0.1 (xq Wq^T + bq)                                                    (scaling: head_dim^-0.5)
-    rc |= sgemm(s, M, QD, QD, xq, QD, 1, P->q_w, 1, QD, qs, QD, 1, P->in_b, 0.1f, false, false);
-    if (!saved) {   // q~_h = qs_h Wk_h   [Q,100] x [100,kdim], both heads in one launch
-      OrcaGemm g[2];
-      for (int h = 0; h < 2; ++h)
-        g[h] = G1(M, kdim, D, qs + h * D, QD, 1, P->k_w + (int64_t)h * D * kdim, kdim, 1, qt + h * kdim, 2 * kdim, 1, nullptr, 1.f);
-      rc |= orca_sgemm_group(s, g, 2, nullptr);
-    }
-  }
-  if (saved) {
-  } else if (K <= 10) k_bwd_attn_fwd<10><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
-  else k_bwd_attn_fwd<ORCA_MAX_K><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
-  if (chain) {
-    const ChainB c{wpack, P->in_b + 2 * QD, P->o_b, P->fc1_b, P->fc2_b, P->ln_w,
-                   grad_out, xbar, invalid, wsum,
-                   x1, ocat, h1, dy, gx, dh1, dx1, docat, dxbar, scaled, dsum, drop ? 1 : 0};
-    k_chain_b<QD + 172><<<tiles, CH_T, CL::B_FLOATS * sizeof(float), s>>>(c, Q);
-  } else {
-    {   // ocat_h = xbar_h Wv_h^T + bv_h  (dropout: + (sum of the head's kept weights) bv_h)
-      OrcaGemm g[2];
-      for (int h = 0; h < 2; ++h)
-        g[h] = G1(M, D, kdim, xbar + h * kdim, 2 * kdim, 1, P->v_w + (int64_t)h * D * kdim, 1, kdim, ocat + h * D, QD, 1,
-                  drop ? nullptr : P->in_b + 2 * QD + h * D, 1.f);
-      rc |= orca_sgemm_group(s, g, 2, nullptr);
-    }
-    if (drop) k_add_scaled_bias<<<ew(Q * QD), 256, 0, s>>>(ocat, Q, wsum, P->in_b + 2 * QD);
-    {   // o = ocat Wo^T + bo -> x1[:, 0:200], zero for invalid queries                 (temporal_attention.py:52)
-      OrcaGemm g = G1(M, QD, QD, ocat, QD, 1, P->o_w, 1, QD, x1, 3 * D, 1, P->o_b, 1.f);
-      g.rowzero = invalid;
-      g.rowzero_n = QD;
-      rc |= orca_sgemm_group(s, &g, 1, nullptr);
-    }
-    // h1 = relu(x1 W1^T + b1), y = h1 W2^T + b2                                     (utils/util.py:22-24)
-    rc |= sgemm(s, M, D, 3 * D, x1, 3 * D, 1, P->fc1_w, 1, 3 * D, h1, D, 1, P->fc1_b, 1.f, false, true);
-    rc |= sgemm(s, M, D, D, h1, D, 1, P->fc2_w, 1, D, y, D, 1, P->fc2_b, 1.f, false, false);
-    k_bwd_ln<<<qb, 256, 0, s>>>(y, grad_out, P->ln_w, Q, dy, gx);
-    {   // fc2: dz1 = (dy W2) where h1 > 0
-      OrcaGemm g = G1(M, D, D, dy, D, 1, P->fc2_w, D, 1, dh1, D, 1, nullptr, 1.f);
-      g.gate = h1;
-      rc |= orca_sgemm_group(s, &g, 1, nullptr);
-    }
-    {   // fc1: dx1 = dz1 W1; do = dx1[:, 0:200] = 0 where the output was zeroed
-      OrcaGemm g = G1(M, 3 * D, D, dh1, D, 1, P->fc1_w, 3 * D, 1, dx1, 3 * D, 1, nullptr, 1.f);
-      g.rowzero = invalid;
-      g.rowzero_n = QD;
-      rc |= orca_sgemm_group(s, &g, 1, nullptr);
-    }
-    // out-proj: docat = do Wo
-    rc |= sgemm(s, M, QD, QD, dx1, 3 * D, 1, P->o_w, QD, 1, docat, QD, 1, nullptr, 1.f, false, false);
-    if (drop)       // docat scaled by the weight sums (the bv gradient's summand), dsum = docat_h . bv_h
-      k_bias_scale_bwd<<<qb, 256, 0, s>>>(docat, Q, wsum, P->in_b + 2 * QD, scaled, dsum);
-    {   // value map: dxbar_h = docat_h Wv_h
-      OrcaGemm g[2];
-      for (int h = 0; h < 2; ++h)
-        g[h] = G1(M, kdim, D, docat + h * D, QD, 1, P->v_w + (int64_t)h * D * kdim, kdim, 1, dxbar + h * kdim, 2 * kdim, 1, nullptr, 1.f);
-      rc |= orca_sgemm_group(s, g, 2, nullptr);
-    }
-  }
   const bool want_t = in->dt && d_time_w;
-  if (K <= 10)
-    k_bwd_attn_bwd<10><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
-  else
-    k_bwd_attn_bwd<ORCA_MAX_K><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
-  if (chain) {
-    k_chain_c<QD + 172><<<tiles, CH_T, CL::C_FLOATS * sizeof(float), s>>>(*in, Q, wpack, dqt, dx1, dq, d_src, d_src_time,
-                                                                       want_t ? tgrad : nullptr);
-  } else {
-    {   // key fold: dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs
-      OrcaGemm g[2];
-      for (int h = 0; h < 2; ++h)
-        g[h] = G1(M, D, kdim, dqt + h * kdim, 2 * kdim, 1, P->k_w + (int64_t)h * D * kdim, 1, kdim, dq + h * D, QD, 1, nullptr, 0.1f);
-      rc |= orca_sgemm_group(s, g, 2, nullptr);
+  if (phases & 1) {
+    // ---- forward recompute, then the data gradients: a chain (fused per 16-row tile when the shapes are the built ones) --
+    const bool chain = chain_usable(d_e, workspace);
+    const unsigned tiles = (unsigned)ceil_div64(Q, 16);
+    using CL = ChainLds<QD + 172>;
+    if (chain) {
+      static bool attr_set[64] = {};
+      if (orca_first_use_on_device(attr_set)) {
+        // (the kernels also hold a few hundred static floats: ask for what each launch uses, not for the whole LDS)
+        ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_chain_a<QD + 172>, hipFuncAttributeMaxDynamicSharedMemorySize, CL::A_FLOATS * (int)sizeof(float)));
+        ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_chain_b<QD + 172>, hipFuncAttributeMaxDynamicSharedMemorySize, CL::B_FLOATS * (int)sizeof(float)));
+        ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_chain_c<QD + 172>, hipFuncAttributeMaxDynamicSharedMemorySize, CL::C_FLOATS * (int)sizeof(float)));
+      }
+      {
+        using CW = ChainW<QD + 172>;
+        const int KDc = QD + 172;
+        ChainPack pk{};
+        int i = 0;
+        pk.j[i++] = chain_pack_job<CW::A1>(P->q_w, 1, QD, 0, QD, QD, true, CW::a1);
+        pk.j[i++] = chain_pack_job<CW::A2>(P->k_w, KDc, 1, D * KDc, KDc, D, false, CW::a2);
+        pk.j[i++] = chain_pack_job<CW::B1>(P->v_w, 1, KDc, D * KDc, D, KDc, true, CW::b1);
+        pk.j[i++] = chain_pack_job<CW::B2>(P->o_w, 1, QD, 0, QD, QD, true, CW::b2);
+        pk.j[i++] = chain_pack_job<CW::B3>(P->fc1_w, 1, 3 * D, 0, D, 3 * D, true, CW::b3);
+        pk.j[i++] = chain_pack_job<CW::B4>(P->fc2_w, 1, D, 0, D, D, true, CW::b4);
+        pk.j[i++] = chain_pack_job<CW::B5>(P->fc2_w, D, 1, 0, D, D, false, CW::b5);
+        pk.j[i++] = chain_pack_job<CW::B6>(P->fc1_w, 3 * D, 1, 0, 3 * D, D, false, CW::b6);
+        pk.j[i++] = chain_pack_job<CW::B7>(P->o_w, QD, 1, 0, QD, QD, false, CW::b7);
+        pk.j[i++] = chain_pack_job<CW::B8>(P->v_w, KDc, 1, D * KDc, KDc, D, false, CW::b8);
+        pk.j[i++] = chain_pack_job<CW::C1>(P->k_w, 1, KDc, D * KDc, D, KDc, true, CW::c1);
+        pk.j[i++] = chain_pack_job<CW::C2>(P->q_w, QD, 1, 0, QD, QD, false, CW::c2);
+        static_assert(CHAIN_PACK_JOBS == 12, "one job per stage");
+        pk.total = CW::total;
+        k_chain_pack<<<(unsigned)ceil_div64((int64_t)CW::total * 64, 256), 256, 0, s>>>(pk, wpack);
+      }
+      k_chain_a<QD + 172><<<tiles, CH_T, CL::A_FLOATS * sizeof(float), s>>>(*in, Q, wpack, P->in_b, xq, x1, qs, saved ? nullptr : qt);
+    } else {
+      k_bwd_prep<<<qb, 256, 0, s>>>(*in, Q, xq, x1);
+      // qs = 0.1 (xq Wq^T + bq)                                                    (scaling: head_dim^-0.5)
+      rc |= sgemm(s, M, QD, QD, xq, QD, 1, P->q_w, 1, QD, qs, QD, 1, P->in_b, 0.1f, false, false);
+      if (!saved) {   // q~_h = qs_h Wk_h   [Q,100] x [100,kdim], both heads in one launch
+        OrcaGemm g[2];
+        for (int h = 0; h < 2; ++h)
+          g[h] = G1(M, kdim, D, qs + h * D, QD, 1, P->k_w + (int64_t)h * D * kdim, kdim, 1, qt + h * kdim, 2 * kdim, 1, nullptr, 1.f);
+        rc |= orca_sgemm_group(s, g, 2, nullptr);
+      }
     }
-    // q projection: dxq = dq Wq
-    rc |= sgemm(s, M, QD, QD, dq, QD, 1, P->q_w, QD, 1, dxq, QD, 1, nullptr, 1.f, false, false);
-    k_bwd_finish<<<ew(Q * D), 256, 0, s>>>(*in, Q, dx1, dxq, d_src, d_src_time, want_t ? tgrad : nullptr);
+    if (saved) {
+    } else if (K <= 10) k_bwd_attn_fwd<10><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
+    else k_bwd_attn_fwd<ORCA_MAX_K><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, xbar, invalid, wsum);
+    if (chain) {
+      const ChainB c{wpack, P->in_b + 2 * QD, P->o_b, P->fc1_b, P->fc2_b, P->ln_w,
+                     grad_out, xbar, invalid, wsum,
+                     x1, ocat, h1, dy, gx, dh1, dx1, docat, dxbar, scaled, dsum, drop ? 1 : 0};
+      k_chain_b<QD + 172><<<tiles, CH_T, CL::B_FLOATS * sizeof(float), s>>>(c, Q);
+    } else {
+      {   // ocat_h = xbar_h Wv_h^T + bv_h  (dropout: + (sum of the head's kept weights) bv_h)
+        OrcaGemm g[2];
+        for (int h = 0; h < 2; ++h)
+          g[h] = G1(M, D, kdim, xbar + h * kdim, 2 * kdim, 1, P->v_w + (int64_t)h * D * kdim, 1, kdim, ocat + h * D, QD, 1,
+                    drop ? nullptr : P->in_b + 2 * QD + h * D, 1.f);
+        rc |= orca_sgemm_group(s, g, 2, nullptr);
+      }
+      if (drop) k_add_scaled_bias<<<ew(Q * QD), 256, 0, s>>>(ocat, Q, wsum, P->in_b + 2 * QD);
+      {   // o = ocat Wo^T + bo -> x1[:, 0:200], zero for invalid queries                 (temporal_attention.py:52)
+        OrcaGemm g = G1(M, QD, QD, ocat, QD, 1, P->o_w, 1, QD, x1, 3 * D, 1, P->o_b, 1.f);
+        g.rowzero = invalid;
+        g.rowzero_n = QD;
+        rc |= orca_sgemm_group(s, &g, 1, nullptr);
+      }
+      // h1 = relu(x1 W1^T + b1), y = h1 W2^T + b2                                     (utils/util.py:22-24)
+      rc |= sgemm(s, M, D, 3 * D, x1, 3 * D, 1, P->fc1_w, 1, 3 * D, h1, D, 1, P->fc1_b, 1.f, false, true);
+      rc |= sgemm(s, M, D, D, h1, D, 1, P->fc2_w, 1, D, y, D, 1, P->fc2_b, 1.f, false, false);
+      k_bwd_ln<<<qb, 256, 0, s>>>(y, grad_out, P->ln_w, Q, dy, gx);
+      {   // fc2: dz1 = (dy W2) where h1 > 0
+        OrcaGemm g = G1(M, D, D, dy, D, 1, P->fc2_w, D, 1, dh1, D, 1, nullptr, 1.f);
+        g.gate = h1;
+        rc |= orca_sgemm_group(s, &g, 1, nullptr);
+      }
+      {   // fc1: dx1 = dz1 W1; do = dx1[:, 0:200] = 0 where the output was zeroed
+        OrcaGemm g = G1(M, 3 * D, D, dh1, D, 1, P->fc1_w, 3 * D, 1, dx1, 3 * D, 1, nullptr, 1.f);
+        g.rowzero = invalid;
+        g.rowzero_n = QD;
+        rc |= orca_sgemm_group(s, &g, 1, nullptr);
+      }
+      // out-proj: docat = do Wo
+      rc |= sgemm(s, M, QD, QD, dx1, 3 * D, 1, P->o_w, QD, 1, docat, QD, 1, nullptr, 1.f, false, false);
+      if (drop)       // docat scaled by the weight sums (the bv gradient's summand), dsum = docat_h . bv_h
+        k_bias_scale_bwd<<<qb, 256, 0, s>>>(docat, Q, wsum, P->in_b + 2 * QD, scaled, dsum);
+      {   // value map: dxbar_h = docat_h Wv_h
+        OrcaGemm g[2];
+        for (int h = 0; h < 2; ++h)
+          g[h] = G1(M, kdim, D, docat + h * D, QD, 1, P->v_w + (int64_t)h * D * kdim, kdim, 1, dxbar + h * kdim, 2 * kdim, 1, nullptr, 1.f);
+        rc |= orca_sgemm_group(s, g, 2, nullptr);
+      }
+    }
+    if (K <= 10)
+      k_bwd_attn_bwd<10><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
+    else
+      k_bwd_attn_bwd<ORCA_MAX_K><<<qb, 256, 0, s>>>(*in, Q, K, d_e, qt, a, dxbar, dqt, d_nbr, d_nbr_time, want_t ? tgrad : nullptr, dsum);
+    if (chain) {
+      k_chain_c<QD + 172><<<tiles, CH_T, CL::C_FLOATS * sizeof(float), s>>>(*in, Q, wpack, dqt, dx1, dq, d_src, d_src_time,
+                                                                         want_t ? tgrad : nullptr);
+    } else {
+      {   // key fold: dqs_h = dq~_h Wk_h^T, dq = 0.1 dqs
+        OrcaGemm g[2];
+        for (int h = 0; h < 2; ++h)
+          g[h] = G1(M, D, kdim, dqt + h * kdim, 2 * kdim, 1, P->k_w + (int64_t)h * D * kdim, 1, kdim, dq + h * D, QD, 1, nullptr, 0.1f);
+        rc |= orca_sgemm_group(s, g, 2, nullptr);
+      }
+      // q projection: dxq = dq Wq
+      rc |= sgemm(s, M, QD, QD, dq, QD, 1, P->q_w, QD, 1, dxq, QD, 1, nullptr, 1.f, false, false);
+      k_bwd_finish<<<ew(Q * D), 256, 0, s>>>(*in, Q, dx1, dxq, d_src, d_src_time, want_t ? tgrad : nullptr);
+    }
+  }
+  if (!(phases & 2)) {
+    if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
+      orca_set_error("orca_tgat_backward: kernel launch failed");
+      return ORCA_EHIP;
+    }
+    return ORCA_OK;
   }
   // ---- backward: every weight gradient (a reduction over the queries) in ONE split-K launch, the bias gradients as a
   // column of ones:  dW2 += dy^T h1, dW1 += dz1^T x1, dWo += do^T ocat, dWv_h += docat_h^T xbar_h, dWk_h += qs_h^T dq~_h

@@ -20,6 +20,7 @@ paths (A, C, train_step) run on coherent replicas with the batch's row writes re
 is the switch from the owner-computes state to that one.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -51,6 +52,10 @@ class OrcaEngine:
     # Path C through the native driver (two layers, one rank): its launches are sized for this many uncached
     # out-of-batch neighbours per batch (their actual number is a device-side count; budget_overflow() reports excess)
     self.native_budget, self.budget_cap = True, 1024
+    # train_step / step_optimizer on two streams: the parameter-gradient reductions and the re-pack after the optimizer
+    # run beside the chain of data gradients and the next batch's first kernels (ORCA_OVERLAP=0: one stream)
+    self.overlap = os.environ.get("ORCA_OVERLAP", "0") != "0"
+    self._ov_mode = int(os.environ.get("ORCA_OVERLAP", "0"))
     self.group = group
     if group is not None:
       import torch.distributed as dist
@@ -126,8 +131,10 @@ class OrcaEngine:
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in (self.prof or {}).items()}
 
   # -------------------------------------------------------------------------------------------
-  def load_state_dict(self, sd):
+  def load_state_dict(self, sd, _time_unchanged=False):
     dev = self.device
+    if getattr(self, "_packed_ready", None) is not None and torch.cuda.current_stream() != getattr(self, "_side", None):
+      self._await_packed()               # a re-pack still running beside this stream writes the same blobs
     if sd is not getattr(self, "params", None):
       sd = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in sd.items()}
       # the raw tensors on the device: what the backward pass reads and an optimizer updates (train_step / refresh)
@@ -140,8 +147,8 @@ class OrcaEngine:
     if first:
       self.time_w, self.time_b = tw.clone(), tb.clone()
       self.att_blobs, self.gru_blob = [None] * self.L, None
-    else:                      # re-pack in place: the native driver holds these addresses
-      self.time_w.copy_(tw)
+    elif not _time_unchanged:  # (step_optimizer with the time encoder frozen: nothing changed them)
+      self.time_w.copy_(tw)    # re-pack in place: the native driver holds these addresses
       self.time_b.copy_(tb)
     pre = "embedding_module.attention_models."
     sds = [{k[len(f"{pre}{i}."):]: v for k, v in sd.items() if k.startswith(f"{pre}{i}.")} for i in range(self.L)]
@@ -156,9 +163,33 @@ class OrcaEngine:
       # get_updated_memory with the current weights on every batch (memory_updater.py:56-78)
       self._invalidate_overlay()
 
-  def refresh(self):
-    """Re-packs the kernels' parameter blobs from self.params (after an optimizer step changed them in place)."""
-    self.load_state_dict(self.params)     # in place: the native driver keeps its blob addresses
+  def refresh(self, beside=False, _time_unchanged=False):
+    """Re-packs the kernels' parameter blobs from self.params (after an optimizer step changed them in place).
+    beside: the re-pack (folds in fp64, fragment orders: seven launches that no kernel of the next batch needs before
+    its GRU) is issued on the engine's second stream, ordered after everything enqueued so far; every method that reads
+    the blobs waits for it (_await_packed), so the next batch's root, sampling and work-list kernels run beside it."""
+    if beside and self.device.type == "cuda" and self.overlap and self._ov_mode in (1, 3):
+      side = self._side_stream()
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        self.load_state_dict(self.params, _time_unchanged=_time_unchanged)
+        ev = torch.cuda.Event()
+        ev.record(side)
+      self._packed_ready = ev
+      return
+    self.load_state_dict(self.params, _time_unchanged=_time_unchanged)     # in place: the native driver keeps its blob addresses
+
+  def _side_stream(self):
+    if getattr(self, "_side", None) is None:
+      self._side = torch.cuda.Stream(device=self.device)
+    return self._side
+
+  def _await_packed(self):
+    """orders the current stream after a re-pack issued beside it (refresh(beside=True)); free when there is none"""
+    ev = getattr(self, "_packed_ready", None)
+    if ev is not None:
+      torch.cuda.current_stream().wait_event(ev)
+      self._packed_ready = None
 
   def set_neighbor_finder(self, csr):
     """tgn_model.py:193-195; csr is an ops.CSR (or a shim NeighborFinder carrying .csr)."""
@@ -316,6 +347,7 @@ class OrcaEngine:
 
   def _step_reuse_native(self, src, dst, neg, ts, eidx, train, gather_output=True):
     """Path B + memory/messages through the C++ driver: begin -> (all-gather) -> layer ... -> finish"""
+    self._await_packed()
     L = _lib.load()
     bs = src.numel()
     Q = 3 * bs
@@ -344,6 +376,7 @@ class OrcaEngine:
   def _step_budget_native(self, src, dst, neg, ts, eidx, train, plan):
     """Path C through the C++ driver (orca_engine_step_budget): the whole batch step on the stream, no host round trip --
     the size of the uncached set stays on the device (the launches are sized for `budget_cap` of them)."""
+    self._await_packed()
     L = _lib.load()
     bs = src.numel()
     Q, K, dev = 3 * bs, self.K, self.device
@@ -434,6 +467,7 @@ class OrcaEngine:
     if self.all_ids is None:
       self.all_ids = torch.arange(self.N, dtype=torch.int64, device=self.device)
     bound = self._build_worklist(None, self.all_ids, self.N)
+    self._await_packed()
     ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory, self.overlay)
     self._set_overlay_complete(True)
 
@@ -471,12 +505,14 @@ class OrcaEngine:
     n32 = ids32.numel() if ids32 is not None else 0
     n64 = ids64.numel() if ids64 is not None else 0
     bound = self._build_worklist(ids32, ids64, n32 + n64)
+    self._await_packed()
     self._timed("gru_update", ops.gru_update, self.gru_blob, self.msg_dim, self.worklist, bound, self.count,
                 self.messages, self.memory, self.overlay)
 
   def _persist_memory(self, ids64):
     """memory_updater.update_memory (:25-39) + memory.clear_messages (memory.py:49-50)."""
     bound = self._build_worklist(None, ids64, ids64.numel())
+    self._await_packed()
     ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory,
                    self.memory, self.last_update, self.msg_ts)
     ops.set_flags(self.pending, ids64=ids64, v=0)
@@ -487,6 +523,7 @@ class OrcaEngine:
     if self.all_ids is None:
       self.all_ids = torch.arange(self.N, dtype=torch.int64, device=self.device)
     bound = self._build_worklist(None, self.all_ids, self.N)
+    self._await_packed()
     ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory,
                    self.memory, self.last_update, self.msg_ts)
     ops.fill_u8(self.pending, 0)
@@ -517,6 +554,7 @@ class OrcaEngine:
       kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
     if drop:
       kw.update(drop)
+    self._await_packed()
     out, _ = self._timed("tgat_forward", ops.tgat_forward, self.att_blobs[layer - 1], self.d_e, Q, self.K, save=save, **kw)
     return out
 
@@ -739,6 +777,7 @@ class OrcaEngine:
         raise OrcaError("OrcaEngine: uniform sampling is wired into Path B (--reuse) and the one-layer exact path only")
       rec = []
       plan = self._dev(cache_plan, torch.int64) if cache_plan is not None else None
+      self._await_packed()
       out = self._embed_budget(nodes, t3, self.L, plan, True, rec=rec)
       cnt_ready = self._cnt_ready
       sl = slice(lo, hi)
@@ -821,6 +860,22 @@ class OrcaEngine:
     want_t = self.train_time_encoder       # (frozen upstream, model/time_encoding.py:20-21: its gradient is not computed)
     d_time = torch.zeros(2, D, dtype=torch.float32, device=dev) if want_t else None
     into_memory = None
+    # The parameter gradients (reductions over the batch's queries: nothing downstream in the backward reads them) are
+    # issued on the second stream once the last attention layer's data gradients are enqueued, and run beside the
+    # scatter into the memory rows, the GRU's backward and the state update; joined before the gradients are handed out.
+    side = self._side_stream() if self.overlap and self._ov_mode in (1, 2) else None
+    deferred = [] if side is not None else None
+    issued, time_grads = [], []
+
+    def issue_deferred():
+      ev = torch.cuda.Event()
+      ev.record()
+      with torch.cuda.stream(side):
+        side.wait_event(ev)
+        for f in deferred:
+          f()
+      issued.extend(deferred)
+      deferred.clear()
     for layer, m, (nbr, eid, dt), tables, sink in reversed(steps):
       p = f"embedding_module.attention_models.{layer - 1}."
       sd = {k[len(p):]: v for k, v in self.params.items() if k.startswith(p)}
@@ -831,12 +886,11 @@ class OrcaEngine:
         kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
       # (sink None: the neighbour rows are detached history rows -- nobody reads their gradient unless --gradient)
       g, d_src, d_nbr, _, _, tw, tb = ops.tgat_backward(sd, self.d_e, m, K, d, want_time_param_grads=want_t, pool=pool, saved=saved,
-                                                        want_d_nbr=sink is not None or self.gradient, **kw)
+                                                        want_d_nbr=sink is not None or self.gradient, deferred=deferred, **kw)
       for k, v in g.items():                           # Path A evaluates a layer once per batch, like Path B
         grads[p + k] = v
       if want_t:
-        d_time[0] += tw
-        d_time[1] += tb
+        time_grads.append((tw, tb))
       if sink == "cat":                                # Path A: the neighbours' rows are embeddings of the level below
         d = torch.cat([d_src, d_nbr])
       elif sink is None:                               # Path B inner layer: history rows are detached (history.py:32-40),
@@ -849,6 +903,8 @@ class OrcaEngine:
           d = d_src + extra[lo:hi]
       else:
         into_memory = (sink, d_src, d_nbr)
+    if deferred:
+      issue_deferred()
     # ---- into the updated-memory rows of the pending ids this slice read, then through the GRU ----
     p = "memory_updater.memory_updater."
     cnt_ready.synchronize()                # distinct pending ids of the overlay work-list: the copy was enqueued right
@@ -858,19 +914,35 @@ class OrcaEngine:
         self._pos = torch.zeros(self.N, dtype=torch.int32, device=dev)
       wl = self.worklist[:cnt]
       ops.index_positions(wl, cnt, None, self._pos)
-      d_upd = torch.zeros(cnt, D, dtype=torch.float32, device=dev)
+      d_upd = pool.take(cnt * D).view(cnt, D)
       (ids_src, ids_nbr), d_src, d_nbr = into_memory
       ops.scatter_add_flagged(d_src, ids_src, self.pending, self._pos, d_upd)
       ops.scatter_add_flagged(d_nbr, ids_nbr, self.pending, self._pos, d_upd)
       gg = ops.gru_backward(self.params[p + "weight_ih"], self.params[p + "weight_hh"], self.params[p + "bias_ih"],
-                            self.params[p + "bias_hh"], wl, self.messages, self.memory, d_upd, pool=pool)
+                            self.params[p + "bias_hh"], wl, self.messages, self.memory, d_upd, pool=pool, deferred=deferred)
       for k, v in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), gg[:4]):
         grads[p + k] = v
+      if deferred:
+        issue_deferred()
     else:
       for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
         grads[p + k] = torch.zeros_like(self.params[p + k])
+    # ---- the state moves on (tgn_model.py:127-141) ----
+    positives = nodes[:2 * bs]
+    if self.world > 1:       # this rank's forward put GRU(message, memory) of ITS pending roots into the overlay: the
+      self._overlay_updated_memory(None, positives)    # other ranks' positives follow (same kernel: same bits as one rank)
+    ops.persist_overlay(positives, self.pending, self.overlay, self.memory, self.last_update, self.msg_ts)
+    ops.set_flags(self.pending, ids64=positives, v=0)
+    ops.message_store(src, dst, eidx, ts, self.memory, self.last_update, self.edge_feats, self.time_w, self.time_b,
+                      self.slot, self._slot_epoch(2 * bs), self.messages, self.msg_ts, self.pending)
     self._grad_pool_floats = pool.asked
+    if side is not None:                   # the parameter gradients are complete from here on
+      torch.cuda.current_stream().wait_stream(side)
+      issued.clear()
     if want_t:
+      for tw, tb in time_grads:
+        d_time[0] += tw
+        d_time[1] += tb
       grads["time_encoder.w.weight"] = d_time[0].view(D, 1)
       if "time_encoder.w.bias" in self.params:
         grads["time_encoder.w.bias"] = d_time[1]
@@ -883,14 +955,6 @@ class OrcaEngine:
         m = grads[k].numel()
         grads[k] = flat[o:o + m].view_as(grads[k])
         o += m
-    # ---- the state moves on (tgn_model.py:127-141) ----
-    positives = nodes[:2 * bs]
-    if self.world > 1:       # this rank's forward put GRU(message, memory) of ITS pending roots into the overlay: the
-      self._overlay_updated_memory(None, positives)    # other ranks' positives follow (same kernel: same bits as one rank)
-    ops.persist_overlay(positives, self.pending, self.overlay, self.memory, self.last_update, self.msg_ts)
-    ops.set_flags(self.pending, ids64=positives, v=0)
-    ops.message_store(src, dst, eidx, ts, self.memory, self.last_update, self.edge_feats, self.time_w, self.time_b,
-                      self.slot, self._slot_epoch(2 * bs), self.messages, self.msg_ts, self.pending)
     return loss, grads
 
   def _fetch_count(self):
@@ -926,7 +990,7 @@ class OrcaEngine:
         g = grads.get(k)
         p.grad = None if g is None else g.reshape(p.shape)
       self._opt.step()
-    self.refresh()
+    self.refresh(beside=True, _time_unchanged=not self.train_time_encoder)
 
   def _dev(self, x, dtype):
     if not isinstance(x, torch.Tensor):

@@ -309,11 +309,15 @@ def _zeros(n, dev, pool):
   return pool.take(n) if pool is not None else torch.zeros(n, dtype=torch.float32, device=dev)
 
 
-def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=None, saved=None, want_d_nbr=True, **kw):
+def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=None, saved=None, want_d_nbr=True,
+                  deferred=None, **kw):
   """orca_tgat_backward.  sd: the layer's raw parameters (keys TGAT_KEYS, fp32 on the device); kw: the fields of
   orca_tgat_inputs of the forward call (mask = the mask BEFORE the forward).  Returns (grads: dict like sd,
   d_src [Q,D], d_nbr [Q*K,D], d_src_time, d_nbr_time, d_time_w, d_time_b) -- the time entries that do not apply
-  to the mode are None."""
+  to the mode are None.  deferred: a list -- only the data gradients are computed now (orca_tgat_backward_phase 1);
+  a callable that issues the parameter gradients (phase 2: grads, d_time_w/b are valid after it) on the then-current
+  stream is appended to the list and keeps the workspace alive; the caller orders that stream after this call and
+  joins it before dropping the callable."""
   dev = grad_out.device
   ps = [sd[k].detach().to(device=dev, dtype=torch.float32).contiguous() for k in TGAT_KEYS]
   gather = kw.get("dt") is not None
@@ -343,7 +347,14 @@ def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=Non
   else:
     d_st = torch.empty((Q, D), dtype=torch.float32, device=dev)
     d_nt = torch.empty((Q * K, D), dtype=torch.float32, device=dev)
-  if saved is not None:
+  if deferred is not None:
+    def run(phases, _keep=(ps, gs, keep, wsp, go, d_src, d_nbr, d_st, d_nt, flat, saved, kw)):
+      check(_lib.load().orca_tgat_backward_phase(ctypes.byref(P), int(d_e), ctypes.byref(inp), int(Q), int(K), ptr(go),
+                                                 ctypes.byref(G), ptr(d_src), ptr(d_nbr), ptr(d_st), ptr(d_nt), ptr(d_tw),
+                                                 ptr(d_tb), ptr(wsp), ptr(saved), phases, stream()), "orca_tgat_backward_phase")
+    run(1)
+    deferred.append(lambda: run(2))
+  elif saved is not None:
     check(_lib.load().orca_tgat_backward_saved(ctypes.byref(P), int(d_e), ctypes.byref(inp), int(Q), int(K), ptr(go),
                                                ctypes.byref(G), ptr(d_src), ptr(d_nbr), ptr(d_st), ptr(d_nt), ptr(d_tw),
                                                ptr(d_tb), ptr(wsp), ptr(saved), stream()), "orca_tgat_backward_saved")
@@ -362,16 +373,19 @@ def gru_pack(weight_ih, weight_hh, bias_ih, bias_hh, device, blob=None):
   n = _lib.load().orca_gru_blob_floats(int(msg_dim))
   if n < 0:
     raise ValueError(f"gru_pack: unsupported message width {msg_dim}")
+  again = blob is not None      # (a blob handed back in was packed here before: orca_gru_repack skips the zero fill)
   if blob is None:
     blob = torch.empty(n, dtype=torch.float32, device=device)
   ts = [t.detach().to(device=device, dtype=torch.float32).contiguous() for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
-  check(_lib.load().orca_gru_pack(int(msg_dim), *(ptr(t) for t in ts), ptr(blob), stream()), "orca_gru_pack")
+  fn = _lib.load().orca_gru_repack if again else _lib.load().orca_gru_pack
+  check(fn(int(msg_dim), *(ptr(t) for t in ts), ptr(blob), stream()), "orca_gru_pack")
   return blob
 
 
-def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_inputs=False, pool=None):
+def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_inputs=False, pool=None, deferred=None):
   """orca_gru_backward.  ids int32 [n] or None (dense rows).  Returns (g_weight_ih, g_weight_hh, g_bias_ih,
-  g_bias_hh, d_x, d_h) -- the last two None unless want_inputs."""
+  g_bias_hh, d_x, d_h) -- the last two None unless want_inputs.  deferred: as in tgat_backward (the parameter
+  gradients are issued by the callable appended to the list)."""
   dev = d_out.device
   ps = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
   flat = _zeros(sum(-(-p.numel() // 64) * 64 for p in ps), dev, pool)    # one fill for the four
@@ -389,6 +403,14 @@ def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_
   d_x = torch.empty((n, msg_dim), dtype=torch.float32, device=dev) if want_inputs else None
   d_h = torch.empty((n, D), dtype=torch.float32, device=dev) if want_inputs else None
   x, h = x.contiguous(), h.contiguous()
+  if deferred is not None:
+    def run(phases, _keep=(ps, gs, ids, x, h, go, d_x, d_h, wsp, flat)):
+      check(_lib.load().orca_gru_backward_phase(int(msg_dim), *(ptr(p) for p in ps), ptr(ids), int(n), ptr(x), ptr(h), ptr(go),
+                                                *(ptr(g) for g in gs), ptr(d_x), ptr(d_h), ptr(wsp), phases, stream()),
+            "orca_gru_backward_phase")
+    run(1)
+    deferred.append(lambda: run(2))
+    return (*gs, d_x, d_h)
   check(_lib.load().orca_gru_backward(int(msg_dim), *(ptr(p) for p in ps), ptr(ids), int(n), ptr(x), ptr(h), ptr(go),
                                       *(ptr(g) for g in gs), ptr(d_x), ptr(d_h), ptr(wsp), stream()), "orca_gru_backward")
   return (*gs, d_x, d_h)

@@ -137,6 +137,20 @@ def test_attention_backward_gather_mode(ops, golden, d_e, K, Q):
     assert_close_fp32(d_tb.cpu().numpy(), bt.grad.numpy(), TOL, f"gather d_time_b ({mode})")
     # padded slots get exactly zero
     assert float(d_nbr.view(Q, K, 100)[torch.from_numpy(nbr == 0).to(DEV)].abs().max()) == 0.0
+    # the same call in two parts (orca_tgat_backward_phase): data gradients now, the parameter gradients later from a
+    # second stream ordered after it -- the same bits
+    later = []
+    two = ops.tgat_backward(dsd, d_e, Q, K, R.to(DEV), want_time_param_grads=True, saved=saved, deferred=later, **inputs)
+    assert len(later) == 1
+    assert torch.equal(two[1], d_src) and torch.equal(two[2], d_nbr)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      later[0]()
+    torch.cuda.current_stream().wait_stream(side)
+    for k in sd:
+      assert torch.equal(two[0][k], grads[k]), f"two-phase grad {k} ({mode})"
+    assert torch.equal(two[5], d_tw) and torch.equal(two[6], d_tb)
 
 
 def test_attention_backward_errors(ops, golden):
@@ -171,6 +185,13 @@ def test_gru_backward(ops, msg_dim, n, gather):
     assert_close_fp32(t.cpu().numpy(), Pg[k].grad.numpy(), TOL, "gru grad " + k)
   assert_close_fp32(got[4].cpu().numpy(), xr.grad.numpy(), TOL, "gru d_x")
   assert_close_fp32(got[5].cpu().numpy(), hr.grad.numpy(), TOL, "gru d_h")
+  later = []       # in two parts (orca_gru_backward_phase): the same bits
+  two = ops.gru_backward(P["weight_ih"].to(DEV), P["weight_hh"].to(DEV), P["bias_ih"].to(DEV), P["bias_hh"].to(DEV),
+                         ids.to(DEV) if gather else None, x.to(DEV), h.to(DEV), R.to(DEV), want_inputs=True, deferred=later)
+  assert torch.equal(two[4], got[4]) and torch.equal(two[5], got[5])
+  later[0]()
+  for a, b in zip(two[:4], got[:4]):
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("reuse,L,bs,drop,hgrad,budget", [

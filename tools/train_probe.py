@@ -33,3 +33,12 @@ for b in range(10, 30):
   t_step += t1 - t0
   t_opt += t2 - t1
 print(f"train_step {1e3 * t_step / 20:.2f} ms   optimizer+refresh {1e3 * t_opt / 20:.2f} ms   loss {float(loss):.4f}")
+# the whole iteration without a sync in between (what bench.py's train_step line times)
+neg = torch.randint(1, N + 1, (140 * bs,), device=dev)
+for rep in range(3):
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for b in range(30 + rep * 30, 60 + rep * 30):
+    eng.step_optimizer(eng.train_step(*batch(b))[1])
+  torch.cuda.synchronize()
+  print(f"pipelined: {1e3 * (time.perf_counter() - t0) / 30:.3f} ms per training iteration")
