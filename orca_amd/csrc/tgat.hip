@@ -88,10 +88,23 @@ __device__ __forceinline__ void fold_tile(int m0, int n0, int M, int N, GA A, GB
   const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
   const int m = m0 + r < M ? m0 + r : M - 1, n = n0 + r < N ? n0 + r : N - 1;     // clamped, never skipped
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-  // (fully unrolled: every operand is requested before the first product; with a loop left over, each load is waited
-  // for where it is issued -- 29 us for the K = 200 product instead of 4)
+  // (every operand of up to 25 steps is requested before the first product, and the scheduler is told to leave it so:
+  // with a loop left over, or with the loads sunk to their products, each load is waited for where it is issued -- 29 us
+  // for the K = 200 product instead of 4)
+  constexpr int STEPS = K / 4, CH = 25;
+  static_assert(K % 4 == 0, "whole MFMA steps");
 #pragma unroll
-  for (int k0 = 0; k0 < K; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A(m, k0 + kq), B(k0 + kq, n), acc, 0, 0, 0);
+  for (int c0 = 0; c0 < STEPS; c0 += CH) {
+    double a[CH], b[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      if (c0 + i < STEPS) { a[i] = A(m, 4 * (c0 + i) + kq); b[i] = B(4 * (c0 + i) + kq, n); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      if (c0 + i < STEPS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     if (m0 + 4 * i + kq < M && n0 + r < N) store(m0 + 4 * i + kq, n0 + r, acc[i]);
@@ -191,9 +204,18 @@ __device__ __forceinline__ void fold_qk_tile(int w, const float* __restrict__ q_
   if (w >= 2 * mtc * FOLD_T100) return;
   const int h = w / (mtc * FOLD_T100), mt = (w / FOLD_T100) % mtc, nt = w % FOLD_T100;
   const double scale = (double)0.1f;
+  // (one unconditional load per operand: the choice is made on the address, or after both loads -- a load under a
+  // lane-dependent branch is waited for where it stands, and 25 such steps in a row were 12 of this launch's 18 us)
   fold_tile<D>(mt * 16, nt * 16, kdim + 1, D + 1,
-               [&](int c, int d) { return (double)(c < kdim ? k_w[(int64_t)(h * D + d) * kdim + c] : in_b[QD + h * D + d]); },
-               [&](int d, int s_) { return s_ < D ? (double)q_w[(int64_t)(h * D + d) * QD + s_] : t[h * D + d]; },
+               [&](int c, int d) {
+                 const float* p = c < kdim ? k_w + (int64_t)(h * D + d) * kdim + c : in_b + QD + h * D + d;
+                 return (double)*p;
+               },
+               [&](int d, int s_) {
+                 const float qv = q_w[(int64_t)(h * D + d) * QD + (s_ < D ? s_ : D - 1)];
+                 const double tv = t[h * D + d];
+                 return s_ < D ? (double)qv : tv;
+               },
                [&](int c, int s_, double v) {
                  if (s_ < D) A[((int64_t)h * (kdim + 1) + c) * D + s_] = (float)(scale * v);
                  else a[h * KP + c] = (float)(scale * v);

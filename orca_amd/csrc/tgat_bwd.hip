@@ -677,6 +677,29 @@ __device__ __forceinline__ float wave_max_f(float v) {
 }
 
 // the slots of one query as the forward kernel reads them (lane j = slot j)
+// lane j's value as a wave-uniform scalar (j uniform): v_readlane into an SGPR.  __shfl is an LDS round trip per call
+// (ds_bpermute) and leaves the result -- here row numbers that become load addresses -- in vector registers: the
+// attention kernels below made 219 of them per query and kept a 64-bit address pair per row load (62 spilled VGPRs).
+__device__ __forceinline__ int lane_value(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ float lane_value(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+// sum over the wave on the DPP path (an inclusive scan inside each row of 16 lanes, then the row totals passed on):
+// six dependent VALU adds instead of six LDS round trips; the total is read from lane 63 as a uniform scalar.
+// (Another order of additions than wave_sum's butterfly: used by the attention backward only.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_scalar(float v) {
+  v = dpp_add<0x111, 0xf>(v);      // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);      // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);      // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row holds the row's sum
+  v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+  return lane_value(v, 63);
+}
 struct Slots {
   int nrow, erow, ovl;
   float dt;
@@ -716,18 +739,20 @@ __device__ __forceinline__ TimeCols load_time_cols(const orca_tgat_inputs& in, i
 }
 __device__ __forceinline__ void key_row(float (&x)[NS], const orca_tgat_inputs& in, const Slots& S, const TimeCols& tc,
                                         int64_t q, int j, int K, int d_e, int lane) {
-  const int nr = __shfl(S.nrow, j, 64), er = __shfl(S.erow, j, 64), ov = __shfl(S.ovl, j, 64);
-  const float dt = __shfl(S.dt, j, 64);
-  const float* np = (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D;
+  const int nr = lane_value(S.nrow, j), er = lane_value(S.erow, j), ov = lane_value(S.ovl, j);      // (j is wave-uniform)
+  const float dt = lane_value(S.dt, j);
+  const float* np = (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D;      // scalar bases, per-lane 32-bit offsets
   const float* ep = in.edge_table + (int64_t)er * d_e;
   const bool hi = lane + 64 < D;
-  x[0] = np[lane];
-  x[1] = np[hi ? lane + 64 : 0];
+  // (a uniform base plus an UNSIGNED 32-bit byte offset is what selects the scalar-base form of the load)
+  auto at = [](const float* base, unsigned col) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + col * 4u); };
+  x[0] = at(np, (unsigned)lane);
+  x[1] = at(np, hi ? (unsigned)lane + 64u : 0u);
   if (!hi) x[1] = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) {
     const int c = lane + 64 * i;
-    x[2 + i] = ep[c < d_e ? c : 0];
+    x[2 + i] = at(ep, c < d_e ? (unsigned)c : 0u);
     if (c >= d_e) x[2 + i] = 0.f;
   }
   if (in.dt) {
@@ -966,17 +991,17 @@ __global__ __launch_bounds__(256, 4) void k_bwd_attn_bwd(orca_tgat_inputs in, in
       for (int s = 0; s < NS; ++s) { p0[u] += x[u][s] * g0[s]; p1[u] += x[u][s] * g1[s]; }
     }
 #pragma unroll
-    for (int u = 0; u < AF_ROWS; ++u) { p0[u] = wave_sum(p0[u]); p1[u] = wave_sum(p1[u]); }
+    for (int u = 0; u < AF_ROWS; ++u) { p0[u] = wave_sum_scalar(p0[u]); p1[u] = wave_sum_scalar(p1[u]); }
     if (jb == 0) {
-      z0 = (p0[0] + ds0) * __shfl(m0, 0, 64);
-      z1 = (p1[0] + ds1) * __shfl(m1, 0, 64);
+      z0 = (p0[0] + ds0) * lane_value(m0, 0);
+      z1 = (p1[0] + ds1) * lane_value(m1, 0);
     }
 #pragma unroll
     for (int u = 0; u < AF_ROWS; ++u) {
       const bool ok = jb + u < K;
       const int j = ok ? jb + u : 0;
-      const float w0 = ok ? __shfl(a0, j, 64) : 0.f, w1 = ok ? __shfl(a1, j, 64) : 0.f;
-      const float d0 = (p0[u] + ds0) * __shfl(m0, j, 64) - z0, d1 = (p1[u] + ds1) * __shfl(m1, j, 64) - z1;
+      const float w0 = ok ? lane_value(a0, j) : 0.f, w1 = ok ? lane_value(a1, j) : 0.f;
+      const float d0 = (p0[u] + ds0) * lane_value(m0, j) - z0, d1 = (p1[u] + ds1) * lane_value(m1, j) - z1;
       if (lane == jb + u) { da0 = d0; da1 = d1; }
       const float e0 = w0 * d0, e1 = w1 * d1;
 #pragma unroll
@@ -986,7 +1011,7 @@ __global__ __launch_bounds__(256, 4) void k_bwd_attn_bwd(orca_tgat_inputs in, in
       }
     }
   }
-  const float c0 = wave_sum(a0 * da0), c1 = wave_sum(a1 * da1);
+  const float c0 = wave_sum_scalar(a0 * da0), c1 = wave_sum_scalar(a1 * da1);
   const float s0 = a0 * (da0 - c0), s1 = a1 * (da1 - c1);      // lane j: ds_hj
   const float aw0 = a0 * m0, aw1 = a1 * m1;
 #pragma unroll
@@ -1008,8 +1033,8 @@ __global__ __launch_bounds__(256, 4) void k_bwd_attn_bwd(orca_tgat_inputs in, in
   // frozen: d_nbr == NULL skips 400 B of stores per slot)
   if (!d_nbr && !d_nbr_time && !tgrad) return;
   for (int j = 0; j < K; ++j) {
-    const float w0 = __shfl(aw0, j, 64), w1 = __shfl(aw1, j, 64), e0 = __shfl(s0, j, 64), e1 = __shfl(s1, j, 64);
-    const float dt = __shfl(S.dt, j, 64);
+    const float w0 = lane_value(aw0, j), w1 = lane_value(aw1, j), e0 = lane_value(s0, j), e1 = lane_value(s1, j);
+    const float dt = lane_value(S.dt, j);
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       const int sn = h2, st = 2 + MAXE + h2;
