@@ -488,6 +488,18 @@ int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64_t* dst, 
  * (callers with several ranks all-gather emb[layer&1] first), then attention over the pulled rows for the
  * slice -> emb[(layer+1)&1][lo:hi).  embedding_module.py:103-113,177-181 */
 int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t hi, void* stream);
+/* Training capture for the steps that follow (train.py:206-237: the forward of a training batch keeps its autograd
+ * graph alive and touches no table before loss.backward() has run).  on != 0: the attention calls of
+ * orca_engine_begin / orca_engine_layer write what orca_tgat_backward_saved reads into saved[l] (layer l + 1 of the
+ * model; orca_tgat_saved_floats(d_e, 3 * bs, K) floats each; entries or the array may be NULL) and apply attention
+ * dropout (dropout_p, dropout_seeds[l], query numbering from 0; train.py:30), and the batch's row writes -- memory
+ * persist, raw-message store -- are not fused into those kernels: orca_engine_finish performs them, and the caller
+ * issues it after the backward has read memory / messages / overlay.  One rank, whole batch, train order, with
+ * overlay_complete cleared (the per-batch work-list `worklist` / `count` is what the GRU's backward walks).
+ * on == 0: back to the plain step. */
+int orca_engine_train_capture(orca_engine_t* e, int on, float* const* saved, float dropout_p,
+                              const uint64_t* dropout_seeds);
+
 /* Memory persist for the batch's positives and raw-message build + store, in the train or eval order the
  * batch was begun with.  tgn_model.py:127-145 */
 int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* eidx,

@@ -114,6 +114,7 @@ SIGNATURES = {
     "orca_engine_take_epochs": (i64, [vp, i64]),
     "orca_engine_begin": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
     "orca_engine_layer": (i32, [vp, i32, i64, i64, vp]),
+    "orca_engine_train_capture": (i32, [vp, i32, vp, ctypes.c_float, vp]),
     "orca_engine_finish": (i32, [vp, vp, vp, vp, vp, vp]),
     "orca_engine_apply": (i32, [vp, vp]),
     "orca_engine_xm_chunk_words": (i64, [i64]),

@@ -46,6 +46,13 @@ struct orca_engine {
   int profile;         // > 0: every profile-th step has HIP events attached to its sampler / GRU / attention launches
   int64_t step;        // steps begun since profiling was switched on
   bool timed_step;     // this step is one of those
+  // Training capture (orca_engine_train_capture): the attention calls of begin() / layer() keep what the backward reads
+  // (saved[l]) and apply dropout; the row writes of the batch (memory persist, raw-message store) are left to finish(),
+  // which the caller issues after the backward has read the tables.
+  bool capture;
+  float* cap_saved[ORCA_ENGINE_MAX_LAYERS];
+  float cap_p;
+  uint64_t cap_seed[ORCA_ENGINE_MAX_LAYERS];
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ORCA_PROF_CLASSES];
 };
 
@@ -560,6 +567,42 @@ ORCA_API int orca_engine_set_sampling(orca_engine_t* e, int mode, uint64_t seed)
   return ORCA_OK;
 }
 
+namespace {
+// the save pointers and dropout fields of attention layer index l (0-based) of a captured training step
+void capture_side(const orca_engine_t* e, int l, int64_t n, orca_tgat_inputs& in, orca_tgat_side& side) {
+  if (e->cap_saved[l]) {
+    const orca_saved_layout SL = orca_saved(e->d.d_e, n, e->d.K);
+    float* sv = e->cap_saved[l];
+    side.save_qt = sv + SL.qt; side.save_a = sv + SL.a; side.save_xbar = sv + SL.xbar;
+    side.save_wsum = sv + SL.wsum; side.save_invalid = sv + SL.invalid;
+  }
+  if (e->cap_p > 0.f) {
+    in.dropout_p = e->cap_p;
+    in.dropout_seed = e->cap_seed[l];
+    in.dropout_q0 = 0;
+  }
+}
+}  // namespace
+
+ORCA_API int orca_engine_train_capture(orca_engine_t* e, int on, float* const* saved, float dropout_p,
+                                       const uint64_t* dropout_seeds) {
+  ORCA_REQUIRE(e, "orca_engine_train_capture: null handle");
+  e->capture = on != 0;
+  e->cap_p = 0.f;
+  for (int l = 0; l < ORCA_ENGINE_MAX_LAYERS; ++l) { e->cap_saved[l] = nullptr; e->cap_seed[l] = 0; }
+  if (!on) return ORCA_OK;
+  ORCA_REQUIRE(e->d.world <= 1, "orca_engine_train_capture: one rank only (several ranks back-propagate slices: the "
+               "dispatched path)");
+  ORCA_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seeds),
+               "orca_engine_train_capture: dropout_p=%g needs seeds and must lie in [0,1)", (double)dropout_p);
+  e->cap_p = dropout_p;
+  for (int l = 0; l < e->d.n_layers; ++l) {
+    if (saved) e->cap_saved[l] = saved[l];
+    if (dropout_seeds) e->cap_seed[l] = dropout_seeds[l];
+  }
+  return ORCA_OK;
+}
+
 ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
                                const int64_t* eidx, const double* ts, int64_t bs, int64_t lo, int64_t hi, int train,
                                void* stream_) {
@@ -723,6 +766,13 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     side.push_table = d.hist[0]; side.push_ids = d.nodes; side.push_winner = d.winners;
     e->pushed_layer = 1;
   }
+  if (e->capture) {
+    ORCA_REQUIRE(full && lazy, "orca_engine_begin: training capture needs the whole batch on this rank, train order and the "
+                 "per-batch work-list (clear overlay_complete first)");
+    side.persist_memory = nullptr; side.persist_last_update = nullptr; side.persist_msg_ts = nullptr; side.persist_n = 0;
+    e->persist_done = false;
+    capture_side(e, 0, n, in, side);
+  }
   // owner-computes step: rank-major rows (3 * per rows per rank) instead of the batch's root order
   float* out = d.emb[0] + (e->sharded ? 3 * e->per * d.rank : lo) * ORCA_D;
   Timed t(e, ORCA_PROF_TGAT, stream);
@@ -769,6 +819,7 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
   }
   // train order, whole batch on this rank, memory already persisted by layer 1: the last layer reads none of the
   // memory / message tables, so its waves also build and store the raw messages (tgn_model.py:131-141)
+  if (e->capture) capture_side(e, layer - 1, hi - lo, in, side);
   if (layer == d.n_layers && lo == 0 && hi == e->Q && e->train && e->persist_done && e->winners_valid && e->eidx) {
     side.store_bs = e->bs; side.store_nodes = d.nodes; side.store_ts = d.qts; side.store_eidx = e->eidx;
     side.store_winner = d.winners + d.q_max;

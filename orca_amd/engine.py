@@ -52,6 +52,7 @@ class OrcaEngine:
     # Path C through the native driver (two layers, one rank): its launches are sized for this many uncached
     # out-of-batch neighbours per batch (their actual number is a device-side count; budget_overflow() reports excess)
     self.native_budget, self.budget_cap = True, 1024
+    self.native_train = os.environ.get("ORCA_NATIVE_TRAIN", "1") != "0"   # train_step's forward through the C++ driver
     # train_step / step_optimizer on two streams: the parameter-gradient reductions and the re-pack after the optimizer
     # run beside the chain of data gradients and the next batch's first kernels (ORCA_OVERLAP=0: one stream)
     self.overlap = os.environ.get("ORCA_OVERLAP", "0") != "0"
@@ -758,11 +759,18 @@ class OrcaEngine:
     self.sync_replicas()
     self._set_overlay_complete(False)
     bs = src.numel()
-    nodes, nodes32, t3 = ops.build_roots(src.contiguous(), dst.contiguous(), neg.contiguous(), ts.contiguous())
-    Q = nodes.numel()
+    src, dst, neg, ts, eidx = src.contiguous(), dst.contiguous(), neg.contiguous(), ts.contiguous(), eidx.contiguous()
+    native_fwd = self.reuse and self._train_native_ok()      # (the driver's first kernel also builds the roots)
+    if native_fwd:
+      nodes = nodes32 = t3 = my_nodes = None
+      Q = 3 * bs
+    else:
+      nodes, nodes32, t3 = ops.build_roots(src, dst, neg, ts)
+      Q = nodes.numel()
     lo, hi, per = self._slice(Q)
-    my_nodes = nodes[lo:hi]
-    n = my_nodes.numel()
+    if nodes is not None:
+      my_nodes = nodes[lo:hi]
+    n = hi - lo
     K = self.K
     # ---- forward, keeping what the backward re-reads (the tables are not touched before it has run).  steps:
     # per attention call (layer, rows, sample, inputs of orca_tgat_inputs that differ between the paths) ----
@@ -790,6 +798,15 @@ class OrcaEngine:
                         (ids64[sl], smp[0].reshape(-1))))
         else:
           steps.append((layer, n, smp, dict(src_table=src_l[sl], nbr_table=h, nbr_idx=smp[0], **dk), None))
+    elif native_fwd:                                     # the same forward issued by the C++ driver (below)
+      my32, nbr, eid, dt, embs, sv, cnt_ready = self._train_forward_native(src, dst, neg, ts, eidx)
+      nodes = my_nodes = self._w["nodes"][:Q]
+      steps.append((1, n, (nbr, eid, dt), dict(src_table=self.memory, src_idx=my32, nbr_table=self.memory, nbr_idx=nbr,
+                                               saved=sv[0], **self._dropout_kw(1, 0)), (my_nodes, nbr.view(-1))))
+      for layer in range(2, self.L + 1):
+        steps.append((layer, n, (nbr, eid, dt), dict(src_table=embs[layer - 2], nbr_table=self.hist[layer - 2], nbr_idx=nbr,
+                                                     saved=sv[layer - 1], **self._dropout_kw(layer, 0)), None))
+      emb = embs[self.L - 1]
     elif self.reuse:                                     # embedding_module.py:154-182
       nbr, eid, dt = self._sample(my_nodes, t3[lo:hi], q0=lo)
       self._overlay_updated_memory(nbr, my_nodes)
@@ -929,12 +946,15 @@ class OrcaEngine:
         grads[p + k] = torch.zeros_like(self.params[p + k])
     # ---- the state moves on (tgn_model.py:127-141) ----
     positives = nodes[:2 * bs]
-    if self.world > 1:       # this rank's forward put GRU(message, memory) of ITS pending roots into the overlay: the
-      self._overlay_updated_memory(None, positives)    # other ranks' positives follow (same kernel: same bits as one rank)
-    ops.persist_overlay(positives, self.pending, self.overlay, self.memory, self.last_update, self.msg_ts)
-    ops.set_flags(self.pending, ids64=positives, v=0)
-    ops.message_store(src, dst, eidx, ts, self.memory, self.last_update, self.edge_feats, self.time_w, self.time_b,
-                      self.slot, self._slot_epoch(2 * bs), self.messages, self.msg_ts, self.pending)
+    if native_fwd:           # persist from the overlay + raw-message store with the winners begin() elected: two launches
+      check(_lib.load().orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), stream()), "orca_engine_finish")
+    else:
+      if self.world > 1:     # this rank's forward put GRU(message, memory) of ITS pending roots into the overlay: the
+        self._overlay_updated_memory(None, positives)  # other ranks' positives follow (same kernel: same bits as one rank)
+      ops.persist_overlay(positives, self.pending, self.overlay, self.memory, self.last_update, self.msg_ts)
+      ops.set_flags(self.pending, ids64=positives, v=0)
+      ops.message_store(src, dst, eidx, ts, self.memory, self.last_update, self.edge_feats, self.time_w, self.time_b,
+                        self.slot, self._slot_epoch(2 * bs), self.messages, self.msg_ts, self.pending)
     self._grad_pool_floats = pool.asked
     if side is not None:                   # the parameter gradients are complete from here on
       torch.cuda.current_stream().wait_stream(side)
@@ -956,6 +976,47 @@ class OrcaEngine:
         grads[k] = flat[o:o + m].view_as(grads[k])
         o += m
     return loss, grads
+
+  def _train_native_ok(self):
+    """Path B's training forward through the C++ driver: one rank, at most two layers (the driver's two embedding
+    buffers alternate: a third layer would overwrite the first layer's output, which the backward of layer 2 reads),
+    no --gradient bookkeeping, no per-kernel host timing."""
+    return (self.native_train and self.world == 1 and self.L <= 2 and not self.gradient and self.prof is None
+            and self.budget == 0)
+
+  def _train_forward_native(self, src, dst, neg, ts, eidx):
+    """The forward of a Path B training batch as the native step issues it (orca_engine_begin / orca_engine_layer with
+    orca_engine_train_capture): roots, sampling, the work-list claims and both last-occurrence elections in ONE launch
+    (k_begin_queries) instead of six, the history push inside attention layer 1; the attention calls keep what the
+    backward reads and apply dropout, and no table row is written -- train_step ends with orca_engine_finish.
+    Returns (root ids int32, nbr, eid, dt, [layer outputs], [saved buffers], the count-copy event)."""
+    L = _lib.load()
+    bs = src.numel()
+    Q, K = 3 * bs, self.K
+    self._ensure_native(Q)
+    self._await_packed()
+    st = stream()
+    if self.sampling == "uniform":
+      check(L.orca_engine_set_sampling(self._native, 1, self._step_seed()), "orca_engine_set_sampling")
+    n_sv = L.orca_tgat_saved_floats(self.d_e, Q, K)
+    cache = getattr(self, "_cap_saved", None)
+    if cache is None or cache[0] != (Q, self.L):
+      cache = self._cap_saved = ((Q, self.L), [torch.empty(n_sv, dtype=torch.float32, device=self.device) for _ in range(self.L)])
+    sv = cache[1]
+    saved_p = (_lib.vp * self.L)(*[ptr(t) for t in sv])
+    seeds = (ctypes.c_uint64 * self.L)(*[self._dropout_kw(l + 1, 0).get("dropout_seed", 0) for l in range(self.L)])
+    check(L.orca_engine_train_capture(self._native, 1, saved_p, float(self.dropout), seeds), "orca_engine_train_capture")
+    try:
+      check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, 0, Q, 1, st), "orca_engine_begin")
+      cnt_ready = self._fetch_count()
+      for layer in range(2, self.L + 1):
+        check(L.orca_engine_layer(self._native, layer, 0, Q, st), "orca_engine_layer")
+    finally:
+      L.orca_engine_train_capture(self._native, 0, None, 0.0, None)
+    w = self._w
+    view = lambda t: t[:Q * K].view(Q, K)
+    embs = [w["emb"][l & 1][:Q] for l in range(self.L)]
+    return w["nodes32"][:Q], view(w["nbr"]), view(w["eid"]), view(w["dt"]), embs, sv, cnt_ready
 
   def _fetch_count(self):
     """starts the copy of the work-list count to pinned host memory; the returned event completes with it"""

@@ -390,6 +390,45 @@ def test_optimizer_step_and_refresh(ops):
   assert torch.equal(a, c) and torch.equal(eng.memory, fresh.memory) and torch.equal(eng.messages, fresh.messages)
 
 
+@pytest.mark.parametrize("drop,sampling", [(0.0, "recent"), (0.4, "recent"), (0.0, "uniform")])
+def test_train_step_native_forward_equals_dispatched(ops, drop, sampling):
+  """train_step's Path B forward through the C++ driver (orca_engine_train_capture + begin / layer / finish) against the
+  Python-dispatched kernels: same loss and tables to the bit (row-wise kernels, same inputs), gradients to rounding
+  (the work-list's order -- appended with atomics -- is the order the GRU's parameter gradients are summed in)."""
+  from orca_amd import synth
+  from orca_amd.engine import OrcaEngine
+  N, E, bs, K, d_e = 1500, 30000, 150, 10, 172
+  src, dst, eidx, ts = synth.powerlaw_graph(N, E, "cuda:0", seed=8)
+  ef = synth.edge_features(E, d_e, "cuda:0")
+  sd = synth.tgn_state_dict(d_e, 2, seed=5)
+  csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
+  engs = []
+  for native in (True, False):
+    e = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=0, device="cuda:0", dropout=drop, sampling=sampling, seed=11)
+    e.set_neighbor_finder(csr)
+    e.native_train = native
+    engs.append(e)
+  assert engs[0]._train_native_ok() and not engs[1]._train_native_ok()
+  g = torch.Generator(device="cuda:0")
+  g.manual_seed(2)
+  for b in range(4):
+    s0 = 20000 + b * bs
+    bt = (src[s0:s0 + bs], dst[s0:s0 + bs], torch.randint(1, N + 1, (bs,), generator=g, device="cuda:0"), ts[s0:s0 + bs],
+          eidx[s0:s0 + bs])
+    (la, ga), (lb, gb) = (e.train_step(*bt) for e in engs)
+    assert float(la) == float(lb), (b, float(la), float(lb))
+    assert set(ga) == set(gb)
+    for k in ga:
+      assert_close_fp32(ga[k].cpu().numpy(), gb[k].cpu().numpy(), 2e-6, f"batch {b} grad {k}")
+    for name in ("memory", "last_update", "messages", "msg_ts", "pending"):
+      assert torch.equal(getattr(engs[0], name), getattr(engs[1], name)), (b, name)
+    assert torch.equal(engs[0].hist[0], engs[1].hist[0]), b
+  # and an inference step after the training steps reads the same state
+  nb = (src[25000:25000 + bs], dst[25000:25000 + bs], torch.randint(1, N + 1, (bs,), generator=g, device="cuda:0"),
+        ts[25000:25000 + bs], eidx[25000:25000 + bs])
+  assert torch.equal(engs[0].compute_temporal_embeddings(*nb, False), engs[1].compute_temporal_embeddings(*nb, False))
+
+
 @pytest.mark.parametrize("tag", ["de172_K10_", "de4_K20_"])
 def test_attention_dropout_forward_and_backward_vs_oracle(ops, golden, tag):
   """Attention-weight dropout (nn.MultiheadAttention(dropout=p), model/temporal_attention.py:17-21; train.py:30
