@@ -352,6 +352,12 @@ int orca_gather_rows(const float* table, int64_t n_rows, int64_t width, const in
 int orca_index_positions(const int32_t* list, int64_t n, const int32_t* n_dev, int32_t* pos, int64_t n_nodes, void* stream);
 int orca_scatter_add_flagged(const float* rows, const int64_t* idx64, const int32_t* idx32, int64_t n,
                              const uint8_t* flags, const int32_t* pos, int64_t n_nodes, float* dst, void* stream);
+/* two lists into the same dst in one launch (the gradients of the source rows and of the neighbour rows of attention
+ * layer 1 both flow into the updated-memory rows, embedding_module.py:159-175): same result as two calls up to the
+ * order of the floating-point additions */
+int orca_scatter_add_flagged_pair(const float* rows_a, const int64_t* idx64_a, const int32_t* idx32_a, int64_t n_a,
+                                  const float* rows_b, const int64_t* idx64_b, const int32_t* idx32_b, int64_t n_b,
+                                  const uint8_t* flags, const int32_t* pos, int64_t n_nodes, float* dst, void* stream);
 /* find_uncached_out_of_batch_neighbors (modules/embedding_module.py:200-212): the distinct ids of nbr [n_nbr] (int32,
  * the sampled neighbours) that are not among batch_nodes [n_batch] and have cache_flag[id] == 0, ascending, WITHOUT
  * the first of them (the reference's `[1:]`, which assumes it is the padding id 0: SURVEY H8) -> out[0 .. *count),

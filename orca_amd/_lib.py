@@ -72,6 +72,7 @@ SIGNATURES = {
     "orca_tgat_pack_layers": (i32, [i32, i32, vp, vp, vp, i32, vp]),
     "orca_index_positions": (i32, [vp, i64, vp, vp, i64, vp]),
     "orca_scatter_add_flagged": (i32, [vp, vp, vp, i64, vp, vp, i64, vp, vp]),
+    "orca_scatter_add_flagged_pair": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp]),
     "orca_gru_backward_workspace_floats": (i64, [i32, i64]),
     "orca_gru_backward": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 11),
     "orca_gru_backward_phase": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 10 + [i32, vp]),

@@ -202,17 +202,24 @@ __global__ void k_index_positions(const int32_t* __restrict__ list, int64_t n, c
 // 256-CU chip).  The LDS and the global adds are separate instructions (one pointer for both is a flat atomic).
 constexpr int SCAT_ROWS = 128, SCAT_HASH = 512, SCAT_U = 4;
 template <int SCAT_CHUNK>
-__global__ __launch_bounds__(1024) void k_scatter_add_flagged(const float* __restrict__ rows, const int64_t* __restrict__ idx64,
-                                                              const int32_t* __restrict__ idx32, int64_t n,
+__global__ __launch_bounds__(1024) void k_scatter_add_flagged(const float* rows, const int64_t* idx64,
+                                                              const int32_t* idx32, int64_t n,
                                                               const uint8_t* __restrict__ flags,
                                                               const int32_t* __restrict__ pos, int64_t n_nodes,
-                                                              float* __restrict__ dst) {
+                                                              float* __restrict__ dst, int blocks1 = 0x7fffffff,
+                                                              const float* rows2 = nullptr, const int64_t* idx64_2 = nullptr,
+                                                              const int32_t* idx32_2 = nullptr, int64_t n2 = 0) {
   constexpr int ROWS = SCAT_CHUNK < SCAT_ROWS ? SCAT_CHUNK : SCAT_ROWS;     // accumulator rows
   __shared__ float acc[ROWS][D];
   __shared__ int keys[SCAT_HASH], vals[SCAT_HASH], key_of[ROWS], n_rows;
   __shared__ int local[SCAT_CHUNK];     // accumulator row of a position, SCAT_ROWS + its dst row when it has none, -1: skip
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t base = (int64_t)blockIdx.x * SCAT_CHUNK;
+  int64_t blk = blockIdx.x;
+  if (blk >= blocks1) {     // a second list in the same launch (orca_scatter_add_flagged_pair): workgroup-uniform
+    blk -= blocks1;
+    rows = rows2; idx64 = idx64_2; idx32 = idx32_2; n = n2;
+  }
+  const int64_t base = blk * SCAT_CHUNK;
   for (int i = t; i < SCAT_HASH; i += 1024) keys[i] = -1;
   for (int i = t; i < ROWS * D; i += 1024) (&acc[0][0])[i] = 0.f;
   if (t == 0) n_rows = 0;
@@ -647,6 +654,27 @@ ORCA_API int orca_scatter_add_flagged(const float* rows, const int64_t* idx64, c
     k_scatter_add_flagged<128><<<blocks(n, 128), 1024, 0, (hipStream_t)stream>>>(rows, idx64, idx32, n, flags, pos, n_nodes, dst);
   else
     k_scatter_add_flagged<256><<<blocks(n, 256), 1024, 0, (hipStream_t)stream>>>(rows, idx64, idx32, n, flags, pos, n_nodes, dst);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+ORCA_API int orca_scatter_add_flagged_pair(const float* rows_a, const int64_t* idx64_a, const int32_t* idx32_a, int64_t n_a,
+                                           const float* rows_b, const int64_t* idx64_b, const int32_t* idx32_b, int64_t n_b,
+                                           const uint8_t* flags, const int32_t* pos, int64_t n_nodes, float* dst,
+                                           void* stream) {
+  ORCA_REQUIRE(n_a >= 0 && n_b >= 0 && (n_a == 0 || (rows_a && (idx64_a || idx32_a))) && (n_b == 0 || (rows_b && (idx64_b || idx32_b))) &&
+               (n_a + n_b == 0 || (flags && pos && dst)), "orca_scatter_add_flagged_pair: bad arguments");
+  if (n_a == 0) return orca_scatter_add_flagged(rows_b, idx64_b, idx32_b, n_b, flags, pos, n_nodes, dst, stream);
+  if (n_b == 0) return orca_scatter_add_flagged(rows_a, idx64_a, idx32_a, n_a, flags, pos, n_nodes, dst, stream);
+  const int64_t n = n_a + n_b;
+  // one launch: the short list's workgroups ride beside the long one's (as two launches: 12.7 + 33.5 us for 4 k + 41 k rows)
+#define ORCA_SCATTER_PAIR(CH)                                                                                              \
+  k_scatter_add_flagged<CH><<<blocks(n_a, CH) + blocks(n_b, CH), 1024, 0, (hipStream_t)stream>>>(                        \
+      rows_a, idx64_a, idx32_a, n_a, flags, pos, n_nodes, dst, (int)blocks(n_a, CH), rows_b, idx64_b, idx32_b, n_b)
+  if (n <= 16384) ORCA_SCATTER_PAIR(64);
+  else if (n <= 131072) ORCA_SCATTER_PAIR(128);
+  else ORCA_SCATTER_PAIR(256);
+#undef ORCA_SCATTER_PAIR
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

@@ -933,8 +933,7 @@ class OrcaEngine:
       ops.index_positions(wl, cnt, None, self._pos)
       d_upd = pool.take(cnt * D).view(cnt, D)
       (ids_src, ids_nbr), d_src, d_nbr = into_memory
-      ops.scatter_add_flagged(d_src, ids_src, self.pending, self._pos, d_upd)
-      ops.scatter_add_flagged(d_nbr, ids_nbr, self.pending, self._pos, d_upd)
+      ops.scatter_add_flagged_pair(d_src, ids_src, d_nbr, ids_nbr, self.pending, self._pos, d_upd)
       gg = ops.gru_backward(self.params[p + "weight_ih"], self.params[p + "weight_hh"], self.params[p + "bias_ih"],
                             self.params[p + "bias_hh"], wl, self.messages, self.memory, d_upd, pool=pool, deferred=deferred)
       for k, v in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), gg[:4]):

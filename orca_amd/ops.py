@@ -498,6 +498,20 @@ def scatter_add_flagged(rows, idx, flags, pos, dst):
                                              flags.numel(), ptr(dst), stream()), "orca_scatter_add_flagged")
 
 
+def scatter_add_flagged_pair(rows_a, idx_a, rows_b, idx_b, flags, pos, dst):
+  """scatter_add_flagged of two lists into the same dst in one launch (orca_scatter_add_flagged_pair)"""
+  def split(idx):
+    if idx.dtype not in (torch.int64, torch.int32):
+      raise TypeError("scatter_add_flagged_pair: idx must be int64 or int32")
+    return (idx if idx.dtype == torch.int64 else None), (idx if idx.dtype == torch.int32 else None)
+  a64, a32 = split(idx_a)
+  b64, b32 = split(idx_b)
+  rows_a, rows_b = rows_a.contiguous(), rows_b.contiguous()
+  check(_lib.load().orca_scatter_add_flagged_pair(ptr(rows_a), ptr(a64), ptr(a32), idx_a.numel(), ptr(rows_b), ptr(b64), ptr(b32),
+                                                  idx_b.numel(), ptr(flags), ptr(pos), flags.numel(), ptr(dst), stream()),
+        "orca_scatter_add_flagged_pair")
+
+
 def gather_rows(table, idx, out=None):
   n = idx.numel()
   width = table.shape[1]

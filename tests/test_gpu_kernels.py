@@ -404,3 +404,37 @@ def test_message_store_vs_oracle(ops, d_e):
   assert_close_fp32(messages.cpu().numpy(), tg.messages.numpy(), 1e-5, "messages")
   # exact copies outside the time-encoding columns
   assert np.array_equal(messages.cpu().numpy()[:, :200 + d_e], tg.messages.numpy()[:, :200 + d_e])
+
+
+@pytest.mark.parametrize("n_a,n_b", [(300, 0), (4095, 40950), (70, 20000), (1, 1)])
+def test_scatter_add_flagged_and_pair(ops, n_a, n_b):
+  """dst[pos[id]] += rows[p] for the flagged ids (the gradient rows of attention layer 1 flowing into the updated-memory
+  rows, embedding_module.py:159-175): one list, and two lists in one launch, against a float64 np.add.at (the order of
+  the fp32 additions is the atomics': tolerance, not bits).  Hub ids repeat thousands of times."""
+  rs = np.random.RandomState(n_a + n_b)
+  N = 5000
+  flags = (rs.rand(N) < 0.6).astype(np.uint8)
+  wl = np.flatnonzero(flags)[rs.permutation(int(flags.sum()))].astype(np.int32)
+  pos = np.zeros(N, np.int32)
+  pos[wl] = np.arange(wl.size, dtype=np.int32)
+  def ids(n):
+    z = rs.zipf(1.3, n) % N            # power-law: a few ids take most positions
+    z[rs.rand(n) < 0.05] = N + 7       # ids outside the table are skipped
+    return z.astype(np.int64)
+  ia, ib = ids(n_a), ids(n_b)
+  ra, rb = rs.randn(n_a, 100).astype(np.float32), rs.randn(n_b, 100).astype(np.float32)
+  want = np.zeros((wl.size, 100), np.float64)
+  for i, r in ((ia, ra), (ib, rb)):
+    ok = (i < N) & (flags[np.minimum(i, N - 1)] != 0)
+    np.add.at(want, pos[i[ok]], r[ok].astype(np.float64))
+  _t = lambda a: torch.from_numpy(a).to(DEV)
+  d1 = torch.zeros(wl.size, 100, device=DEV)
+  if n_a:
+    ops.scatter_add_flagged(_t(ra), _t(ia), _t(flags), _t(pos), d1)
+  if n_b:
+    ops.scatter_add_flagged(_t(rb), _t(ib.astype(np.int32)), _t(flags), _t(pos), d1)
+  d2 = torch.zeros(wl.size, 100, device=DEV)
+  ops.scatter_add_flagged_pair(_t(ra), _t(ia), _t(rb), _t(ib.astype(np.int32)), _t(flags), _t(pos), d2)
+  scale = max(1.0, float(np.abs(want).max()))
+  assert float(np.abs(d1.cpu().numpy() - want).max()) <= 2e-5 * scale
+  assert float(np.abs(d2.cpu().numpy() - want).max()) <= 2e-5 * scale
