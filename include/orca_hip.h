@@ -254,6 +254,13 @@ int orca_gru_update(const float* blob, int msg_dim, const int32_t* ids, int64_t 
                     const float* x, const float* h, float* out, float* last_update, const float* msg_ts,
                     void* stream);
 
+/* orca_gru_update that also keeps, for row r (id = ids[r]), the gates r, z, n and the hidden part of n's pre-activation
+ * in gates[r][4][ORCA_D] (what autograd keeps of nn.GRUCell for train.py:236): orca_gru_backward_saved then does not
+ * recompute them.  Built for msg_dim = 3 * ORCA_D + 172 with an id list, out of place (EINVAL otherwise: call
+ * orca_gru_update and orca_gru_backward). */
+int orca_gru_update_saving(const float* blob, int msg_dim, const int32_t* ids, int64_t n, const int32_t* n_dev,
+                           const float* x, const float* h, float* out, float* gates, void* stream);
+
 /* Backward of GRUCell as get_updated_memory calls it (modules/memory_updater.py:56-78,86; train.py:236-237): for the
  * n rows id = ids ? ids[r] : r with inputs x[id] [msg_dim], h[id] [ORCA_D] and d_out [n, ORCA_D] = dL/d(new h) in
  * row order, ADDS the parameter gradients into g_* (shapes of the raw tensors) and writes d_x [n, msg_dim] and
@@ -270,6 +277,13 @@ int orca_gru_backward_phase(int msg_dim, const float* weight_ih, const float* we
                             const float* bias_hh, const int32_t* ids, int64_t n, const float* x, const float* h,
                             const float* d_out, float* g_weight_ih, float* g_weight_hh, float* g_bias_ih, float* g_bias_hh,
                             float* d_x, float* d_h, float* workspace, int phases, void* stream);
+
+/* orca_gru_backward_phase reading the gates orca_gru_update_saving kept for the same id list (gates == NULL: as
+ * orca_gru_backward_phase) */
+int orca_gru_backward_saved(int msg_dim, const float* weight_ih, const float* weight_hh, const float* bias_ih,
+                            const float* bias_hh, const int32_t* ids, int64_t n, const float* x, const float* h,
+                            const float* d_out, float* g_weight_ih, float* g_weight_hh, float* g_bias_ih, float* g_bias_hh,
+                            float* d_x, float* d_h, float* workspace, const float* gates, int phases, void* stream);
 
 /* dst_table[id] = src_table[id] (rows of ORCA_D floats) and, if last_update != NULL, last_update[id] =
  * msg_ts[id], for the first min(n, *n_dev) ids of a work-list: commits GRU rows held in the overlay into
@@ -502,9 +516,10 @@ int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t hi, void*
  * persist, raw-message store -- are not fused into those kernels: orca_engine_finish performs them, and the caller
  * issues it after the backward has read memory / messages / overlay.  One rank, whole batch, train order, with
  * overlay_complete cleared (the per-batch work-list `worklist` / `count` is what the GRU's backward walks).
- * on == 0: back to the plain step. */
+ * gru_gates != NULL (d_e = 172): the work-list's GRU runs as orca_gru_update_saving into it
+ * ([min(3 * bs * (K + 1), n_nodes)][4][ORCA_D] floats).  on == 0: back to the plain step. */
 int orca_engine_train_capture(orca_engine_t* e, int on, float* const* saved, float dropout_p,
-                              const uint64_t* dropout_seeds);
+                              const uint64_t* dropout_seeds, float* gru_gates);
 
 /* Memory persist for the batch's positives and raw-message build + store, in the train or eval order the
  * batch was begun with.  tgn_model.py:127-145 */

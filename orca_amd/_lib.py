@@ -76,6 +76,8 @@ SIGNATURES = {
     "orca_gru_backward_workspace_floats": (i64, [i32, i64]),
     "orca_gru_backward": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 11),
     "orca_gru_backward_phase": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 10 + [i32, vp]),
+    "orca_gru_backward_saved": (i32, [i32, vp, vp, vp, vp, vp, i64] + [vp] * 11 + [i32, vp]),
+    "orca_gru_update_saving": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp]),
     "orca_tgat_backward_workspace_floats": (i64, [i32, i64, i32]),
     "orca_tgat_backward": (i32, [vp, i32, vp, i64, i32] + [vp] * 10),
     "orca_tgat_backward_saved": (i32, [vp, i32, vp, i64, i32] + [vp] * 11),
@@ -115,7 +117,7 @@ SIGNATURES = {
     "orca_engine_take_epochs": (i64, [vp, i64]),
     "orca_engine_begin": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
     "orca_engine_layer": (i32, [vp, i32, i64, i64, vp]),
-    "orca_engine_train_capture": (i32, [vp, i32, vp, ctypes.c_float, vp]),
+    "orca_engine_train_capture": (i32, [vp, i32, vp, ctypes.c_float, vp, vp]),
     "orca_engine_finish": (i32, [vp, vp, vp, vp, vp, vp]),
     "orca_engine_apply": (i32, [vp, vp]),
     "orca_engine_xm_chunk_words": (i64, [i64]),

@@ -53,6 +53,7 @@ struct orca_engine {
   float* cap_saved[ORCA_ENGINE_MAX_LAYERS];
   float cap_p;
   uint64_t cap_seed[ORCA_ENGINE_MAX_LAYERS];
+  float* cap_gates;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ORCA_PROF_CLASSES];
 };
 
@@ -585,17 +586,20 @@ void capture_side(const orca_engine_t* e, int l, int64_t n, orca_tgat_inputs& in
 }  // namespace
 
 ORCA_API int orca_engine_train_capture(orca_engine_t* e, int on, float* const* saved, float dropout_p,
-                                       const uint64_t* dropout_seeds) {
+                                       const uint64_t* dropout_seeds, float* gru_gates) {
   ORCA_REQUIRE(e, "orca_engine_train_capture: null handle");
   e->capture = on != 0;
   e->cap_p = 0.f;
+  e->cap_gates = nullptr;
   for (int l = 0; l < ORCA_ENGINE_MAX_LAYERS; ++l) { e->cap_saved[l] = nullptr; e->cap_seed[l] = 0; }
   if (!on) return ORCA_OK;
   ORCA_REQUIRE(e->d.world <= 1, "orca_engine_train_capture: one rank only (several ranks back-propagate slices: the "
                "dispatched path)");
   ORCA_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seeds),
                "orca_engine_train_capture: dropout_p=%g needs seeds and must lie in [0,1)", (double)dropout_p);
+  ORCA_REQUIRE(!gru_gates || e->d.d_e == 172, "orca_engine_train_capture: gru_gates needs d_e = 172");
   e->cap_p = dropout_p;
+  e->cap_gates = gru_gates;
   for (int l = 0; l < e->d.n_layers; ++l) {
     if (saved) e->cap_saved[l] = saved[l];
     if (dropout_seeds) e->cap_seed[l] = dropout_seeds[l];
@@ -744,8 +748,12 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     if (rc != ORCA_OK) return rc;
     {
       Timed t(e, ORCA_PROF_GRU, stream);
-      rc = orca_gru_update(d.gru_blob, 3 * ORCA_D + d.d_e, d.worklist, cand < d.n_nodes ? cand : d.n_nodes, d.count,
-                           d.messages, d.memory, d.overlay, nullptr, nullptr, stream_);
+      if (e->capture && e->cap_gates)
+        rc = orca_gru_update_saving(d.gru_blob, 3 * ORCA_D + d.d_e, d.worklist, cand < d.n_nodes ? cand : d.n_nodes, d.count,
+                                    d.messages, d.memory, d.overlay, e->cap_gates, stream_);
+      else
+        rc = orca_gru_update(d.gru_blob, 3 * ORCA_D + d.d_e, d.worklist, cand < d.n_nodes ? cand : d.n_nodes, d.count,
+                             d.messages, d.memory, d.overlay, nullptr, nullptr, stream_);
     }
     if (rc != ORCA_OK) return rc;
   }

@@ -339,10 +339,10 @@ __global__ __launch_bounds__(GRU_KW * 64) void k_gru_split(const float* __restri
                                                         const float* __restrict__ x, const float* __restrict__ h,
                                                         float* __restrict__ out, float* last_update,
                                                         const float* __restrict__ msg_ts,
-                                                        long long* __restrict__ phase_clock) {
+                                                        long long* __restrict__ phase_clock, float* __restrict__ save_gates) {
   __shared__ f32x4 part[GRU_KW - 1][MT][3][64];
   gru_split_workgroup<MSG, GS, MT>(blob, ids, n_max, n_dev, x, h, out, last_update, msg_ts, (int)blockIdx.x, (int)gridDim.x,
-                                   part, phase_clock);
+                                   part, phase_clock, save_gates);
 }
 
 }  // namespace
@@ -405,13 +405,14 @@ static int gru_launch_stream(const float* blob, const int32_t* ids, int64_t n, c
 }
 
 static int gru_launch_split(const float* blob, const int32_t* ids, int64_t n, const int32_t* n_dev, const float* x,
-                            const float* h, float* out, float* last_update, const float* msg_ts, hipStream_t stream) {
+                            const float* h, float* out, float* last_update, const float* msg_ts, hipStream_t stream,
+                            float* save_gates = nullptr) {
   // 16-row tiles (MT = 1).  32-row tiles (MT = 2: half the weight traffic, half the workgroups) measured 18.5 vs
   // 19.1 us on an isolated 2084-row work-list but 1 % slower inside the step, and slower at 2730 rows (24.0 vs 22.3)
   const int64_t tiles = ceil_div64(n, 16);
   const unsigned grid = (unsigned)((tiles < GRU_SPLIT_TILES ? tiles : GRU_SPLIT_TILES) * NWG);
   ORCA_LAUNCH_TIMED((k_gru_split<3 * D + 172, 3, 1>), grid, GRU_KW * 64, 0, stream, blob, ids, n, n_dev, x, h, out, last_update,
-                    msg_ts, g_gru_clock);
+                    msg_ts, g_gru_clock, save_gates);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -449,6 +450,16 @@ ORCA_API int orca_gru_update(const float* blob, int msg_dim, const int32_t* ids,
   // counts, the reduction is split over 4 waves; many rows: one wave per (row tile, hidden tile) streams the lot
   if (n_dev || n <= 4096) return gru_launch_split(blob, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
   return gru_launch_stream(blob, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
+}
+
+ORCA_API int orca_gru_update_saving(const float* blob, int msg_dim, const int32_t* ids, int64_t n, const int32_t* n_dev,
+                                    const float* x, const float* h, float* out, float* gates, void* stream) {
+  ORCA_REQUIRE(n >= 0, "orca_gru_update_saving: n < 0");
+  if (n == 0) return ORCA_OK;
+  ORCA_REQUIRE(blob && x && h && out && gates && ids, "orca_gru_update_saving: null pointer");
+  ORCA_REQUIRE(msg_dim == 3 * D + 172 && out != h, "orca_gru_update_saving: built for msg_dim=%d, out of place (got %d%s)",
+               3 * D + 172, msg_dim, out == h ? ", in place" : "");
+  return gru_launch_split(blob, ids, n, n_dev, x, h, out, nullptr, nullptr, (hipStream_t)stream, gates);
 }
 
 // out_table[id] = src_table[id] (+ last_update[id] = msg_ts[id]) for the ids of a device-counted work-list:

@@ -40,6 +40,28 @@ __global__ void k_gru_gates_bwd(float* __restrict__ gi, float* __restrict__ gh, 
   a[2 * D + u] = dpn;  b[2 * D + u] = dpn * r;
   if (dh_direct) dh_direct[i] = go * z;
 }
+// the same from the gates the forward kept (orca_gru_update_saving: g = [n][r, z, n, h_n][100]): no recompute of the
+// pre-activations.  Writes d gi, d gh [n,300].
+__global__ void k_gru_gates_bwd_saved(const float* __restrict__ g, const float* __restrict__ h, const float* __restrict__ d_out,
+                                      int64_t n, float* __restrict__ gi, float* __restrict__ gh, float* __restrict__ dh_direct) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * D) return;
+  const int64_t r_ = i / D;
+  const int u = (int)(i % D);
+  const float* gr = g + r_ * 4 * D + u;
+  const float r = gr[0], z = gr[D], nn = gr[2 * D], ghn = gr[3 * D];
+  float* a = gi + r_ * G3;
+  float* b = gh + r_ * G3;
+  const float go = d_out[i];
+  const float dn = go * (1.0f - z), dz = go * (h[i] - nn);
+  const float dpn = dn * (1.0f - nn * nn);
+  const float dpr = dpn * ghn * r * (1.0f - r);
+  const float dpz = dz * z * (1.0f - z);
+  a[u] = dpr;          b[u] = dpr;
+  a[D + u] = dpz;      b[D + u] = dpz;
+  a[2 * D + u] = dpn;  b[2 * D + u] = dpn * r;
+  if (dh_direct) dh_direct[i] = go * z;
+}
 }  // namespace
 
 namespace { constexpr int GRU_SPLITS = 16; }   // split-K pieces of the two weight-gradient GEMMs (one launch)
@@ -63,6 +85,17 @@ ORCA_API int orca_gru_backward_phase(int msg_dim, const float* weight_ih, const 
                                      const float* bias_hh, const int32_t* ids, int64_t n, const float* x, const float* h,
                                      const float* d_out, float* g_weight_ih, float* g_weight_hh, float* g_bias_ih,
                                      float* g_bias_hh, float* d_x, float* d_h, float* workspace, int phases, void* stream_) {
+  return orca_gru_backward_saved(msg_dim, weight_ih, weight_hh, bias_ih, bias_hh, ids, n, x, h, d_out, g_weight_ih, g_weight_hh,
+                                 g_bias_ih, g_bias_hh, d_x, d_h, workspace, nullptr, phases, stream_);
+}
+
+// gates != NULL: rows r of what orca_gru_update_saving kept for the same id list (row r = ids[r]); the gate
+// pre-activations are then not recomputed (no [n x msg_dim] x [msg_dim x 300] product in the backward)
+ORCA_API int orca_gru_backward_saved(int msg_dim, const float* weight_ih, const float* weight_hh, const float* bias_ih,
+                                     const float* bias_hh, const int32_t* ids, int64_t n, const float* x, const float* h,
+                                     const float* d_out, float* g_weight_ih, float* g_weight_hh, float* g_bias_ih,
+                                     float* g_bias_hh, float* d_x, float* d_h, float* workspace, const float* gates,
+                                     int phases, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   ORCA_REQUIRE(phases >= 1 && phases <= 3, "orca_gru_backward_phase: phases=%d", phases);
   ORCA_REQUIRE(n >= 0, "orca_gru_backward: negative row count");
@@ -88,12 +121,13 @@ ORCA_API int orca_gru_backward_phase(int msg_dim, const float* weight_ih, const 
                 float* C, int64_t scm, int64_t scn, const float* bias, int accumulate) {
     return OrcaGemm{M_, N_, K_, A, sam, sak, B, sbk, sbn, C, scm, scn, bias, 1.f, accumulate, 0, nullptr, nullptr, 0, nullptr, 1};
   };
-  if (phases & 1) {   // gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh: one launch
+  if ((phases & 1) && !gates) {   // gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh: one launch
     OrcaGemm g[2] = {G1(M, G3, msg_dim, xg, msg_dim, 1, weight_ih, 1, msg_dim, gi, G3, 1, bias_ih, 0),
                      G1(M, G3, D, hg, D, 1, weight_hh, 1, D, gh, G3, 1, bias_hh, 0)};
     rc |= orca_sgemm_group(s, g, 2, nullptr);
   }
-  if (phases & 1) k_gru_gates_bwd<<<ew(n * D), 256, 0, s>>>(gi, gh, hg, d_out, n, d_h);
+  if ((phases & 1) && gates) k_gru_gates_bwd_saved<<<ew(n * D), 256, 0, s>>>(gates, hg, d_out, n, gi, gh, d_h);
+  else if (phases & 1) k_gru_gates_bwd<<<ew(n * D), 256, 0, s>>>(gi, gh, hg, d_out, n, d_h);
   if (phases & 2) {   // weight_ih [300,msg] += dgi^T x;  weight_hh [300,100] += dgh^T h;  the biases as a column of ones: one launch
     OrcaGemm g[2] = {G1(G3, msg_dim, M, gi, 1, G3, xg, msg_dim, 1, g_weight_ih, msg_dim, 1, nullptr, 1),
                      G1(G3, D, M, gh, 1, G3, hg, D, 1, g_weight_hh, D, 1, nullptr, 1)};

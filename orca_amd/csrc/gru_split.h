@@ -84,7 +84,8 @@ __device__ __forceinline__ void gru_split_workgroup(const float* __restrict__ bl
                                                     const float* __restrict__ x, const float* __restrict__ h,
                                                     float* __restrict__ out, float* last_update,
                                                     const float* __restrict__ msg_ts, int wg, int n_wg,
-                                                    f32x4 (*part)[MT][3][64], long long* __restrict__ phase_clock) {
+                                                    f32x4 (*part)[MT][3][64], long long* __restrict__ phase_clock,
+                                                    float* __restrict__ save_gates = nullptr) {
   const int wg_first = wg;
   if constexpr (SUBS > 1) {
     const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
@@ -189,6 +190,10 @@ __device__ __forceinline__ void gru_split_workgroup(const float* __restrict__ bl
               const float zz = gru_sigmoid(az[r] + bz);
               const float nn = tanhf(a3[r] + bi + rr * (ah[r] + bh));
               out[id_o[m][r] * D + u] = (1.0f - zz) * nn + zz * hp[m][r];
+              if (save_gates) {     // what the backward would otherwise recompute (orca_gru_update_saving): [row][r, z, n, h_n][D]
+                float* sg = save_gates + ro * 4 * D + u;
+                sg[0] = rr; sg[D] = zz; sg[2 * D] = nn; sg[3 * D] = ah[r] + bh;
+              }
             }
           }
         }

@@ -935,7 +935,8 @@ class OrcaEngine:
       (ids_src, ids_nbr), d_src, d_nbr = into_memory
       ops.scatter_add_flagged_pair(d_src, ids_src, d_nbr, ids_nbr, self.pending, self._pos, d_upd)
       gg = ops.gru_backward(self.params[p + "weight_ih"], self.params[p + "weight_hh"], self.params[p + "bias_ih"],
-                            self.params[p + "bias_hh"], wl, self.messages, self.memory, d_upd, pool=pool, deferred=deferred)
+                            self.params[p + "bias_hh"], wl, self.messages, self.memory, d_upd, pool=pool, deferred=deferred,
+                            gates=self._step_gates if native_fwd else None)
       for k, v in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), gg[:4]):
         grads[p + k] = v
       if deferred:
@@ -1004,14 +1005,21 @@ class OrcaEngine:
     sv = cache[1]
     saved_p = (_lib.vp * self.L)(*[ptr(t) for t in sv])
     seeds = (ctypes.c_uint64 * self.L)(*[self._dropout_kw(l + 1, 0).get("dropout_seed", 0) for l in range(self.L)])
-    check(L.orca_engine_train_capture(self._native, 1, saved_p, float(self.dropout), seeds), "orca_engine_train_capture")
+    gates = None
+    if self.d_e == 172:      # the work-list's GRU keeps its gates for the backward (orca_gru_update_saving)
+      need = min(Q * (K + 1), self.N) * 4 * D
+      if getattr(self, "_gates", None) is None or self._gates.numel() < need:
+        self._gates = torch.empty(need, dtype=torch.float32, device=self.device)
+      gates = self._gates
+    self._step_gates = gates
+    check(L.orca_engine_train_capture(self._native, 1, saved_p, float(self.dropout), seeds, ptr(gates)), "orca_engine_train_capture")
     try:
       check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, 0, Q, 1, st), "orca_engine_begin")
       cnt_ready = self._fetch_count()
       for layer in range(2, self.L + 1):
         check(L.orca_engine_layer(self._native, layer, 0, Q, st), "orca_engine_layer")
     finally:
-      L.orca_engine_train_capture(self._native, 0, None, 0.0, None)
+      L.orca_engine_train_capture(self._native, 0, None, 0.0, None, None)
     w = self._w
     view = lambda t: t[:Q * K].view(Q, K)
     embs = [w["emb"][l & 1][:Q] for l in range(self.L)]

@@ -382,10 +382,12 @@ def gru_pack(weight_ih, weight_hh, bias_ih, bias_hh, device, blob=None):
   return blob
 
 
-def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_inputs=False, pool=None, deferred=None):
+def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_inputs=False, pool=None, deferred=None,
+                 gates=None):
   """orca_gru_backward.  ids int32 [n] or None (dense rows).  Returns (g_weight_ih, g_weight_hh, g_bias_ih,
   g_bias_hh, d_x, d_h) -- the last two None unless want_inputs.  deferred: as in tgat_backward (the parameter
-  gradients are issued by the callable appended to the list)."""
+  gradients are issued by the callable appended to the list).  gates: what gru_update(gates=) kept for the same id
+  list (orca_gru_backward_saved: no recompute of the gate pre-activations)."""
   dev = d_out.device
   ps = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
   flat = _zeros(sum(-(-p.numel() // 64) * 64 for p in ps), dev, pool)    # one fill for the four
@@ -405,11 +407,16 @@ def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_
   x, h = x.contiguous(), h.contiguous()
   if deferred is not None:
     def run(phases, _keep=(ps, gs, ids, x, h, go, d_x, d_h, wsp, flat)):
-      check(_lib.load().orca_gru_backward_phase(int(msg_dim), *(ptr(p) for p in ps), ptr(ids), int(n), ptr(x), ptr(h), ptr(go),
-                                                *(ptr(g) for g in gs), ptr(d_x), ptr(d_h), ptr(wsp), phases, stream()),
-            "orca_gru_backward_phase")
+      check(_lib.load().orca_gru_backward_saved(int(msg_dim), *(ptr(p) for p in ps), ptr(ids), int(n), ptr(x), ptr(h), ptr(go),
+                                                *(ptr(g) for g in gs), ptr(d_x), ptr(d_h), ptr(wsp), ptr(gates), phases, stream()),
+            "orca_gru_backward_saved")
     run(1)
     deferred.append(lambda: run(2))
+    return (*gs, d_x, d_h)
+  if gates is not None:
+    check(_lib.load().orca_gru_backward_saved(int(msg_dim), *(ptr(p) for p in ps), ptr(ids), int(n), ptr(x), ptr(h), ptr(go),
+                                              *(ptr(g) for g in gs), ptr(d_x), ptr(d_h), ptr(wsp), ptr(gates), 3, stream()),
+          "orca_gru_backward_saved")
     return (*gs, d_x, d_h)
   check(_lib.load().orca_gru_backward(int(msg_dim), *(ptr(p) for p in ps), ptr(ids), int(n), ptr(x), ptr(h), ptr(go),
                                       *(ptr(g) for g in gs), ptr(d_x), ptr(d_h), ptr(wsp), stream()), "orca_gru_backward")
@@ -423,7 +430,12 @@ def persist_overlay(ids64, pending, overlay, memory, last_update, msg_ts):
                                          ptr(msg_ts), memory.shape[0], stream()), "orca_persist_overlay")
 
 
-def gru_update(blob, msg_dim, ids, n, n_dev, x, h, out, last_update=None, msg_ts=None):
+def gru_update(blob, msg_dim, ids, n, n_dev, x, h, out, last_update=None, msg_ts=None, gates=None):
+  """gates: float32 [>= n * 4 * 100] -- orca_gru_update_saving (keeps r, z, n, h_n per row for gru_backward(gates=))"""
+  if gates is not None:
+    check(_lib.load().orca_gru_update_saving(ptr(blob), int(msg_dim), ptr(ids), int(n), ptr(n_dev), ptr(x), ptr(h), ptr(out),
+                                             ptr(gates), stream()), "orca_gru_update_saving")
+    return
   check(_lib.load().orca_gru_update(ptr(blob), int(msg_dim), ptr(ids), int(n), ptr(n_dev), ptr(x), ptr(h), ptr(out),
                                     ptr(last_update), ptr(msg_ts), stream()), "orca_gru_update")
 
