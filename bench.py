@@ -280,7 +280,7 @@ def main():
              "steps": args.train_steps, "last_loss": float(loss),
              "what": "train-ordered forward + BCE loss + backward (attention x layers, GRU) + Adam + blob re-pack; "
                      "backward per layer = fused row-chain kernels + single-pass per-query kernels + one weight-gradient GEMM; "
-                     "fused Adam; Python-dispatched"}
+                     "fused Adam; forward issued by the C++ step driver (training capture), backward dispatched from Python"}
 
   path_a = None
   if world == 1 and not args.no_reuse and args.layers > 1 and args.path_a_steps > 0 and args.sampling == "recent":
