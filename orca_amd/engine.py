@@ -53,10 +53,10 @@ class OrcaEngine:
     # out-of-batch neighbours per batch (their actual number is a device-side count; budget_overflow() reports excess)
     self.native_budget, self.budget_cap = True, 1024
     self.native_train = os.environ.get("ORCA_NATIVE_TRAIN", "1") != "0"   # train_step's forward through the C++ driver
-    # train_step / step_optimizer on two streams: the parameter-gradient reductions and the re-pack after the optimizer
-    # run beside the chain of data gradients and the next batch's first kernels (ORCA_OVERLAP=0: one stream)
+    # ORCA_OVERLAP=1: train_step / step_optimizer on two streams -- the parameter-gradient reductions and the re-pack after
+    # the optimizer run beside the chain of data gradients and the next batch's first kernels.  Off by default: it wins
+    # inside one synchronised step and loses in the pipelined loop ("a second stream")
     self.overlap = os.environ.get("ORCA_OVERLAP", "0") != "0"
-    self._ov_mode = int(os.environ.get("ORCA_OVERLAP", "0"))
     self.group = group
     if group is not None:
       import torch.distributed as dist
@@ -169,7 +169,7 @@ class OrcaEngine:
     beside: the re-pack (folds in fp64, fragment orders: seven launches that no kernel of the next batch needs before
     its GRU) is issued on the engine's second stream, ordered after everything enqueued so far; every method that reads
     the blobs waits for it (_await_packed), so the next batch's root, sampling and work-list kernels run beside it."""
-    if beside and self.device.type == "cuda" and self.overlap and self._ov_mode in (1, 3):
+    if beside and self.device.type == "cuda" and self.overlap:
       side = self._side_stream()
       side.wait_stream(torch.cuda.current_stream())
       with torch.cuda.stream(side):
@@ -880,7 +880,7 @@ class OrcaEngine:
     # The parameter gradients (reductions over the batch's queries: nothing downstream in the backward reads them) are
     # issued on the second stream once the last attention layer's data gradients are enqueued, and run beside the
     # scatter into the memory rows, the GRU's backward and the state update; joined before the gradients are handed out.
-    side = self._side_stream() if self.overlap and self._ov_mode in (1, 2) else None
+    side = self._side_stream() if self.overlap else None
     deferred = [] if side is not None else None
     issued, time_grads = [], []
 
