@@ -193,14 +193,13 @@ __global__ void k_index_positions(const int32_t* __restrict__ list, int64_t n, c
 }
 // dst[pos[id]] += rows[p] for every position p whose id carries a flag.  Several positions share an id -- in a
 // power-law batch a hub id thousands of them -- and fp32 atomics on one row serialise at L2 (95 us for 41 k rows), so a
-// workgroup first sums its SCAT_CHUNK positions per id in LDS (a hash table hands the first SCAT_ROWS distinct ids
-// of the chunk an accumulator row; LDS atomics) and then adds each accumulator row to dst once: a hub row receives
-// one global atomic per chunk instead of one per occurrence.  Ids beyond the chunk's SCAT_ROWS go to dst directly.
-// A wave takes 16 positions, four at a time with their loads in flight together (a loop over single rows pays a
-// memory round trip per row: measured 125 us that way).
-// CHUNK = positions per workgroup: 256, or 64 for short lists (4095 positions in chunks of 256 are 16 workgroups on a
-// 256-CU chip).  The LDS and the global adds are separate instructions (one pointer for both is a flat atomic).
-constexpr int SCAT_ROWS = 128, SCAT_HASH = 512, SCAT_U = 4;
+// workgroup first GROUPS its SCAT_CHUNK positions by destination row (a hash table numbers the chunk's distinct rows, a
+// counting sort over those numbers lists the positions row by row) and then sums each group in REGISTERS: the 16 waves
+// split the sorted list at group boundaries, a wave loads its positions' rows together (one memory round trip), walks
+// them in order and issues one global atomic row add whenever the destination changes -- a hub row receives ONE add per
+// chunk instead of one per occurrence.  (The first version summed into LDS accumulator rows with ds_add_f32: 19 of its
+// 34 us were those LDS atomics, 9 the global ones, 6 everything else.)
+// CHUNK = positions per workgroup: sized to the list (4095 positions in chunks of 256 are 16 workgroups on a 256-CU chip).
 template <int SCAT_CHUNK>
 __global__ __launch_bounds__(1024) void k_scatter_add_flagged(const float* rows, const int64_t* idx64,
                                                               const int32_t* idx32, int64_t n,
@@ -209,10 +208,13 @@ __global__ __launch_bounds__(1024) void k_scatter_add_flagged(const float* rows,
                                                               float* __restrict__ dst, int blocks1 = 0x7fffffff,
                                                               const float* rows2 = nullptr, const int64_t* idx64_2 = nullptr,
                                                               const int32_t* idx32_2 = nullptr, int64_t n2 = 0) {
-  constexpr int ROWS = SCAT_CHUNK < SCAT_ROWS ? SCAT_CHUNK : SCAT_ROWS;     // accumulator rows
-  __shared__ float acc[ROWS][D];
-  __shared__ int keys[SCAT_HASH], vals[SCAT_HASH], key_of[ROWS], n_rows;
-  __shared__ int local[SCAT_CHUNK];     // accumulator row of a position, SCAT_ROWS + its dst row when it has none, -1: skip
+  constexpr int SCAT_HASH = SCAT_CHUNK <= 256 ? 512 : 2 * SCAT_CHUNK;
+  static_assert(SCAT_CHUNK <= 512 && SCAT_HASH <= 1024 && SCAT_CHUNK % 16 == 0, "a thread per position and per table slot, a sparse table");
+  constexpr int PER = SCAT_CHUNK / 16;          // sorted positions per wave (at most)
+  __shared__ int keys[SCAT_HASH], vals[SCAT_HASH];
+  __shared__ int cnt[SCAT_CHUNK], start[SCAT_CHUNK];      // per distinct row of the chunk: positions, first place in the list
+  __shared__ int lpos[SCAT_CHUNK], lkey[SCAT_CHUNK], lrow[SCAT_CHUNK];   // the sorted list: position in the chunk, destination row, its number
+  __shared__ int n_rows, n_valid;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int64_t blk = blockIdx.x;
   if (blk >= blocks1) {     // a second list in the same launch (orca_scatter_add_flagged_pair): workgroup-uniform
@@ -221,8 +223,8 @@ __global__ __launch_bounds__(1024) void k_scatter_add_flagged(const float* rows,
   }
   const int64_t base = blk * SCAT_CHUNK;
   for (int i = t; i < SCAT_HASH; i += 1024) keys[i] = -1;
-  for (int i = t; i < ROWS * D; i += 1024) (&acc[0][0])[i] = 0.f;
-  if (t == 0) n_rows = 0;
+  if (t < SCAT_CHUNK) cnt[t] = 0;
+  if (t == 0) { n_rows = 0; n_valid = 0; }
   __syncthreads();
   // the key of this thread's position: the row of dst it adds to, or -1
   int key = -1, h = 0;
@@ -242,45 +244,75 @@ __global__ __launch_bounds__(1024) void k_scatter_add_flagged(const float* rows,
     }
   }
   __syncthreads();
-  if (t < SCAT_HASH && keys[t] >= 0) {
-    const int r = atomicAdd(&n_rows, 1);
-    vals[t] = r;
-    if (r < ROWS) key_of[r] = keys[t];
+  if (t < SCAT_HASH && keys[t] >= 0) vals[t] = atomicAdd(&n_rows, 1);     // number the distinct rows
+  __syncthreads();
+  int row = -1, rank = 0;
+  if (key >= 0) {
+    row = vals[h];
+    rank = atomicAdd(&cnt[row], 1);
   }
   __syncthreads();
-  if (t < SCAT_CHUNK) local[t] = key < 0 ? -1 : (vals[h] < ROWS ? vals[h] : ROWS + key);
+  if (t < SCAT_CHUNK) {           // exclusive prefix of the counts (at most SCAT_CHUNK short LDS reads per thread)
+    int s0 = 0;
+    const int nr = n_rows;
+#pragma unroll 16
+    for (int i = 0; i < SCAT_CHUNK; ++i) s0 += (i < t && i < nr) ? cnt[i] : 0;     // (fixed trip count: the reads pipeline)
+    start[t] = s0;
+    if (t == nr - 1) n_valid = s0 + cnt[t];
+  }
   __syncthreads();
+  if (key >= 0) {
+    const int at = start[row] + rank;
+    lpos[at] = t;
+    lkey[at] = key;
+    lrow[at] = row;
+  }
+  __syncthreads();
+  // The sorted list in 16 nearly even pieces, cut at group boundaries: a wave owns every group that STARTS in its
+  // piece and follows the last one to its end, so a destination row is added to ONCE per workgroup (a hub row flushed
+  // by every wave it spans serialises at L2 again).  A wave's positions are loaded together, PER at a time.
+  const int nv = n_valid;
+  if (nv == 0) return;
+  const int per = (nv + 15) / 16;
+  auto cut = [&](int i) {       // first group start at or after list place i
+    if (i >= nv) return nv;
+    const int r = lrow[i], s0 = start[r];
+    return s0 == i ? i : s0 + cnt[r];
+  };
+  const int b = __builtin_amdgcn_readfirstlane(cut(wave * per)), e = __builtin_amdgcn_readfirstlane(cut((wave + 1) * per));
+  if (b >= e) return;
   const int c1 = lane + 64;
-  for (int i0 = wave * (SCAT_CHUNK / 16); i0 < (wave + 1) * (SCAT_CHUNK / 16); i0 += SCAT_U) {
-    int r[SCAT_U];
-    float va[SCAT_U], vb[SCAT_U];
+  const bool hi = c1 < D;
+  float sa = 0.f, sb = 0.f;
+  int cur = __builtin_amdgcn_readfirstlane(lkey[b]);
+  for (int i0 = b; i0 < e; i0 += PER) {
+    float va[PER], vb[PER];
+    int kk[PER];
 #pragma unroll
-    for (int u = 0; u < SCAT_U; ++u) {
-      r[u] = local[i0 + u];            // wave-uniform
-      const float* src = rows + (r[u] >= 0 ? base + i0 + u : base) * D;     // clamped, not skipped
+    for (int u = 0; u < PER; ++u) {
+      const int i = i0 + u < e ? i0 + u : e - 1;          // clamped, not skipped (wave-uniform)
+      kk[u] = __builtin_amdgcn_readfirstlane(i0 + u < e ? lkey[i] : -1);
+      const float* src = rows + (base + __builtin_amdgcn_readfirstlane(lpos[i])) * D;
       va[u] = src[lane];
-      vb[u] = c1 < D ? src[c1] : 0.f;
+      vb[u] = src[hi ? c1 : 0];
     }
 #pragma unroll
-    for (int u = 0; u < SCAT_U; ++u) {
-      if (r[u] < 0) continue;
-      if (r[u] < ROWS) {          // wave-uniform
-        atomicAdd(&acc[r[u]][lane], va[u]);
-        if (c1 < D) atomicAdd(&acc[r[u]][c1], vb[u]);
-      } else {
-        float* d = dst + (int64_t)(r[u] - ROWS) * D;
-        atomicAdd(d + lane, va[u]);
-        if (c1 < D) atomicAdd(d + c1, vb[u]);
+    for (int u = 0; u < PER; ++u) {
+      if (kk[u] < 0) break;                               // wave-uniform: past this wave's groups
+      if (kk[u] != cur) {
+        float* d = dst + (int64_t)cur * D;
+        atomicAdd(d + lane, sa);
+        if (hi) atomicAdd(d + c1, sb);
+        sa = sb = 0.f;
+        cur = kk[u];
       }
+      sa += va[u];
+      sb += vb[u];
     }
   }
-  __syncthreads();
-  const int nr = n_rows < ROWS ? n_rows : ROWS;
-  for (int r = wave; r < nr; r += 16) {
-    float* d = dst + (int64_t)key_of[r] * D;
-    atomicAdd(d + lane, acc[r][lane]);
-    if (c1 < D) atomicAdd(d + c1, acc[r][c1]);
-  }
+  float* d = dst + (int64_t)cur * D;
+  atomicAdd(d + lane, sa);
+  if (hi) atomicAdd(d + c1, sb);
 }
 
 __global__ __launch_bounds__(256) void k_scatter_rows(float* __restrict__ table, int64_t n_rows, int64_t width,
@@ -648,10 +680,9 @@ ORCA_API int orca_scatter_add_flagged(const float* rows, const int64_t* idx64, c
   ORCA_REQUIRE(n >= 0 && (n == 0 || (rows && (idx64 || idx32) && flags && pos && dst)),
                "orca_scatter_add_flagged: bad arguments");
   if (n == 0) return ORCA_OK;
+  // (41 k positions: 25.0 us in chunks of 128, 22.6 in chunks of 256 -- half as many adds per hub row --, 30.1 in chunks of 512)
   if (n <= 16384)
     k_scatter_add_flagged<64><<<blocks(n, 64), 1024, 0, (hipStream_t)stream>>>(rows, idx64, idx32, n, flags, pos, n_nodes, dst);
-  else if (n <= 131072)      // (41 k positions: 29 us in chunks of 128, 35 in chunks of 64, 40 in chunks of 256)
-    k_scatter_add_flagged<128><<<blocks(n, 128), 1024, 0, (hipStream_t)stream>>>(rows, idx64, idx32, n, flags, pos, n_nodes, dst);
   else
     k_scatter_add_flagged<256><<<blocks(n, 256), 1024, 0, (hipStream_t)stream>>>(rows, idx64, idx32, n, flags, pos, n_nodes, dst);
   ORCA_LAUNCH_CHECK();
@@ -667,12 +698,11 @@ ORCA_API int orca_scatter_add_flagged_pair(const float* rows_a, const int64_t* i
   if (n_a == 0) return orca_scatter_add_flagged(rows_b, idx64_b, idx32_b, n_b, flags, pos, n_nodes, dst, stream);
   if (n_b == 0) return orca_scatter_add_flagged(rows_a, idx64_a, idx32_a, n_a, flags, pos, n_nodes, dst, stream);
   const int64_t n = n_a + n_b;
-  // one launch: the short list's workgroups ride beside the long one's (as two launches: 12.7 + 33.5 us for 4 k + 41 k rows)
+  // one launch: the short list's workgroups ride beside the long one's
 #define ORCA_SCATTER_PAIR(CH)                                                                                              \
   k_scatter_add_flagged<CH><<<blocks(n_a, CH) + blocks(n_b, CH), 1024, 0, (hipStream_t)stream>>>(                        \
       rows_a, idx64_a, idx32_a, n_a, flags, pos, n_nodes, dst, (int)blocks(n_a, CH), rows_b, idx64_b, idx32_b, n_b)
   if (n <= 16384) ORCA_SCATTER_PAIR(64);
-  else if (n <= 131072) ORCA_SCATTER_PAIR(128);
   else ORCA_SCATTER_PAIR(256);
 #undef ORCA_SCATTER_PAIR
   ORCA_LAUNCH_CHECK();
