@@ -270,6 +270,10 @@ __device__ __forceinline__ int wgrad_m_items(int M) {
   const int r = M & 63;
   return (M >> 6) + (r == 0 ? 0 : (r > 32 && r <= 48) ? 2 : 1);
 }
+inline int wgrad_m_items_host(int M) {
+  const int r = M & 63;
+  return (M >> 6) + (r == 0 ? 0 : (r > 32 && r <= 48) ? 2 : 1);
+}
 template <int V>
 __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, int m0, int n0, int bz, f32x4* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kq = lane >> 4;
@@ -562,9 +566,20 @@ int orca_sgemm_group(hipStream_t s, const OrcaGemm* in, int n, float* part) {
       struct It { int v, code; };
       std::vector<It> list;
       bool fits = true;
+      // k pieces per tile: enough for about one round of workgroups (four per CU), at least WG_SPLITS and never more than
+      // the caller sized `part` for -- the GRU's two gradients are 60 tiles over 2 k rows: with 8 pieces half the chip idles
+      int n_tiles = 0, cap = ORCA_GEMM_SPLITS;
+      for (int i = 0; i < np; ++i) {
+        const GemmArgs& g = grp.g[i];
+        n_tiles += ((g.N + 63) / 64) * wgrad_m_items_host(g.M);
+        cap = g.gz < cap ? g.gz : cap;
+      }
+      int splits = n_tiles > 0 ? (1024 + n_tiles - 1) / n_tiles : WG_SPLITS;
+      splits = splits < WG_SPLITS ? WG_SPLITS : splits;
+      splits = splits > cap ? cap : splits;
       for (int i = 0; i < np; ++i) {
         GemmArgs& g = w.g[i];
-        const int kc = (g.K + WG_SPLITS - 1) / WG_SPLITS;
+        const int kc = (g.K + splits - 1) / splits;
         g.kchunk = (kc + 15) / 16 * 16;
         g.gz = (g.K + g.kchunk - 1) / g.kchunk;
         if (g.gz != w.g[0].gz) fits = false;       // (one k split for the whole launch: the problems share K)
