@@ -5,7 +5,7 @@ One "step" = one batch of the hot path in the reference's train ordering, forwar
 dropout off (model/tgn_model.py:95-147 with --reuse, i.e. Path B modules/embedding_module.py:154-182):
 GRU(message, memory) of the ids the previous batch stored -> sample 3*bs (node, t) root queries -> layer-1 TGAT
 attention (+ persist memory update, history push) -> layer-2 attention over pulled history rows (+ raw-message
-build and store): every operation of the reference's step, 4 kernel launches.
+build and store): every operation of the reference's step, 3 kernel launches.
 
 Workload (BASELINE.json configs[3], the one the metric's north_star is quoted on; it fits one GPU):
 synthetic power-law temporal graph, 1M nodes / 100M edges, 172-d edge features, K=10, 2 layers,

@@ -329,8 +329,11 @@ int orca_segment_last(const int64_t* ids, int64_t M, int64_t* slot, int64_t epoc
 /* orca_segment_last for callers that cannot allocate or own a scratch table (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference.  The election table is
  * a file-scope device array of ORCA_STATIC_IDS_MAX int64 (8 MiB per GPU, held until the process ends); the call
- * allocates nothing and rejects n_nodes or M beyond that maximum with ORCA_EINVAL.  Every call on a GPU shares
- * that GPU's table: calls that overlap on one GPU (two streams, two threads) race -- serialise them. */
+ * allocates nothing and rejects n_nodes or M beyond that maximum with ORCA_EINVAL.  The table is all zero between
+ * calls (a call zeroes the entries it used) and no state of a call lives on the host, so a call recorded into a HIP
+ * graph may be replayed any number of times, with other calls in between (take the first call on a device outside
+ * the capture: it looks the table's address up).  Every call on a GPU shares that GPU's table: calls whose KERNELS
+ * overlap on one GPU (two streams) race -- serialise them; host threads may call concurrently otherwise. */
 #define ORCA_STATIC_IDS_MAX (1 << 20)
 int orca_segment_last_static(const int64_t* ids, int64_t M, int64_t n_nodes, uint8_t* winner, void* stream);
 /* modules/message_aggregator.py:61-81: per distinct id the mean of its rows (arrival order) and the

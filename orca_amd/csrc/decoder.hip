@@ -82,6 +82,7 @@ ORCA_API int orca_decoder_train(const float* emb, int64_t bs, const float* fc1_w
   ORCA_REQUIRE(bs >= 1 && bs < (1LL << 30), "orca_decoder_train: bs=%lld out of range", (long long)bs);
   ORCA_REQUIRE(emb && fc1_w && fc1_b && fc2_w && fc2_b && loss && d_emb && g_fc1_w && g_fc1_b && g_fc2_w && g_fc2_b && workspace,
                "orca_decoder_train: null pointer");
+  (void)hipGetLastError();      // (a status left behind by an earlier runtime call is not this call's)
   const Ws w = ws_layout(bs);
   float *U = workspace + w.U, *H = workspace + w.H, *dS = workspace + w.dS, *dU = workspace + w.dU,
         *lossv = workspace + w.lossv, *part = workspace + w.part;
@@ -118,7 +119,8 @@ ORCA_API int orca_decoder_train(const float* emb, int64_t bs, const float* fc1_w
     g[2].ones_out = g_fc2_b;
     rc |= orca_sgemm_group(s, g, 3, part);
   }
-  if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
+  if (rc != ORCA_OK) return ORCA_EHIP;      // (orca_last_error keeps the failing callee's own message)
+  if (hipGetLastError() != hipSuccess) {
     orca_set_error("orca_decoder_train: kernel launch failed");
     return ORCA_EHIP;
   }

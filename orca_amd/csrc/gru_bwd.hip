@@ -112,6 +112,7 @@ ORCA_API int orca_gru_backward_saved(int msg_dim, const float* weight_ih, const 
   float* part = gh + n * G3;
   part += (64 - ((part - workspace) & 63)) & 63;
   auto ew = [&](int64_t k) { return (unsigned)ceil_div64(k, 256); };
+  (void)hipGetLastError();      // (a status left behind by an earlier runtime call is not this call's)
   int rc = ORCA_OK;
   if (phases & 1) {
     k_gather_wide<<<ew(n * msg_dim), 256, 0, s>>>(x, ids, n, msg_dim, xg);
@@ -143,7 +144,8 @@ ORCA_API int orca_gru_backward_saved(int msg_dim, const float* weight_ih, const 
     if (d_h) g[ng++] = G1(M, D, G3, gh, G3, 1, weight_hh, D, 1, d_h, D, 1, nullptr, 1);
     rc |= orca_sgemm_group(s, g, ng, nullptr);
   }
-  if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
+  if (rc != ORCA_OK) return ORCA_EHIP;      // (orca_last_error keeps the failing callee's own message)
+  if (hipGetLastError() != hipSuccess) {
     orca_set_error("orca_gru_backward: kernel launch failed");
     return ORCA_EHIP;
   }

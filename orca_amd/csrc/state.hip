@@ -537,15 +537,19 @@ ORCA_API int orca_segment_last(const int64_t* ids, int64_t M, int64_t* slot, int
 // ---- the entry point that allocates nothing (include/orca_hip.h: orca_segment_last_static) ---------------------
 // Its election table is this file-scope device array instead of a caller-owned `slot`: every GPU the library runs
 // on holds its own 8 MiB copy at its own address until the process ends.  In host code the name `scratch` is only a
-// stand-in for the symbol: the address kernels and memsets get is the one hipGetSymbolAddress returned for the
-// current device.
+// stand-in for the symbol: the address kernels get is the one hipGetSymbolAddress returned for the current device.
+// The table is all zero between calls: a call elects with atomicMax(scratch[id], 1 + position), reads the winners and
+// then zeroes exactly the entries it touched.  Nothing about a call lives on the host (no epoch counter), so a call
+// recorded into a HIP graph replays correctly any number of times, whatever other calls ran in between.
 static __device__ __align__(256) int64_t scratch[ORCA_STATIC_IDS_MAX];
 namespace {
-struct StaticSlot {
-  int64_t* ptr = nullptr;    // device address of `scratch` on this GPU
-  int64_t epoch = 1;         // next unused election value: the array keeps the last call's contents, and values
-};                           // below the epoch are stale by construction (a zero-initialised array starts below 1)
-StaticSlot static_slot[64];
+int64_t* static_slot_ptr[64];      // device address of `scratch` per GPU (written once per device)
+__global__ void k_clear_slots(const int64_t* __restrict__ ids, int64_t M, int64_t* slot, int64_t n_nodes) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const int64_t id = ids[p];
+  if (id >= 0 && id < n_nodes) slot[id] = 0;
+}
 }  // namespace
 
 ORCA_API int orca_segment_last_static(const int64_t* ids, int64_t M, int64_t n_nodes, uint8_t* winner, void* stream) {
@@ -557,22 +561,17 @@ ORCA_API int orca_segment_last_static(const int64_t* ids, int64_t M, int64_t n_n
   int dev = 0;
   ORCA_HIP_TRY(hipGetDevice(&dev));
   ORCA_REQUIRE(dev >= 0 && dev < 64, "orca_segment_last_static: device %d out of range", dev);
-  StaticSlot& st = static_slot[dev];
-  if (!st.ptr) {     // once per device, with that device current
-    int64_t* p = nullptr;
-    ORCA_HIP_TRY(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
-    ORCA_REQUIRE(p != nullptr, "orca_segment_last_static: no device address for the static table");
-    st.ptr = p;
+  int64_t* table = __atomic_load_n(&static_slot_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!table) {     // once per device, with that device current (two host threads may both ask: they get the same address)
+    ORCA_HIP_TRY(hipGetSymbolAddress((void**)&table, HIP_SYMBOL(scratch)));
+    ORCA_REQUIRE(table != nullptr, "orca_segment_last_static: no device address for the static table");
+    __atomic_store_n(&static_slot_ptr[dev], table, __ATOMIC_RELEASE);
   }
   if (M == 0) return ORCA_OK;
-  if (st.epoch > INT64_MAX - 2 * ORCA_STATIC_IDS_MAX) {   // (not reachable in practice) start over from a cleared table
-    ORCA_HIP_TRY(hipMemsetAsync(st.ptr, 0, sizeof(int64_t) * ORCA_STATIC_IDS_MAX, (hipStream_t)stream));
-    st.epoch = 1;
-  }
-  const int64_t epoch = st.epoch;
-  st.epoch += M + 1;
-  k_elect<<<blocks(M, 256), 256, 0, (hipStream_t)stream>>>(ids, M, st.ptr, epoch, n_nodes);
-  k_winner<<<blocks(M, 256), 256, 0, (hipStream_t)stream>>>(ids, M, st.ptr, epoch, n_nodes, winner);
+  hipStream_t s = (hipStream_t)stream;
+  k_elect<<<blocks(M, 256), 256, 0, s>>>(ids, M, table, 1, n_nodes);
+  k_winner<<<blocks(M, 256), 256, 0, s>>>(ids, M, table, 1, n_nodes, winner);
+  k_clear_slots<<<blocks(M, 256), 256, 0, s>>>(ids, M, table, n_nodes);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

@@ -1608,6 +1608,7 @@ int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_input
   ORCA_REQUIRE(d_e >= 1 && d_e <= ORCA_MAX_DE, "orca_tgat_backward: d_e=%d outside [1,%d]", d_e, ORCA_MAX_DE);
   ORCA_REQUIRE(K >= 1 && K <= ORCA_MAX_K, "orca_tgat_backward: K=%d outside [1,%d]", K, ORCA_MAX_K);
   ORCA_REQUIRE(Q < (1LL << 31) / 1024, "orca_tgat_backward: Q too large for one call");
+  (void)hipGetLastError();      // (a status left behind by an earlier runtime call is not this call's)
   ORCA_REQUIRE(P->q_w && P->k_w && P->v_w && P->in_b && P->o_w && P->o_b && P->fc1_w && P->fc1_b && P->fc2_w &&
                P->fc2_b && P->ln_w && P->ln_b, "orca_tgat_backward: null parameter");
   ORCA_REQUIRE(G->q_w && G->k_w && G->v_w && G->in_b && G->o_w && G->o_b && G->fc1_w && G->fc1_b && G->fc2_w &&
@@ -1760,7 +1761,8 @@ int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_input
     }
   }
   if (!(phases & 2)) {
-    if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
+    if (rc != ORCA_OK) return ORCA_EHIP;      // (orca_last_error keeps the failing callee's own message)
+    if (hipGetLastError() != hipSuccess) {
       orca_set_error("orca_tgat_backward: kernel launch failed");
       return ORCA_EHIP;
     }
@@ -1804,7 +1806,8 @@ int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_input
     }
     rc |= orca_colsum_group(s, nj, X, ld, nc, out, Q, 1.f, true, part);
   }
-  if (rc != ORCA_OK || hipGetLastError() != hipSuccess) {
+  if (rc != ORCA_OK) return ORCA_EHIP;      // (orca_last_error keeps the failing callee's own message)
+  if (hipGetLastError() != hipSuccess) {
     orca_set_error("orca_tgat_backward: kernel launch failed");
     return ORCA_EHIP;
   }

@@ -94,7 +94,7 @@ def all_gather_chunks(buf, chunk, group=None, async_op=False):
 def sync_owned_rows(tables, group=None, chunk_bytes=64 << 20):
   """Every table [N, ...] of `tables` holds current rows only where owner(row) == this rank; afterwards every rank
   holds every owner's rows.  Masked all-reduce in slabs of about chunk_bytes: each row has exactly one non-zero
-  contributor, so the sum is that contributor's row bit for bit (up to the sign of zero)."""
+  contributor, so the sum is that contributor's row bit for bit (up to the sign of zero), whatever the other ranks' stale rows hold."""
   world, rank = dist.get_world_size(group), dist.get_rank(group)
   for t in tables:
     n = t.shape[0]
@@ -103,6 +103,8 @@ def sync_owned_rows(tables, group=None, chunk_bytes=64 << 20):
     for r0 in range(0, n, step):
       r1 = min(n, r0 + step)
       own = (torch.arange(r0, r1, device=t.device) % world) == rank
-      part = t[r0:r1] * (own if t.dim() == 1 else own.view(-1, *([1] * (t.dim() - 1))))
+      # select, not multiply: a stale non-owner row may hold inf / nan, and 0 * inf would poison the owner's row in the sum
+      mask = own if t.dim() == 1 else own.view(-1, *([1] * (t.dim() - 1)))
+      part = torch.where(mask, t[r0:r1], torch.zeros_like(t[r0:r1]))
       all_reduce_sum(part, group)
       t[r0:r1] = part

@@ -49,9 +49,12 @@ class OrcaEngine:
       raise OrcaError("OrcaEngine needs a HIP device (there is no CPU fallback)")
     self.N, self.L, self.K = int(n_nodes), int(n_layers), int(n_neighbors)
     self.reuse, self.budget = bool(reuse), int(budget)
-    # Path C through the native driver (two layers, one rank): its launches are sized for this many uncached
-    # out-of-batch neighbours per batch (their actual number is a device-side count; budget_overflow() reports excess)
-    self.native_budget, self.budget_cap = True, 1024
+    # Path C through the native driver (two layers, one rank): its launches are sized for `budget_cap` uncached
+    # out-of-batch neighbours per batch (their actual number is a device-side count).  None = the safe bound
+    # min(3*bs*K, n_nodes): every uncached neighbour is a distinct sampled id.  A smaller cap makes the launches
+    # smaller; a batch that exceeds it evaluates only the first `cap` ids (embedding_module.py:251-280 evaluates all),
+    # which the NEXT native step -- or check_errors() / budget_overflow() -- reports by raising OrcaError.
+    self.native_budget, self.budget_cap = True, None
     self.native_train = os.environ.get("ORCA_NATIVE_TRAIN", "1") != "0"   # train_step's forward through the C++ driver
     # ORCA_OVERLAP=1: train_step / step_optimizer on two streams -- the parameter-gradient reductions and the re-pack after
     # the optimizer run beside the chain of data gradients and the next batch's first kernels.  Off by default: it wins
@@ -381,7 +384,8 @@ class OrcaEngine:
     L = _lib.load()
     bs = src.numel()
     Q, K, dev = 3 * bs, self.K, self.device
-    cap = self.budget_cap
+    self._raise_budget_overflow(wait=False)        # the previous step's flag, copied out while it ran
+    cap = int(self.budget_cap) if self.budget_cap else max(1, min(Q * K, self.N))
     self._ensure_native(Q + cap)
     b = getattr(self, "_bw", None)
     if b is None or b["cap"] != cap or b["Q"] < Q:
@@ -399,11 +403,32 @@ class OrcaEngine:
                                     ptr(b["unc"]), cap, ptr(b["cnt"]), ptr(b["tmax"]), ptr(b["nbr"]), ptr(b["eid"]), ptr(b["et"]),
                                     ptr(b["dt"]), ptr(out), ptr(b["err"]), stream()), "orca_engine_step_budget")
     self._overlay_complete = False
+    # the overflow word travels to pinned host memory behind the step (no synchronisation here): whoever looks next
+    # -- the next native step, check_errors() -- raises if it was set
+    if getattr(self, "_berr_host", None) is None:
+      self._berr_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    self._berr_host.copy_(b["err"], non_blocking=True)
+    self._berr_ev = torch.cuda.Event()
+    self._berr_ev.record()
+    self._berr_cap = cap
     return out
+
+  def _raise_budget_overflow(self, wait):
+    ev = getattr(self, "_berr_ev", None)
+    if ev is None or not (wait or ev.query()):
+      return
+    if wait:
+      ev.synchronize()
+    if int(self._berr_host[0]) & 2:
+      self._berr_ev = None
+      raise OrcaError(f"OrcaEngine: a Path C batch had more than budget_cap={self._berr_cap} uncached out-of-batch neighbours; "
+                      "only the first budget_cap were evaluated, so embeddings and history rows from that batch on differ from "
+                      "the reference (embedding_module.py:251-280) -- leave budget_cap at None (the safe bound) or raise it")
 
   def budget_overflow(self):
     """True if a native Path C step met more uncached neighbours than `budget_cap` (it then evaluated the first
-    budget_cap of them: raise the cap, or set native_budget = False); reads a device flag (one sync)."""
+    budget_cap of them); reads a device flag (one sync).  The same condition raises from the next native step and
+    from check_errors()."""
     b = getattr(self, "_bw", None)
     return bool(b is not None and int(b["err"].item()) & 2)
 
@@ -473,7 +498,9 @@ class OrcaEngine:
     self._set_overlay_complete(True)
 
   def check_errors(self):
-    """raises if a device-side error word is set (synchronises): an owner-computes exchange that overflowed"""
+    """raises if a device-side error word is set (synchronises): an owner-computes exchange that overflowed, or a
+    native Path C step that met more uncached neighbours than budget_cap"""
+    self._raise_budget_overflow(wait=True)
     err = getattr(self, "_err", None)
     if err is not None and int(err.item()) & 1:
       raise OrcaError(f"OrcaEngine: a rank owned more than exchange_cap={self._xm_cap} of a batch's distinct positive "

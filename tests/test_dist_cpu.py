@@ -37,7 +37,10 @@ def _worker(rank, world, port, q):
   mine = []
   for t in truth:
     own = (torch.arange(37) % world) == rank
-    m = torch.where(own.view(-1, *([1] * (t.dim() - 1))), t, torch.full_like(t, 123.0 + rank))
+    junk = torch.full_like(t, 123.0 + rank)       # stale rows of a non-owner: anything, inf and nan included
+    junk.view(-1)[::3] = float("inf")
+    junk.view(-1)[1::3] = float("nan")
+    m = torch.where(own.view(-1, *([1] * (t.dim() - 1))), t, junk)
     mine.append(m)
   sync_owned_rows(mine, dist.group.WORLD, chunk_bytes=160)      # several slabs
   ok = ok and all(torch.equal(a, b) for a, b in zip(mine, truth))

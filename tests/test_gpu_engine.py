@@ -408,3 +408,14 @@ def test_budget_step_native_equals_dispatched():
   A.compute_temporal_embeddings(src[40000:40000 + bs], dst[40000:40000 + bs], neg, ts[40000:40000 + bs], eidx[40000:40000 + bs],
                                 True, None)
   assert A.budget_overflow()
+  # ... and nobody has to ask: the next native step (once the flag has arrived) or check_errors() raises
+  import pytest
+  from orca_amd._lib import OrcaError
+  with pytest.raises(OrcaError, match="budget_cap=1"):
+    A.check_errors()
+  A.budget_cap = None                    # the safe bound: min(3*bs*K, n_nodes)
+  A._bw["err"].zero_()
+  A.compute_temporal_embeddings(src[40200:40200 + bs], dst[40200:40200 + bs], neg, ts[40200:40200 + bs], eidx[40200:40200 + bs],
+                                True, None)
+  A.check_errors()
+  assert not A.budget_overflow()

@@ -51,6 +51,48 @@ def test_static_election_matches_segment_last():
     assert np.array_equal(new, exp)
 
 
+def test_static_election_replays_from_a_graph():
+  """The call keeps no state on the host and leaves its table zeroed, so a captured call can be replayed on new
+  contents of the same buffers -- also when an id's last occurrence moves to an EARLIER position than in the previous
+  replay, and with eager calls in between (a host-side epoch froze in the graph and broke exactly that)."""
+  L = _lib.load()
+  dev = torch.device("cuda:0")
+  n_nodes, M = 5_000, 4_096
+  g = torch.Generator(device="cpu").manual_seed(5)
+  ids = torch.zeros(M, dtype=torch.int64, device=dev)
+  win = torch.zeros(M, dtype=torch.uint8, device=dev)
+  other = torch.randint(0, n_nodes, (777,), generator=g, dtype=torch.int64).to(dev)
+  w_other = torch.zeros(777, dtype=torch.uint8, device=dev)
+  check(L.orca_segment_last_static(ptr(ids), M, n_nodes, ptr(win), stream()), "warm-up (takes the table's address)")
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    check(L.orca_segment_last_static(ptr(ids), M, n_nodes, ptr(win), stream()), "captured call")
+
+  def expected(h):
+    last = {}
+    for p, v in enumerate(h):
+      if 0 <= v < n_nodes:
+        last[v] = p
+    e = np.zeros(len(h), np.uint8)
+    e[list(last.values())] = 1
+    return e
+
+  base = torch.randint(0, 600, (M,), generator=g, dtype=torch.int64)
+  for r in range(4):
+    h = torch.flip(base, [0]) if r % 2 else base.clone()      # every id's last occurrence moves between replays
+    if r == 2:
+      h[::3] = -1
+    ids.copy_(h.to(dev))
+    win.fill_(5)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(win.cpu().numpy(), expected(h.numpy())), f"replay {r}"
+    check(L.orca_segment_last_static(ptr(other), 777, n_nodes, ptr(w_other), stream()), "eager call between replays")
+    torch.cuda.synchronize()
+    assert np.array_equal(w_other.cpu().numpy(), expected(other.cpu().numpy()))
+
+
 def test_static_election_rejects_oversize():
   L = _lib.load()
   dev = torch.device("cuda:0")
