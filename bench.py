@@ -83,7 +83,85 @@ def parse():
   ap.add_argument("--train-steps", type=int, default=20,
                   help="N=1, Path B: also time this many full training steps (forward + backward + Adam + re-pack), "
                        "reported as the secondary figure 'train_step' (0 = skip)")
+  ap.add_argument("--extra-configs", default="1,2,3,5",
+                  help="N=1, default workload: BASELINE.json's other configurations timed as labelled secondary entries "
+                       "('extra': config1 .. config5; '' = skip)")
+  ap.add_argument("--train-dropout", type=float, default=0.4,
+                  help="attention dropout of the 'train_step' figure (train.py:30 --drop_out, default 0.4; SURVEY section 8d)")
   return ap.parse_args()
+
+
+# BASELINE.json configs other than the one the metric is quoted on (configs[3], the main run).  The real datasets are
+# not in the image and cannot be fetched, so each is a synthetic power-law graph of the dataset's SHAPE (SURVEY
+# section 8d); bs = 200 is the reference's batch size (train.py:21).
+EXTRA_CONFIGS = {
+    "1": dict(name="config1", what="Wikipedia shape: 9,227 nodes / 157,474 interactions, 172-d, K=10, n_layer=1, no reuse (the reference's "
+                                   "default, Path A), bs=200", nodes=9227, edges=157474, d_e=172, k=10, layers=1, reuse=False,
+              budget=0, bs=200, sampling="recent", warm=30, steps=200),
+    "2": dict(name="config2", what="Reddit shape: 10,984 nodes / 672,447 interactions, 172-d, K=10, 2 layers, --reuse (Path B), bs=200",
+              nodes=10984, edges=672447, d_e=172, k=10, layers=2, reuse=True, budget=0, bs=200, sampling="recent", warm=50, steps=400),
+    "3": dict(name="config3", what="Wiki-Talk shape: 1,140,149 nodes / 7,833,140 interactions, zero-feature edges (d_e=1), K=10, 2 layers, "
+                                   "--reuse --budget 1000 with the MRD plan of the device planner (Path C), bs=200",
+              nodes=1140149, edges=7833140, d_e=1, k=10, layers=2, reuse=True, budget=1000, bs=200, sampling="recent", warm=100, steps=500),
+    "5": dict(name="config5", what="10 M nodes / 1 B edges, zero-feature edges (d_e=1), K=20 seeded-uniform sampling (not in the reference), "
+                                   "2 layers, --reuse (Path B), 4095-query batches; state replicated on the one GPU",
+              nodes=10_000_000, edges=1_000_000_000, d_e=1, k=20, layers=2, reuse=True, budget=0, bs=1365, sampling="uniform",
+              warm=20, steps=100),
+}
+
+
+def run_extra_config(c, dev):
+  """one secondary configuration: forward train-order steps on consecutive time-ordered batches, drained wall time"""
+  import argparse as _ap
+  from orca_amd import api, ops, synth
+  from orca_amd.engine import OrcaEngine
+  torch.cuda.empty_cache()
+  t_setup = time.perf_counter()
+  src, dst, eidx, ts = synth.powerlaw_graph(c["nodes"], c["edges"], dev)
+  csr = ops.CSR.from_edges_device(src, dst, eidx, ts, c["nodes"] + 1)
+  ef = synth.edge_features(c["edges"], c["d_e"], dev, zero=c["d_e"] == 1)
+  sd = synth.tgn_state_dict(c["d_e"], c["layers"])
+  n_b, bs = c["warm"] + c["steps"], c["bs"]
+  start = int(0.7 * c["edges"]) if c["budget"] == 0 else int(0.5 * c["edges"])
+  start = min(start, c["edges"] - n_b * bs)
+  plans = None
+  if c["budget"]:     # utils/cache.py:407-428 on the device, for exactly the batches that are run (train.py:157-162)
+    n = n_b * bs
+    h = lambda x: x[start:start + n].cpu().numpy()
+    data = api.Data(h(src), h(dst), h(ts), h(eidx), np.zeros(n))
+    nf = api.NeighborFinder(None, None, None, device=dev, _csr=csr)
+    pa = _ap.Namespace(bs=bs, n_degree=c["k"], budget=c["budget"], planner="device")
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # (the planner prints the reference's statistics line, cache.py:427)
+      plans = [torch.from_numpy(p).to(dev) for p in api.get_cache_plan(pa, data, nf, c["nodes"] + 1, "MRD")]
+  eng = OrcaEngine(sd, ef, c["nodes"] + 1, c["layers"], c["k"], reuse=c["reuse"], budget=c["budget"], device=dev,
+                   sampling=c["sampling"], seed=2024)
+  eng.set_neighbor_finder(csr)
+  g = torch.Generator(device=dev)
+  g.manual_seed(7)
+  neg = torch.randint(1, c["nodes"] + 1, (n_b * bs,), generator=g, device=dev)
+  batches = [(src[start + b * bs:start + (b + 1) * bs].clone(), dst[start + b * bs:start + (b + 1) * bs].clone(),
+              neg[b * bs:(b + 1) * bs], ts[start + b * bs:start + (b + 1) * bs].clone(),
+              eidx[start + b * bs:start + (b + 1) * bs].clone()) for b in range(n_b)]
+  del src, dst, eidx, ts
+  torch.cuda.empty_cache()
+  torch.cuda.synchronize()
+  t_setup = time.perf_counter() - t_setup
+  with torch.no_grad():
+    for b in range(n_b):
+      if b == c["warm"]:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+      eng.compute_temporal_embeddings(*batches[b], train=True, cache_plan=plans[b] if plans else None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+  eng.check_errors()
+  out = {"edges_per_s": c["steps"] * bs / dt, "ms_per_step": 1e3 * dt / c["steps"], "steps": c["steps"], "warmup": c["warm"],
+         "queries_per_batch": 3 * bs, "setup_s": round(t_setup, 1), "data": "synthetic stand-in of the dataset's shape",
+         "workload": c["what"] + "; forward train-order step (sample + embed + memory persist + message store)"}
+  del eng, csr, ef, batches
+  torch.cuda.empty_cache()
+  return out
 
 
 class DeviceBackedRows:
@@ -265,6 +343,7 @@ def main():
   eng.prof = None
   train = None
   if n_train:       # secondary figure: the full training step on the batches that follow
+    eng.dropout = float(args.train_dropout)        # nn.MultiheadAttention(dropout=0.4) in train() mode, train.py:30
     eng.optimizer(lr=1e-4)
     tb = batches[args.warmup + args.steps * max_repeats:]
     for b in tb[:5]:
@@ -277,7 +356,7 @@ def main():
     barrier()
     t1 = time.perf_counter() - t1
     train = {"edges_per_s": args.train_steps * gbs / t1, "ms_per_step": 1e3 * t1 / args.train_steps,
-             "steps": args.train_steps, "last_loss": float(loss),
+             "steps": args.train_steps, "last_loss": float(loss), "dropout": float(args.train_dropout),
              "what": "train-ordered forward + BCE loss + backward (attention x layers, GRU) + Adam + blob re-pack; "
                      "backward per layer = fused row-chain kernels + single-pass per-query kernels + one weight-gradient GEMM; "
                      "fused Adam; forward issued by the C++ step driver (training capture), backward dispatched from Python"}
@@ -358,6 +437,22 @@ def main():
     if world == 1 and args.cpu_batches > 0:
       threads = min(16, os.cpu_count() or 1)
       out["cpu_baseline"] = cpu_baseline(args, csr, ef, sd, batches[args.warmup:], threads)
+    default_workload = (world == 1 and not args.no_reuse and args.layers == 2 and args.d_e == 172 and args.k == 10 and
+                        args.sampling == "recent" and args.nodes == 1_000_000 and args.edges == 100_000_000)
+    if default_workload and args.extra_configs:
+      # BASELINE.json's other configurations as labelled secondary entries (the bench line proper is configs[3])
+      del eng, csr, ef, batches, neg_all, src, dst, eidx, ts
+      torch.cuda.empty_cache()
+      out["extra"] = {"config4": {"edges_per_s": out["value"], "ms_per_step": out["ms_per_step"],
+                                  "workload": "this line's own workload (BASELINE.json configs[3])"}}
+      for key in args.extra_configs.split(","):
+        c = EXTRA_CONFIGS.get(key.strip())
+        if c is None:
+          continue
+        try:
+          out["extra"][c["name"]] = run_extra_config(c, dev)
+        except Exception as ex:        # a secondary figure must not cost the line (e.g. less free HBM than config 5 needs)
+          out["extra"][c["name"]] = {"error": f"{type(ex).__name__}: {ex}"}
     print(json.dumps(out), flush=True)
   if world > 1:
     import torch.distributed as dist

@@ -63,6 +63,11 @@ int orca_message_store_winners(const int64_t* src, const int64_t* dst, const int
                                const float* time_w, const float* time_b, const uint8_t* winner, int64_t n_nodes,
                                float* messages, float* msg_ts, uint8_t* pending, void* stream);
 
+// orca_find_uncached without the order: out[0 .. *count) holds the same ids in no particular order (state.hip)
+int orca_find_uncached_unordered(const int32_t* nbr, int64_t n_nbr, const int64_t* batch_nodes, int64_t n_batch,
+                                 const uint8_t* cache_flag, int64_t* slot, int64_t epoch, int64_t n_nodes, uint32_t* bitmap,
+                                 int64_t* out, int64_t cap, int32_t* count, void* stream);
+
 // orca_tgat_forward with the step driver's extra row writes fused in (either half may be left null):
 //  persist: a query q < persist_n whose source row was read from the overlay (src_flags[row] set) also commits it:
 //           persist_memory[row] = that row, persist_last_update[row] = persist_msg_ts[row]  (memory_updater.py:25-39;

@@ -224,7 +224,9 @@ struct begin_gru {
   const float *x, *h;
   float* out;
 };
-template <bool WITH_GRU>     // the GRU role raises the register count of the whole kernel: the plain variant keeps its occupancy
+// GRU_MSG: the message width of the GRU role (472 = the 172-d datasets, 301 = the zero-feature ones; 0 = no GRU role:
+// it raises the register count of the whole kernel, and the plain variant keeps its occupancy)
+template <int GRU_MSG>
 __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
@@ -239,9 +241,10 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const int64_t* a = i < bs ? src : (i < 2 * bs ? dst - bs : neg - 2 * bs);
     return a[i];
   };
+  constexpr bool WITH_GRU = GRU_MSG != 0;
   if (WITH_GRU && (int)blockIdx.x < gru.n_blocks) {
     static_assert(sizeof(tab) >= sizeof(f32x4) * GRU_SUBS * (GRU_KW - 1) * 3 * 64, "GRU partial sums must fit the election tables");
-    gru_split_workgroup<3 * ORCA_D + 172, 2, 1, GRU_SUBS>(gru.blob, gru.ids, gru.n_max, gru.n_dev, gru.x, gru.h, gru.out, nullptr,
+    gru_split_workgroup<WITH_GRU ? GRU_MSG : 3 * ORCA_D + 172, 2, 1, GRU_SUBS>(gru.blob, gru.ids, gru.n_max, gru.n_dev, gru.x, gru.h, gru.out, nullptr,
                                                           nullptr, (int)blockIdx.x * GRU_SUBS, gru.n_wg,
                                                           reinterpret_cast<f32x4 (*)[1][3][64]>(tab), nullptr);
     return;
@@ -676,7 +679,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     if (e->overlay_complete) {
       const int32_t* ids = d.eager_ids + (int64_t)(e->cur ^ 1) * d.q_max;
       const int64_t tiles = ceil_div64(e->list_bound, 16);
-      if (d.d_e == 172 && e->fuse_gru && !e->timed_step && tiles <= GRU_SPLIT_TILES) {
+      if ((d.d_e == 172 || d.d_e == 1) && e->fuse_gru && !e->timed_step && tiles <= GRU_SPLIT_TILES) {
         // a role of the first kernel (begin_gru): every tile has its GRU_NWG groups, so a group loops at most once
         gru.n_wg = (int)tiles * GRU_NWG;
         gru.n_blocks = (int)ceil_div64(gru.n_wg, GRU_SUBS);
@@ -721,12 +724,16 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     begin_sample smp{e->sampling, e->seed, {}};
     if ((rc = orca_csr_fences(d.csr, &smp.fences)) != ORCA_OK) return rc;
     Timed t(e, ORCA_PROF_SAMPLE, stream);
-    if (gru.n_blocks)
-      ORCA_LAUNCH_TIMED(k_begin_queries<true>, (unsigned)(gru.n_blocks + nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
+    if (gru.n_blocks && d.d_e == 1)
+      ORCA_LAUNCH_TIMED(k_begin_queries<3 * ORCA_D + 1>, (unsigned)(gru.n_blocks + nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
+                        bs, d.nodes, d.qts, d.nodes32, gru, el, nbs, d.n_nodes,
+                        indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
+    else if (gru.n_blocks)
+      ORCA_LAUNCH_TIMED(k_begin_queries<3 * ORCA_D + 172>, (unsigned)(gru.n_blocks + nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
                         bs, d.nodes, d.qts, d.nodes32, gru, el, nbs, d.n_nodes,
                         indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
     else
-      ORCA_LAUNCH_TIMED(k_begin_queries<false>, (unsigned)(nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
+      ORCA_LAUNCH_TIMED(k_begin_queries<0>, (unsigned)(nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
                         bs, d.nodes, d.qts, d.nodes32, gru, el, nbs, d.n_nodes,
                         indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
     ORCA_LAUNCH_CHECK();
@@ -914,8 +921,8 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
   k_budget_roots<<<1, 1024, 0, s>>>(src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32, tmax);
   ORCA_LAUNCH_CHECK();
   STEP(orca_sample_recent(d.csr, d.nodes, d.qts, Q, K, nbr_top, eid_top, et_top, dt_top, nullptr, stream_));
-  STEP(orca_find_uncached(nbr_top, Q * K, d.nodes, Q, cache_flag, d.slot, take_epochs(e, 1), d.n_nodes, bitmap, unc, cap,
-                          unc_count, stream_));
+  STEP(orca_find_uncached_unordered(nbr_top, Q * K, d.nodes, Q, cache_flag, d.slot, take_epochs(e, 1), d.n_nodes, bitmap, unc,
+                                    cap, unc_count, stream_));
   k_budget_cnodes<<<(unsigned)ceil_div64(cap, 256), 256, 0, s>>>(unc, unc_count, cap, Q, tmax, d.nodes, d.nodes32, d.qts, err);
   ORCA_LAUNCH_CHECK();
   // layer 1 over [roots; uncached]: neighbours, updated memory of what they read (:224-246), attention
@@ -958,11 +965,20 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
   // the state moves on (tgn_model.py:127-145): persist the positives' memory, store the raw messages -- in that order
   // when training, the other way round in evaluation
   auto persist = [&]() -> int {
+    // Train order: the overlay already holds GRU(message, memory) of every pending positive -- the roots are part of the
+    // work-list above -- so the rows are committed by one copy kernel, and the flags need no clearing: the message store
+    // that follows raises them for exactly these ids (as orca_engine_finish does for Path B).
+    if (train)
+      return orca_persist_overlay(d.nodes, 2 * bs, d.pending, d.overlay, d.memory, d.last_update, d.msg_ts, d.n_nodes, stream_);
+    // Evaluation order: GRU of the messages just stored, out of place into the overlay (the split kernels; in place a row
+    // would have to be read and written by one workgroup), then the commit.  The overlay rows of ids that stop being
+    // pending are dead.
     STEP(orca_worklist_build(nullptr, 0, d.nodes, 2 * bs, d.pending, d.slot, take_epochs(e, 2 * bs), d.n_nodes, d.worklist,
                              d.count, stream_));
     const int64_t bound = 2 * bs < d.n_nodes ? 2 * bs : d.n_nodes;
-    STEP(orca_gru_update(d.gru_blob, 300 + d.d_e, d.worklist, bound, d.count, d.messages, d.memory, d.memory, d.last_update,
-                         d.msg_ts, stream_));
+    STEP(orca_gru_update(d.gru_blob, 300 + d.d_e, d.worklist, bound, d.count, d.messages, d.memory, d.overlay, nullptr,
+                         nullptr, stream_));
+    STEP(orca_commit_rows(d.worklist, bound, d.count, d.overlay, d.memory, d.last_update, d.msg_ts, d.n_nodes, stream_));
     return orca_set_flags(d.pending, d.nodes, nullptr, 2 * bs, nullptr, 0, d.n_nodes, stream_);
   };
   if (train) STEP(persist());

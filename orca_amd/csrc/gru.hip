@@ -404,6 +404,7 @@ static int gru_launch_stream(const float* blob, const int32_t* ids, int64_t n, c
   return ORCA_OK;
 }
 
+template <int MSG = 3 * D + 172>
 static int gru_launch_split(const float* blob, const int32_t* ids, int64_t n, const int32_t* n_dev, const float* x,
                             const float* h, float* out, float* last_update, const float* msg_ts, hipStream_t stream,
                             float* save_gates = nullptr) {
@@ -411,7 +412,7 @@ static int gru_launch_split(const float* blob, const int32_t* ids, int64_t n, co
   // 19.1 us on an isolated 2084-row work-list but 1 % slower inside the step, and slower at 2730 rows (24.0 vs 22.3)
   const int64_t tiles = ceil_div64(n, 16);
   const unsigned grid = (unsigned)((tiles < GRU_SPLIT_TILES ? tiles : GRU_SPLIT_TILES) * NWG);
-  ORCA_LAUNCH_TIMED((k_gru_split<3 * D + 172, 3, 1>), grid, GRU_KW * 64, 0, stream, blob, ids, n, n_dev, x, h, out, last_update,
+  ORCA_LAUNCH_TIMED((k_gru_split<MSG, 3, 1>), grid, GRU_KW * 64, 0, stream, blob, ids, n, n_dev, x, h, out, last_update,
                     msg_ts, g_gru_clock, save_gates);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
@@ -444,6 +445,9 @@ ORCA_API int orca_gru_update(const float* blob, int msg_dim, const int32_t* ids,
   if (out == h) return gru_launch_rows(blob, msg_dim, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
   // out of place with an id list at the common message width (d_e = 172): (16-row tile) x (hidden tile)
   // workgroups streaming their operands; anything else (other widths, ids == NULL) takes the row kernel
+  // (the zero-feature datasets' width, train.py:139-142 d_e = 1: the same split kernel; its grid loops over the row tiles)
+  if (msg_dim == 3 * D + 1 && ids)
+    return gru_launch_split<3 * D + 1>(blob, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
   if (msg_dim != 3 * D + 172 || !ids)
     return gru_launch_rows(blob, msg_dim, ids, n, n_dev, x, h, out, last_update, msg_ts, (hipStream_t)stream);
   // a device-counted work-list (launch bound far above the real row count) or a few thousand rows: latency is what

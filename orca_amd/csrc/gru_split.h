@@ -15,12 +15,20 @@ constexpr int GRU_SPLIT_TILES = 384;  // row tiles the grid covers in one pass (
 // offset by the lane); the MT tiles share every weight fragment.  Fully unrolled and branch-free; only the LAST
 // step can reach past the row (WIDTH_LEFT = columns of the row that remain at the first k-block): its load is
 // clamped and its fragment zeroed when consumed.
-template <int NSTEP, int GS, int MT, typename WidthLeft>
+// ODD: the row width is not a multiple of 4 floats (the zero-feature datasets' 301-wide message, train.py:139-142): rows
+// then start at any 4-byte boundary -- the 16-byte fragment loads say so (f32x4u) -- and the row's last fragment is loaded
+// element by element, each column clamped, so that nothing is read past the row's end.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int NSTEP, int GS, int MT, bool ODD, typename WidthLeft>
 __device__ __forceinline__ void gru_chain(const float* const (&arow)[MT], const f32x4* const (&bgate)[3], int kq,
                                           WidthLeft width_left, f32x4 (&acc)[MT][3]) {
   static_assert(GS <= NSTEP, "ring deeper than the chain");
   f32x4 bq[GS][3], aq[GS][MT];
   auto last_ok = [&]() { return (NSTEP - 1) * 16 + kq < width_left; };
+  auto load_a = [&](const float* p) -> f32x4 {
+    if constexpr (ODD) return *reinterpret_cast<const f32x4u*>(p);
+    else return *reinterpret_cast<const f32x4*>(p);
+  };
   auto fill = [&](auto J) {
     constexpr int j = decltype(J)::value;
     if constexpr (j < NSTEP) {
@@ -28,8 +36,19 @@ __device__ __forceinline__ void gru_chain(const float* const (&arow)[MT], const 
       for (int k = 0; k < 3; ++k) bq[j % GS][k] = bgate[k][j * 64];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        if constexpr (j < NSTEP - 1) aq[j % GS][m] = *reinterpret_cast<const f32x4*>(arow[m] + j * 16);
-        else                         aq[j % GS][m] = *reinterpret_cast<const f32x4*>(arow[m] + (last_ok() ? j * 16 : 0));
+        if constexpr (j < NSTEP - 1) {
+          aq[j % GS][m] = load_a(arow[m] + j * 16);
+        } else if constexpr (ODD) {
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int c = j * 16 + kq + k;          // column counted from this wave's first one
+            v[k] = arow[m][c < width_left ? j * 16 + k : 0];
+          }
+          aq[j % GS][m] = v;
+        } else {
+          aq[j % GS][m] = load_a(arow[m] + (last_ok() ? j * 16 : 0));
+        }
       }
     }
   };
@@ -43,8 +62,14 @@ __device__ __forceinline__ void gru_chain(const float* const (&arow)[MT], const 
     for (int m = 0; m < MT; ++m) {
       a[m] = aq[j % GS][m];
       if constexpr (j == NSTEP - 1) {
-        const bool ok = last_ok();
-        a[m] = f32x4{ok ? a[m][0] : 0.f, ok ? a[m][1] : 0.f, ok ? a[m][2] : 0.f, ok ? a[m][3] : 0.f};
+        if constexpr (ODD) {
+          const int c = j * 16 + kq;
+          a[m] = f32x4{c < width_left ? a[m][0] : 0.f, c + 1 < width_left ? a[m][1] : 0.f, c + 2 < width_left ? a[m][2] : 0.f,
+                       c + 3 < width_left ? a[m][3] : 0.f};
+        } else {
+          const bool ok = last_ok();
+          a[m] = f32x4{ok ? a[m][0] : 0.f, ok ? a[m][1] : 0.f, ok ? a[m][2] : 0.f, ok ? a[m][3] : 0.f};
+        }
       }
     }
 #pragma unroll
@@ -93,9 +118,12 @@ __device__ __forceinline__ void gru_split_workgroup(const float* __restrict__ bl
     part += sub * (GRU_KW - 1);
   }
   const long long clk0 = phase_clock ? wall_clock64() : 0;
-  static_assert(MSG % 4 == 0 && ORCA_D % 4 == 0, "a float4 A fragment must not straddle the end of a row");
-  constexpr int KBx = (MSG + 15) / 16, KBh = (ORCA_D + 15) / 16, SPW = KBx / (GRU_KW - 1), TR = 16 * MT;
-  static_assert(KBx % (GRU_KW - 1) == 0, "the message k-blocks must split evenly over the message waves");
+  static_assert(ORCA_D % 4 == 0, "a float4 fragment of a memory row must not straddle its end");
+  // the message k-blocks are dealt to the message waves SPW at a time; the last of them takes what is left (SPW_L)
+  constexpr int KBx = (MSG + 15) / 16, KBh = (ORCA_D + 15) / 16, SPW = (KBx + GRU_KW - 2) / (GRU_KW - 1), TR = 16 * MT;
+  constexpr int SPW_L = KBx - (GRU_KW - 2) * SPW;
+  constexpr bool ODD = MSG % 4 != 0;
+  static_assert(SPW_L >= 1, "every message wave has at least one k-block");
   constexpr int D = ORCA_D;
   constexpr int64_t PW_X = 0, PW_H = 3 * (int64_t)GRU_NWG * KBx * 256, BIAS = PW_H + 3 * (int64_t)GRU_NWG * KBh * 256;
   const int t = wg % GRU_NWG;                           // hidden-unit tile
@@ -157,8 +185,9 @@ __device__ __forceinline__ void gru_split_workgroup(const float* __restrict__ bl
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[m][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (act) {
-      if (hw) gru_chain<KBh, (GS < KBh ? GS : KBh), MT>(arow, bgate, kq, std::integral_constant<int, D>{}, acc);
-      else    gru_chain<SPW, GS, MT>(arow, bgate, kq, MSG - kb0 * 16, acc);
+      if (hw) gru_chain<KBh, (GS < KBh ? GS : KBh), MT, false>(arow, bgate, kq, std::integral_constant<int, D>{}, acc);
+      else if (SPW_L != SPW && wave == GRU_KW - 2) gru_chain<SPW_L, (GS < SPW_L ? GS : SPW_L), MT, ODD>(arow, bgate, kq, MSG - kb0 * 16, acc);
+      else gru_chain<SPW, GS, MT, ODD>(arow, bgate, kq, MSG - kb0 * 16, acc);
     }
     if (phase_clock) clk2 = wall_clock64();
 

@@ -620,8 +620,9 @@ constexpr int KC = 10;   // neighbour rows a wave keeps in registers at a time
 
 // The K key rows [nbr(100) | edge(d_e) | time(100)] of one query, spread over the 64 lanes: lane l holds
 // columns l and l+64 of the nbr and time parts and columns l, l+64, l+128 of the edge part.
+template <int ME>     // ME = edge-feature registers per lane and slot: ceil(d_e / 64), or MAXE for a run-time width
 struct KeyRows {
-  float na[KC], nb[KC], e[KC][MAXE];
+  float na[KC], nb[KC], e[KC][ME];
 };
 struct KeyTimes {
   float ta[KC], tb[KC];
@@ -634,7 +635,8 @@ struct QuerySlots {   // lane j (< K) describes neighbour slot j of this wave's 
 };
 
 // Issues the global loads of slots j0 .. j0+KC-1 (all in flight at once; nothing here waits on them).
-__device__ __forceinline__ void load_key_rows(KeyRows& R, KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S,
+template <int ME>
+__device__ __forceinline__ void load_key_rows(KeyRows<ME>& R, KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S,
                                               int64_t q, int j0, int K, int d_e, int lane) {
   const int c1 = lane + 64;
 #pragma unroll
@@ -651,7 +653,7 @@ __device__ __forceinline__ void load_key_rows(KeyRows& R, KeyTimes& T, const orc
       R.na[j] = np[lane];
       R.nb[j] = np[c1 < D ? c1 : 0];
 #pragma unroll
-      for (int i = 0; i < MAXE; ++i) {
+      for (int i = 0; i < ME; ++i) {
         const int c = lane + 64 * i;
         R.e[j][i] = ep[c < d_e ? c : 0];
       }
@@ -663,7 +665,7 @@ __device__ __forceinline__ void load_key_rows(KeyRows& R, KeyTimes& T, const orc
     } else {
       R.na[j] = R.nb[j] = 0.f;
 #pragma unroll
-      for (int i = 0; i < MAXE; ++i) R.e[j][i] = 0.f;
+      for (int i = 0; i < ME; ++i) R.e[j][i] = 0.f;
       if (!in.dt) T.ta[j] = T.tb[j] = 0.f;
     }
   }
@@ -765,6 +767,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   const Blob L = DE ? LC : blob_layout(d_e);
   constexpr int KBT_C = DE ? LC.KBT : 0;         // k-blocks of the folded tail (0 = run time)
   constexpr bool FOLD_ALL = DE && LC.NTk == 24;  // every (head, slot) wave of P2 owns exactly 3 live tiles
+  constexpr int ME = DE ? (DE + 63) / 64 : MAXE;  // edge-feature registers per lane and slot
   const int kdim = L.kdim;
   const int KPS = L.KP;                           // columns of one head's q~ / x-bar
   const int RS = L.KBT * 16 + 4;                  // row stride of the tail input [x-bar_0 | x-bar_1 | src | 0]
@@ -924,7 +927,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     if (!live_q) {
       for (int c = lane; c < 2 * KPS; c += 64) xb0[c] = 0.0f;
     } else {
-      KeyRows R;
+      KeyRows<ME> R;
       load_key_rows(R, T, in, S, q, 0, K, d_e, lane);
       unsigned long long livebits = __ballot(lane < K && !S.masked);
       const bool invalid = livebits == 0ull;                           // temporal_attention.py:46
@@ -936,9 +939,9 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       const int tb = D + d_e;
       const float qn0a = xb0[lane], qn1a = xb1[lane];
       const float qn0b = c1 < D ? xb0[c1] : 0.f, qn1b = c1 < D ? xb1[c1] : 0.f;
-      float qe0[MAXE], qe1[MAXE];
+      float qe0[ME], qe1[ME];
 #pragma unroll
-      for (int i = 0; i < MAXE; ++i) {
+      for (int i = 0; i < ME; ++i) {
         const int c = lane + 64 * i;
         qe0[i] = c < d_e ? xb0[D + c] : 0.f;
         qe1[i] = c < d_e ? xb1[D + c] : 0.f;
@@ -972,7 +975,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
           p0[j] = R.na[j] * qn0a + R.nb[j] * qn0b + T.ta[j] * qt0a + T.tb[j] * qt0b;
           p1[j] = R.na[j] * qn1a + R.nb[j] * qn1b + T.ta[j] * qt1a + T.tb[j] * qt1b;
 #pragma unroll
-          for (int i = 0; i < MAXE; ++i) {
+          for (int i = 0; i < ME; ++i) {
             p0[j] += R.e[j][i] * qe0[i];
             p1[j] += R.e[j][i] * qe1[i];
           }
@@ -1036,9 +1039,9 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       }
       // x-bar_h = sum_j a_hj x_j
       float an0 = 0.f, an1 = 0.f, bn0 = 0.f, bn1 = 0.f, at0 = 0.f, at1 = 0.f, bt0 = 0.f, bt1 = 0.f;
-      float ae0[MAXE], ae1[MAXE];
+      float ae0[ME], ae1[ME];
 #pragma unroll
-      for (int i = 0; i < MAXE; ++i) { ae0[i] = 0.f; ae1[i] = 0.f; }
+      for (int i = 0; i < ME; ++i) { ae0[i] = 0.f; ae1[i] = 0.f; }
       auto accumulate = [&](float a_c) {
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
@@ -1047,7 +1050,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
           an0 += w0 * R.na[j]; an1 += w1 * R.na[j]; bn0 += w0 * R.nb[j]; bn1 += w1 * R.nb[j];
           at0 += w0 * T.ta[j]; at1 += w1 * T.ta[j]; bt0 += w0 * T.tb[j]; bt1 += w1 * T.tb[j];
 #pragma unroll
-          for (int i = 0; i < MAXE; ++i) { ae0[i] += w0 * R.e[j][i]; ae1[i] += w1 * R.e[j][i]; }
+          for (int i = 0; i < ME; ++i) { ae0[i] += w0 * R.e[j][i]; ae1[i] += w1 * R.e[j][i]; }
         }
       };
       if (K > KC) {          // the registers hold slots KC..K-1: use them, then fetch slots 0..KC-1 again (L2 hits)
@@ -1059,7 +1062,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       xb0[lane] = an0; xb1[lane] = an1;
       if (c1 < D) { xb0[c1] = bn0; xb1[c1] = bn1; }
 #pragma unroll
-      for (int i = 0; i < MAXE; ++i) {
+      for (int i = 0; i < ME; ++i) {
         const int c = lane + 64 * i;
         if (c < d_e) { xb0[D + c] = ae0[i]; xb1[D + c] = ae1[i]; }
       }
@@ -1209,7 +1212,9 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
     const int lim = 160 * 1024 - 256;
     const void* fns[] = {(const void*)k_tgat_forward<10, 172, false>, (const void*)k_tgat_forward<10, 172, true>,
                          (const void*)k_tgat_forward<10, 0, false>,   (const void*)k_tgat_forward<10, 0, true>,
-                         (const void*)k_tgat_forward<0, 0, false>,    (const void*)k_tgat_forward<0, 0, true>};
+                         (const void*)k_tgat_forward<0, 0, false>,    (const void*)k_tgat_forward<0, 0, true>,
+                         (const void*)k_tgat_forward<10, 1, false>,   (const void*)k_tgat_forward<10, 1, true>,
+                         (const void*)k_tgat_forward<20, 1, false>,   (const void*)k_tgat_forward<20, 1, true>};
     for (const void* f : fns) ORCA_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
   ORCA_REQUIRE(lds_bytes <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds_bytes);
@@ -1226,8 +1231,14 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
       ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, false>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, \
                         out_weights, side, g_phase_clock);                                                      \
   } while (0)
+  // compile-time shapes: the reference's default (n_degree 10, 172-d Wikipedia / Reddit features), and the zero-feature
+  // datasets (train.py:139-142: d_e = 1) at n_degree 10 (BASELINE config 3) and 20 (config 5)
   if (K == 10 && d_e == 172)
     ORCA_TGAT_LAUNCH(10, 172);
+  else if (K == 10 && d_e == 1)
+    ORCA_TGAT_LAUNCH(10, 1);
+  else if (K == 20 && d_e == 1)
+    ORCA_TGAT_LAUNCH(20, 1);
   else if (K == 10)
     ORCA_TGAT_LAUNCH(10, 0);
   else

@@ -537,12 +537,18 @@ class OrcaEngine:
     self._timed("gru_update", ops.gru_update, self.gru_blob, self.msg_dim, self.worklist, bound, self.count,
                 self.messages, self.memory, self.overlay)
 
-  def _persist_memory(self, ids64):
-    """memory_updater.update_memory (:25-39) + memory.clear_messages (memory.py:49-50)."""
-    bound = self._build_worklist(None, ids64, ids64.numel())
-    self._await_packed()
-    ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory,
-                   self.memory, self.last_update, self.msg_ts)
+  def _persist_memory(self, ids64, overlay_covers=False):
+    """memory_updater.update_memory (:25-39) + memory.clear_messages (memory.py:49-50).  overlay_covers: the overlay
+    already holds GRU(message, memory) of every pending id of ids64 (a train-ordered batch on one rank: its roots are
+    part of the rows it read), so the rows are committed by a copy -- as the native driver does; otherwise the GRU runs
+    out of place into the overlay (the split kernels) and the rows are committed from there."""
+    if overlay_covers:
+      ops.persist_overlay(ids64, self.pending, self.overlay, self.memory, self.last_update, self.msg_ts)
+    else:
+      bound = self._build_worklist(None, ids64, ids64.numel())
+      self._await_packed()
+      ops.gru_update(self.gru_blob, self.msg_dim, self.worklist, bound, self.count, self.messages, self.memory, self.overlay)
+      ops.commit_rows(self.worklist, bound, self.count, self.overlay, self.memory, self.last_update, self.msg_ts)
     ops.set_flags(self.pending, ids64=ids64, v=0)
 
   def _flush_all_pending(self):
@@ -739,7 +745,7 @@ class OrcaEngine:
     else:
       emb = self._embed_exact(nodes, t3, train)
     if train:                                          # :127-129
-      self._persist_memory(positives)
+      self._persist_memory(positives, overlay_covers=self.world == 1)
     ops.message_store(src, dst, eidx, ts, self.memory, self.last_update, self.edge_feats, self.time_w, self.time_b,
                       self.slot, self._slot_epoch(2 * src.numel()), self.messages, self.msg_ts, self.pending)  # :131-141
     if not train:                                      # :143-145

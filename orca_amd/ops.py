@@ -430,6 +430,13 @@ def persist_overlay(ids64, pending, overlay, memory, last_update, msg_ts):
                                          ptr(msg_ts), memory.shape[0], stream()), "orca_persist_overlay")
 
 
+def commit_rows(ids32, n, n_dev, src_table, dst_table, last_update=None, msg_ts=None):
+  """dst_table[id] = src_table[id] (+ last_update[id] = msg_ts[id]) for the ids of a device-counted work-list: the row
+  commit of update_memory (memory_updater.py:36-39) from rows the GRU wrote to the overlay"""
+  check(_lib.load().orca_commit_rows(ptr(ids32), int(n), ptr(n_dev), ptr(src_table), ptr(dst_table), ptr(last_update), ptr(msg_ts),
+                                     dst_table.shape[0], stream()), "orca_commit_rows")
+
+
 def gru_update(blob, msg_dim, ids, n, n_dev, x, h, out, last_update=None, msg_ts=None, gates=None):
   """gates: float32 [>= n * 4 * 100] -- orca_gru_update_saving (keeps r, z, n, h_n per row for gru_backward(gates=))"""
   if gates is not None:
