@@ -230,3 +230,28 @@ def test_exchange_helpers_on_rccl_single_rank():
   ok, msg = q.get(timeout=240)
   p.join(timeout=60)
   assert ok, msg
+
+
+def test_bench_launches_its_own_ranks():
+  """`python bench.py --gpus 2` with no launcher in front -- the command form of the driver's scaling run -- starts its
+  ranks itself (torch.distributed.run, 127.0.0.1) and rank 0 prints the one JSON line.  Rehearsed with two gloo ranks
+  sharing this box's GPU (RCCL refuses two ranks per device) on a small graph; what is checked is the launcher path and
+  the line's contract, not a rate."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, ORCA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+  env.pop("WORLD_SIZE", None)
+  env.pop("RANK", None)
+  cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--nodes", "20000",
+         "--edges", "400000", "--bs", "200", "--min-region-ms", "1", "--cpu-batches", "0", "--train-steps", "0",
+         "--path-a-steps", "0", "--extra-configs", ""]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+  assert r.returncode == 0, r.stderr[-3000:]
+  lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+  assert len(lines) == 1, r.stdout[-2000:]
+  d = json.loads(lines[0])
+  assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
+  assert np.isfinite(d["value"]) and d["value"] > 0 and d["unit"] == "temporal edges/s"
+  assert "2 ranks" in d["config"]["parallelism"]
