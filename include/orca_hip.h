@@ -531,6 +531,39 @@ int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst,
 /* owner-computes step: after the xm all-gather, overlay[id] = row and pending[id] = 1 for every id any rank sent */
 int orca_engine_apply(orca_engine_t* e, void* stream);
 
+/* Budget-bounded history for orca_engine_step_budget (north_star: "a GPU-resident index-and-gather with budget-bounded
+ * eviction"; replaces the dense [n_nodes, ORCA_D] table of modules/history.py:11 under --budget B).  All device memory,
+ * caller-owned:
+ *   rows      [n_slots, ORCA_D]  slot 0 is a zero row (an id that was never pushed, the padding id 0) and is never handed out
+ *   slot_of   int32 [n_nodes]    id -> slot, <= 0: none            (initialise to -1)
+ *   slot_id   int32 [n_slots]    slot -> id, < 0: free             (initialise to -1)
+ *   free_list int32 [n_slots]    free slots BELOW the high-water mark, ascending, handed out from state[0] on
+ *   state     int32 [8]          [0] slots handed out since the last eviction, [1] entries of free_list, [2] error bits,
+ *                                [3] ids in prev_plan, [4] high-water mark: every slot from it up is free
+ *                                (initialise to 0, 0, 0, 0, 1)
+ *   pull_idx  int32 [3*bs*K]     work buffer: the slot of every sampled neighbour of the batch
+ *   prev_plan int64 [prev_cap]   the plan of the last step (whose flags the next one clears)
+ * n_slots must exceed budget + 3*bs + cap (every node evaluated in a batch gets a slot until the plan decides) and is at
+ * most 65536.  With a cache set, a step pushes the evaluated rows into slots, pulls through slot_of, makes cache_flag
+ * exactly the plan (history.py:25-30) and frees every slot whose id the plan does not keep.  It needs a plan (plan_n >= 0):
+ * a plan of the reference's planner only keeps ids that were kept before or evaluated in this batch, so every kept id has a
+ * row.  Differences from the dense table, both outside what the planner produces: a flagged id WITHOUT a row reads zeros
+ * (dense: whatever was pushed last, however long ago), and so does the one uncached id that embedding_module.py:212's
+ * `[1:]` drops when it is not the padding id.  orca_slot_cache_materialize writes the dense view (rows of the ids that
+ * hold a slot; the caller zeroes `dense` first). */
+typedef struct {
+  float* rows;
+  int32_t* slot_of;
+  int32_t* slot_id;
+  int32_t* free_list;
+  int32_t* state;
+  int32_t* pull_idx;
+  int64_t* prev_plan;
+  int64_t n_slots, prev_cap;
+} orca_slot_cache;
+int orca_engine_set_slot_cache(orca_engine_t* e, const orca_slot_cache* cache);    /* NULL or rows == NULL: back to hist[0] */
+int orca_slot_cache_materialize(const orca_slot_cache* cache, int64_t n_nodes, float* dense, void* stream);
+
 /* The root queries of a batch (model/tgn_model.py:99-102: nodes = [src; dst; neg], timestamps = [t; t; t]) in one launch:
  * nodes int64 [3*bs], qts double [3*bs], nodes32 = the ids as int32; *tmax (device double, may be NULL) = max t. */
 int orca_build_roots(const int64_t* src, const int64_t* dst, const int64_t* neg, const double* ts, int64_t bs,
@@ -542,7 +575,7 @@ int orca_build_roots(const int64_t* src, const int64_t* dst, const int64_t* neg,
  * push, cache flags (history.py:25-30: the plan's ids when plan_n >= 0, else every evaluated id) -> layer 2 over the
  * roots -> memory persist + raw-message store (tgn_model.py:127-145, order by `train`).  out [3*bs, ORCA_D].  Uses the
  * tables and work buffers of the engine's descriptor (3*bs + cap <= q_max); cache_flag uint8 [n_nodes]; bitmap as in
- * orca_find_uncached; tmax device double [1].  More uncached ids than `cap` set bit 1 of *err (device int, may be
+ * orca_find_uncached; unc_count device int [2] (word 0 = the count, word 1 scratch); tmax device double [1].  More uncached ids than `cap` set bit 1 of *err (device int, may be
  * NULL): the step then evaluated only the first `cap` of them. */
 int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
                             const double* ts, const int64_t* eidx, int64_t bs, int train, const int64_t* plan,

@@ -36,6 +36,12 @@ class TgatParams(ctypes.Structure):
 ORCA_ENGINE_MAX_LAYERS = 4
 
 
+class SlotCache(ctypes.Structure):
+  """orca_slot_cache (include/orca_hip.h): the budget-bounded history of the native Path C step."""
+  _fields_ = [(n, vp) for n in ("rows", "slot_of", "slot_id", "free_list", "state", "pull_idx", "prev_plan")] + \
+             [("n_slots", i64), ("prev_cap", i64)]
+
+
 class EngineDesc(ctypes.Structure):
   """orca_engine_desc (include/orca_hip.h)."""
   _fields_ = ([("n_nodes", i64), ("n_layers", ctypes.c_int32), ("K", ctypes.c_int32), ("d_e", ctypes.c_int32),
@@ -125,6 +131,8 @@ SIGNATURES = {
     "orca_engine_set_overlay_complete": (i32, [vp, i32]),
     "orca_engine_get_overlay_complete": (i32, [vp]),
     "orca_build_roots": (i32, [vp] * 4 + [i64] + [vp] * 5),
+    "orca_engine_set_slot_cache": (i32, [vp, vp]),
+    "orca_slot_cache_materialize": (i32, [vp, i64, vp, vp]),
     "orca_engine_step_budget": (i32, [vp] * 6 + [i64, i32, vp, i64, vp, vp, vp, i64] + [vp] * 9),
     "orca_engine_drain": (i32, [vp, vp]),
     "orca_mrd_plan_host": (i32, [i64, i64, i32, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]),

@@ -54,6 +54,7 @@ struct orca_engine {
   float cap_p;
   uint64_t cap_seed[ORCA_ENGINE_MAX_LAYERS];
   float* cap_gates;
+  orca_slot_cache sc;          // budget-bounded history of the native Path C step (orca_engine_set_slot_cache), rows == NULL: off
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ORCA_PROF_CLASSES];
 };
 
@@ -479,7 +480,7 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
                d.msg_ts && d.pending && d.overlay && d.slot && d.worklist && d.count && d.nodes && d.qts && d.nodes32 &&
                d.nbr && d.eid && d.et && d.dt && d.emb[0] && d.emb[1], "orca_engine_create: null table or work buffer");
   for (int l = 0; l < d.n_layers; ++l) ORCA_REQUIRE(d.att_blob[l], "orca_engine_create: missing attention blob %d", l);
-  for (int l = 0; l + 1 < d.n_layers; ++l) ORCA_REQUIRE(d.hist[l], "orca_engine_create: missing history table %d", l);
+  // (hist[l] may be NULL for a caller that keeps layer l's history in a slot cache: the steps that need the table say so)
   ORCA_REQUIRE(d.world <= 1 || (d.rank >= 0 && d.rank < d.world && d.q_max % d.world == 0),
                "orca_engine_create: bad rank %d of %d (q_max must be a multiple of world)", d.rank, d.world);
   orca_engine* e = new (std::nothrow) orca_engine();
@@ -502,6 +503,7 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
     const char* v = getenv("ORCA_FUSE_GRU");
     e->fuse_gru = !(v && v[0] == '0');
   }
+  e->sc = orca_slot_cache{};
   e->eidx = nullptr;
   e->overlay_complete = false;
   e->have_list = false;
@@ -777,6 +779,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     side.persist_n = 2 * bs;
     e->persist_done = true;
   }
+  ORCA_REQUIRE(d.n_layers < 2 || d.hist[0], "orca_engine_begin: no history table for layer 1");
   if (full && e->winners_valid && d.n_layers >= 2) {
     side.push_table = d.hist[0]; side.push_ids = d.nodes; side.push_winner = d.winners;
     e->pushed_layer = 1;
@@ -801,6 +804,7 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
   ORCA_REQUIRE(0 <= lo && lo <= hi && hi <= (e->sharded ? e->bs : e->Q), "orca_engine_layer: bad slice");
   if (e->Q == 0) return ORCA_OK;
   float* h = d.hist[layer - 2];
+  ORCA_REQUIRE(h && (layer == d.n_layers || d.hist[layer - 1]), "orca_engine_layer: no history table for layer %d", layer - 1);
   orca_tgat_inputs in{};
   in.nbr_table = h; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;   // pull (history.py:32-36) fused into the gather
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
@@ -887,7 +891,197 @@ __global__ void k_budget_cnodes(const int64_t* __restrict__ unc, const int32_t* 
   nodes32[Q + i] = ok ? (int32_t)id : 0;
   qts[Q + i] = *tmax;
 }
+
+// ---- budget-bounded history (slot cache) of the native Path C step ---------------------------------------------------
+// The reference keeps layer-1 embeddings in a dense [n_nodes, 100] table (modules/history.py:11) of which, under
+// --budget B, only the B rows of the current cache plan plus the rows pushed in the running batch are ever pulled
+// (embedding_module.py:186-212).  Here those rows live in `rows` [n_slots, 100] (slot 0 = a zero row: what the dense
+// table holds for an id that was never pushed, and for the padding id 0), found through slot_of [n_nodes] (id -> slot,
+// <= 0: none); slot_id [n_slots] is the inverse.  Free slots: every slot from state[4] (the high-water mark) up, plus the
+// state[1] entries of free_list below it, handed out in that order from state[0] on -- the used slots therefore stay
+// packed at the bottom of `rows`, and the eviction sweep only walks up to the mark.  BASELINE config 3
+// (1.14 M nodes, budget 1000): 3 MB of rows + 4.6 MB of index instead of 456 MB, and the pulls of layer 2 stay in L2.
+__global__ void k_slot_elect(const int64_t* __restrict__ ids, int64_t n, int64_t* slot, int64_t epoch, int64_t n_nodes) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int64_t id = ids[p];
+  if (id < 0 || id >= n_nodes) return;
+  atomicMax(reinterpret_cast<unsigned long long*>(&slot[id]), (unsigned long long)(epoch + p));
+}
+// history push (history.py:38-40; last occurrence wins): the winner position of every id writes its row.  A
+// thread per position finds the winners and whether they need a slot; the block takes its new slots with ONE atomicAdd
+// (a returning atomic per winner on the one counter serialised at L2: 15 us for 1500 winners), then its waves copy the
+// winners' rows.
+constexpr int SLOT_PUSH_THREADS = 256;      // positions per block: enough blocks for the row copies, few enough atomics
+__global__ __launch_bounds__(SLOT_PUSH_THREADS) void k_slot_push(const int64_t* __restrict__ ids, int64_t n,
+                                                                 const int64_t* __restrict__ elect, int64_t epoch, int64_t n_nodes,
+                                                                 const float* __restrict__ x, float* __restrict__ rows,
+                                                                 int32_t* __restrict__ slot_of, int32_t* __restrict__ slot_id,
+                                                                 const int32_t* __restrict__ free_list,
+                                                                 int32_t* __restrict__ state, int n_slots) {
+  constexpr int T = SLOT_PUSH_THREADS, NWV = T / 64;
+  __shared__ int wave_new[NWV], wave_win[NWV];
+  __shared__ int block_first, block_win;
+  __shared__ int32_t s_pos[T], s_slot[T];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t p = (int64_t)blockIdx.x * T + tid;
+  bool win = false, need = false;
+  int64_t id = -1;
+  int sl = 0;
+  if (p < n) {
+    id = ids[p];
+    win = id >= 0 && id < n_nodes && elect[id] == epoch + p;
+    if (win) { sl = slot_of[id]; need = sl <= 0; }
+  }
+  const unsigned long long m_new = __ballot(need), m_win = __ballot(win);
+  if (lane == 0) { wave_new[wave] = __popcll(m_new); wave_win[wave] = __popcll(m_win); }
+  __syncthreads();
+  if (tid == 0) {
+    int tn = 0, tw = 0;
+    for (int w = 0; w < NWV; ++w) { int c = wave_new[w]; wave_new[w] = tn; tn += c; c = wave_win[w]; wave_win[w] = tw; tw += c; }
+    block_win = tw;
+    block_first = tn ? atomicAdd(&state[0], tn) : 0;
+  }
+  __syncthreads();
+  if (need) {
+    const int k = block_first + wave_new[wave] + __popcll(m_new & ((1ull << lane) - 1ull)), n_listed = state[1];
+    sl = k < n_listed ? free_list[k] : state[4] + (k - n_listed);
+    if (sl < n_slots) {
+      slot_of[id] = sl;
+      slot_id[sl] = (int32_t)id;
+    } else {
+      atomicOr(&state[2], 1);          // no free slot: cannot happen while n_slots > budget + evaluated nodes
+      sl = 0;
+    }
+  }
+  if (win) {
+    const int j = wave_win[wave] + __popcll(m_win & ((1ull << lane) - 1ull));
+    s_pos[j] = tid;
+    s_slot[j] = sl;
+  }
+  __syncthreads();
+  // the winners' rows, 16 lanes a row (25 float4), four rows per wave and trip: every load of a trip is in flight at once
+  const int sub = lane & 15, grp = lane >> 4;
+  for (int j0 = wave * 4; j0 < block_win; j0 += NWV * 4) {
+    const int j = j0 + grp;
+    const bool on = j < block_win && s_slot[j < block_win ? j : 0] > 0;
+    const int jc = j < block_win ? j : 0;
+    const f32x4* src = reinterpret_cast<const f32x4*>(x + ((int64_t)blockIdx.x * T + s_pos[jc]) * ORCA_D);
+    f32x4* dst = reinterpret_cast<f32x4*>(rows + (int64_t)s_slot[jc] * ORCA_D);
+    const f32x4 a = src[sub], b2 = src[sub + 16 < ORCA_D / 4 ? sub + 16 : sub];
+    if (on) {
+      dst[sub] = a;
+      if (sub + 16 < ORCA_D / 4) dst[sub + 16] = b2;
+    }
+  }
+}
+// history pull (history.py:32-36) as an index translation: the attention kernel gathers rows[pull_idx[i]]
+__global__ void k_slot_translate(const int32_t* __restrict__ nbr, int64_t n, int64_t n_nodes, const int32_t* __restrict__ slot_of,
+                                 int32_t* __restrict__ pull_idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = nbr[i];
+  int sl = 0;
+  if (v >= 0 && v < n_nodes) sl = slot_of[v];
+  pull_idx[i] = sl > 0 ? sl : 0;
+}
+// update_flag (history.py:25-30: the flags become exactly the plan) and the eviction it implies: one workgroup clears the
+// previous plan's flags, marks the slots of the new plan's ids, frees every other used slot and rebuilds the free list
+// in slot order (deterministic), then remembers the plan for the next call.
+__global__ __launch_bounds__(1024) void k_slot_evict(const int64_t* __restrict__ plan, int64_t plan_n, int64_t n_nodes,
+                                                     int32_t* __restrict__ slot_of, int32_t* __restrict__ slot_id,
+                                                     int32_t* __restrict__ free_list, int32_t* __restrict__ state,
+                                                     int64_t n_slots, int64_t* __restrict__ prev_plan,
+                                                     uint8_t* __restrict__ cache_flag) {
+  __shared__ uint32_t keep[2048];                 // one bit per slot (n_slots <= 65536)
+  __shared__ int wave_n[16];
+  __shared__ int base, top;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // every load that depends on nothing is requested up front (one workgroup: the kernel is a chain of round trips)
+  const int s0 = state[0], s1 = state[1], s4 = state[4];
+  const int64_t prev_n = state[3];
+  constexpr int PRE = 4;                           // sweep chunks whose slot ids are fetched ahead
+  int32_t sid[PRE];
+#pragma unroll
+  for (int c = 0; c < PRE; ++c) {
+    const int64_t sl = (int64_t)c * 1024 + tid;
+    sid[c] = slot_id[sl < n_slots ? sl : n_slots - 1];
+  }
+  const int64_t my_plan = tid < plan_n ? plan[tid] : -1;
+  for (int i = tid; i < 2048; i += 1024) keep[i] = 0u;
+  for (int64_t i = tid; i < prev_n; i += 1024) {
+    const int64_t id = prev_plan[i];
+    if (id >= 0 && id < n_nodes) cache_flag[id] = 0;
+  }
+  if (tid == 0) { base = 0; top = 0; }
+  __syncthreads();
+  for (int64_t i = tid; i < plan_n; i += 1024) {
+    const int64_t id = i == tid ? my_plan : plan[i];
+    prev_plan[i] = id;
+    if (id < 0 || id >= n_nodes) continue;
+    cache_flag[id] = 1;
+    const int sl = slot_of[id];
+    if (sl > 0) { atomicOr(&keep[sl >> 5], 1u << (sl & 31)); atomicMax(&top, sl); }
+  }
+  __syncthreads();
+  // slots in use lie below the mark as the pushes of this step left it; after the sweep the mark drops to just above the
+  // highest kept slot, and the free slots below it are listed in ascending order
+  int64_t used_to = (int64_t)s4 + (s0 > s1 ? s0 - s1 : 0);
+  used_to = used_to < n_slots ? used_to : n_slots;
+  const int new_mark = top + 1;
+  for (int64_t c0 = 0; c0 < used_to; c0 += 1024) {
+    const int64_t sl = c0 + tid;
+    bool listed = false;
+    if (sl >= 1 && sl < used_to) {
+      const bool kept = (keep[sl >> 5] >> (sl & 31)) & 1u;
+      if (!kept) {
+        const int c = (int)(c0 >> 10);
+        int32_t id = c < PRE ? 0 : slot_id[sl];
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) id = c == k ? sid[k] : id;
+        if (id >= 0) { slot_of[id] = -1; slot_id[sl] = -1; }
+        listed = sl < new_mark;
+      }
+    }
+    const unsigned long long m = __ballot(listed);
+    if (lane == 0) wave_n[wave] = __popcll(m);
+    __syncthreads();
+    int off = base, total = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) off += wave_n[w]; total += wave_n[w]; }
+    if (listed) free_list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)sl;
+    __syncthreads();
+    if (tid == 0) base += total;
+    __syncthreads();
+  }
+  if (tid == 0) { state[0] = 0; state[1] = base; state[3] = (int32_t)plan_n; state[4] = new_mark; }
+}
+// dense[slot_id[s]] = rows[s]: the dense table of the reference (History.emb) for whoever wants to look at it
+__global__ __launch_bounds__(256) void k_slot_materialize(const float* __restrict__ rows, const int32_t* __restrict__ slot_id,
+                                                          int64_t n_slots, int64_t n_nodes, float* __restrict__ dense) {
+  const int lane = threadIdx.x & 63;
+  const int64_t sl = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (sl < 1 || sl >= n_slots) return;
+  const int64_t id = slot_id[sl];
+  if (id < 0 || id >= n_nodes) return;
+  for (int c = lane; c < ORCA_D; c += 64) dense[id * ORCA_D + c] = rows[sl * ORCA_D + c];
+}
 }  // namespace
+
+ORCA_API int orca_engine_set_slot_cache(orca_engine_t* e, const orca_slot_cache* c) {
+  ORCA_REQUIRE(e, "orca_engine_set_slot_cache: null handle");
+  if (!c || !c->rows) { e->sc = orca_slot_cache{}; return ORCA_OK; }
+  ORCA_REQUIRE(c->slot_of && c->slot_id && c->free_list && c->state && c->pull_idx && c->prev_plan && c->n_slots >= 2 &&
+               c->n_slots <= 65536 && c->prev_cap >= 0, "orca_engine_set_slot_cache: bad descriptor");
+  e->sc = *c;
+  return ORCA_OK;
+}
+
+ORCA_API int orca_slot_cache_materialize(const orca_slot_cache* c, int64_t n_nodes, float* dense, void* stream) {
+  ORCA_REQUIRE(c && c->rows && c->slot_id && dense && n_nodes > 0, "orca_slot_cache_materialize: null pointer");
+  k_slot_materialize<<<(unsigned)ceil_div64(c->n_slots, 4), 256, 0, (hipStream_t)stream>>>(c->rows, c->slot_id, c->n_slots, n_nodes, dense);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
 
 ORCA_API int orca_build_roots(const int64_t* src, const int64_t* dst, const int64_t* neg, const double* ts, int64_t bs,
                               int64_t* nodes, double* qts, int32_t* nodes32, double* tmax, void* stream) {
@@ -912,7 +1106,14 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
                (long long)(3 * bs + cap), (long long)d.q_max);
   if (bs == 0) return ORCA_OK;
   ORCA_REQUIRE(src && dst && neg && ts && eidx && cache_flag && bitmap && unc && unc_count && tmax && nbr_top && eid_top &&
-               et_top && dt_top && out && d.csr && d.hist[0], "orca_engine_step_budget: null pointer");
+               et_top && dt_top && out && d.csr, "orca_engine_step_budget: null pointer");
+  const bool slots = e->sc.rows != nullptr;
+  ORCA_REQUIRE(slots || d.hist[0], "orca_engine_step_budget: neither a history table nor a slot cache");
+  ORCA_REQUIRE(!slots || plan_n >= 0, "orca_engine_step_budget: the slot cache follows a cache plan; a step without one (flags "
+               "accumulate, history.py:25-30) needs the dense table -- materialise the slots and switch the cache off first");
+  ORCA_REQUIRE(!slots || (e->sc.n_slots > plan_n + 3 * bs + cap && plan_n <= e->sc.prev_cap),
+               "orca_engine_step_budget: slot cache of %lld rows / %lld plan ids is too small for plan %lld + %lld evaluated nodes",
+               (long long)e->sc.n_slots, (long long)e->sc.prev_cap, (long long)plan_n, (long long)(3 * bs + cap));
   const int64_t Q = 3 * bs, Qc = Q + cap;
   const int K = d.K;
 #define STEP(expr) do { const int rc_ = (expr); if (rc_ != ORCA_OK) return rc_; } while (0)
@@ -948,6 +1149,19 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
     STEP(orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, Qc, K, comb, nullptr, &side, stream_));
   }
   // push them (last occurrence wins, H7) and move the cache flags on (history.py:25-30)
+  if (slots) {
+    // budget-bounded history: the evaluated rows go to slots (the id -> slot index decides: reuse the id's slot or take a
+    // free one), the layer-2 pulls are translated to slot numbers, and what the plan does not keep is evicted
+    const orca_slot_cache& c = e->sc;
+    const int64_t ep = take_epochs(e, Qc);
+    k_slot_elect<<<(unsigned)ceil_div64(Qc, 256), 256, 0, s>>>(d.nodes, Qc, d.slot, ep, d.n_nodes);
+    k_slot_push<<<(unsigned)ceil_div64(Qc, SLOT_PUSH_THREADS), SLOT_PUSH_THREADS, 0, s>>>(d.nodes, Qc, d.slot, ep, d.n_nodes, comb, c.rows, c.slot_of, c.slot_id,
+                                                           c.free_list, c.state, (int)c.n_slots);
+    k_slot_translate<<<(unsigned)ceil_div64(Q * K, 256), 256, 0, s>>>(nbr_top, Q * K, d.n_nodes, c.slot_of, c.pull_idx);
+    k_slot_evict<<<1, 1024, 0, s>>>(plan, plan_n, d.n_nodes, c.slot_of, c.slot_id, c.free_list, c.state, c.n_slots, c.prev_plan,
+                                    cache_flag);
+    ORCA_LAUNCH_CHECK();
+  } else {
   STEP(orca_history_push(d.hist[0], comb, d.nodes, Qc, d.slot, take_epochs(e, Qc), d.n_nodes, stream_));
   if (plan_n >= 0) {
     STEP(orca_fill_u8(cache_flag, d.n_nodes, 0, stream_));
@@ -955,10 +1169,13 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
   } else {
     STEP(orca_set_flags(cache_flag, d.nodes, nullptr, Qc, nullptr, 1, d.n_nodes, stream_));
   }
+  }
   // layer 2 over the roots: their own layer-1 rows, neighbours pulled from the history table (:273-285)
   orca_tgat_inputs in2{};
   in2.src_table = comb;
-  in2.nbr_table = d.hist[0]; in2.nbr_idx = nbr_top; in2.nbr_ids = nbr_top;
+  in2.nbr_table = slots ? e->sc.rows : d.hist[0];
+  in2.nbr_idx = slots ? e->sc.pull_idx : nbr_top;
+  in2.nbr_ids = nbr_top;
   in2.edge_table = d.edge_feats; in2.edge_idx = eid_top;
   in2.dt = dt_top; in2.time_w = d.time_w; in2.time_b = d.time_b; in2.q_folded = d.att_q_folded;
   STEP(orca_tgat_forward_side(d.att_blob[1], d.d_e, &in2, Q, K, out, nullptr, nullptr, stream_));

@@ -475,7 +475,7 @@ namespace {
 __global__ void k_stamp_ids_zero(const int64_t* __restrict__ ids, int64_t n, int64_t* __restrict__ slot, int64_t epoch,
                                  int64_t n_nodes, int32_t* __restrict__ count) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *count = 0;
+  if (i == 0) { count[0] = 0; count[1] = 0; }
   if (i >= n) return;
   const int64_t v = ids[i];
   if (v >= 0 && v < n_nodes) slot[v] = epoch;
@@ -489,8 +489,13 @@ __global__ void k_mark_append(const int32_t* __restrict__ nbr, int64_t n, const 
   int64_t v = -1;
   if (i < n) {
     v = nbr[i];
-    if (v >= 0 && v < n_nodes && slot[v] != epoch && !cache_flag[v]) {
-      // test before set: padded slots all name node 0 and hubs repeat -- thousands of atomics on one word serialise at L2
+    if (v == 0) {
+      // the padding id: every short neighbourhood names it, hundreds of times per batch -- as many atomics on one bitmap
+      // word serialise at L2 (7 of this kernel's 15 us).  It is the set's smallest element whenever it is in the set, i.e.
+      // the one `[1:]` drops: it only has to be SEEN (count[1]), never listed.
+      if (slot[0] != epoch && !cache_flag[0]) count[1] = 1;
+    } else if (v > 0 && v < n_nodes && slot[v] != epoch && !cache_flag[v]) {
+      // test before set: hubs repeat -- many atomics on one word serialise at L2
       const uint32_t bit = 1u << (v & 31);
       if (!(__hip_atomic_load(&bitmap[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
         take = !(atomicOr(&bitmap[v >> 5], bit) & bit);           // the first setter owns the id
@@ -514,6 +519,7 @@ __global__ __launch_bounds__(1024) void k_drop_min_clear(int64_t* __restrict__ o
   __shared__ long long the_min;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t n = *count, stored = n < cap ? n : cap;
+  const bool zero_seen = count[1] != 0;          // the padding id is in the set: it is the element `[1:]` drops, and it is not listed
   long long mn = INT64_MAX;
   for (int64_t i = tid; i < stored; i += 1024) {
     const long long v = out[i];
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(1024) void k_drop_min_clear(int64_t* __restrict__ o
     the_min = m2;
   }
   __syncthreads();
-  if (n <= 0) return;
+  if (n <= 0 || zero_seen) return;               // (zero_seen: the count is already that of the set without its first element)
   // (with more ids than cap the true minimum may be among the ones that were not stored: the caller's overflow flag
   // already says the step is invalid; the stored list still loses one entry so that the count stays n - 1)
   const long long last = out[stored - 1];

@@ -36,14 +36,18 @@ D = ORCA_D
 class OrcaEngine:
   def __init__(self, state_dict, edge_feats, n_nodes, n_layers, n_neighbors, reuse=False, budget=0,
                device="cuda:0", group=None, sampling="recent", seed=0, exchange_cap=None, pretend=None, dropout=0.0,
-               gradient=False):
+               gradient=False, slot_history=None):
     """state_dict: the TGN state_dict of the reference (key names of SURVEY §8b); edge_feats
     [n_edges+1, d_e] (row 0 = padding); n_nodes = number of table rows (args.n_nodes, train.py:129).
     sampling: "recent" (the reference's NeighborFinder) or "uniform" (seeded, not in the reference: BASELINE
     config 5) with `seed`.  exchange_cap: rows a rank can send per owner-computes step (default: 1.25 x its even
     share of the batch's positives + 256, at most all of them); a batch that gives one owner more raises at the
     next check_errors().  pretend=(rank, world): measurement aid (tools/slice_probe.py) -- behave as that rank of
-    a world with the exchanges stubbed out."""
+    a world with the exchanges stubbed out.  slot_history: Path C keeps its layer-1 history in a budget-bounded slot
+    cache (budget + one batch of rows and an id -> slot index) instead of the dense [n_nodes, 100] table of
+    modules/history.py:11 -- None = wherever the native Path C step runs (budget > 0, two layers, one rank); it needs
+    cache plans of the planner (include/orca_hip.h, orca_slot_cache) and falls back to the dense table, materialised from
+    the slots, the moment a step without a plan (evaluation: flags accumulate) or a Python-dispatched step comes."""
     self.device = torch.device(device)
     if self.device.type != "cuda":
       raise OrcaError("OrcaEngine needs a HIP device (there is no CPU fallback)")
@@ -100,7 +104,12 @@ class OrcaEngine:
     self.overlay = torch.zeros(self.N, D, **f32)
     # modules/history.py:11-20
     nh = self.L - 1 if self.reuse else 0
-    self.hist = [torch.zeros(self.N, D, **f32) for _ in range(nh)]
+    self._slot_eligible = bool(self.reuse and self.budget > 0 and self.L == 2 and self.world == 1 and
+                               (slot_history is None or slot_history))
+    if slot_history and not self._slot_eligible:
+      raise OrcaError("OrcaEngine: slot_history needs the native Path C step (reuse, budget > 0, two layers, one rank)")
+    self._sc = None                  # slot-cache arrays while the history lives in slots (then self._hist_dense is None)
+    self._hist_dense = None if self._slot_eligible else [torch.zeros(self.N, D, **f32) for _ in range(nh)]
     self.cache_flag = [torch.zeros(self.N, dtype=torch.uint8, device=dev) for _ in range(nh)]
     # scratch
     self.slot = torch.zeros(self.N, dtype=torch.int64, device=dev)
@@ -195,6 +204,87 @@ class OrcaEngine:
       torch.cuda.current_stream().wait_event(ev)
       self._packed_ready = None
 
+  # ---- history tables: dense (modules/history.py:11) or, for the native Path C step, a budget-bounded slot cache --------
+  @property
+  def hist(self):
+    """the dense [n_nodes, 100] history tables of the reference (History.emb).  While the history lives in the slot cache
+    this is a MATERIALISED VIEW built on every access (rows of the ids that hold a slot, zeros elsewhere): for tests and
+    for the drop-in mirror, not for the hot path."""
+    if self._hist_dense is not None:
+      return self._hist_dense
+    dense = torch.zeros(self.N, D, dtype=torch.float32, device=self.device)
+    if self._sc is not None:
+      check(_lib.load().orca_slot_cache_materialize(ctypes.byref(self._sc["desc"]), self.N, ptr(dense), stream()),
+            "orca_slot_cache_materialize")
+    return [dense]
+
+  def history_footprint_bytes(self):
+    """device bytes that hold layer-1 history rows and their index right now"""
+    if self._hist_dense is not None:
+      return sum(t.numel() * 4 for t in self._hist_dense)
+    if self._sc is None:
+      return 0
+    return sum(self._sc[k].numel() * self._sc[k].element_size() for k in ("rows", "slot_of", "slot_id", "free_list", "prev_plan"))
+
+  def _slots_for(self, need_rows, plan_n, n_pull):
+    """the slot cache, (re)allocated for `need_rows` evaluated nodes per batch and plans of plan_n ids"""
+    dev = self.device
+    sc = self._sc
+    n_slots = int(self.budget) + int(need_rows) + 2
+    n_slots = max(n_slots, int(plan_n) + int(need_rows) + 2)
+    if n_slots > 65536:
+      raise OrcaError(f"OrcaEngine: a slot cache of {n_slots} rows exceeds 65536 (budget {self.budget} + {need_rows} evaluated "
+                      "nodes per batch): construct the engine with slot_history=False, or lower budget_cap")
+    prev_cap = max(int(self.budget), int(plan_n), 1)
+    if sc is not None and sc["n_slots"] >= n_slots and sc["prev_cap"] >= prev_cap and sc["pull"].numel() >= n_pull:
+      return sc
+    new = dict(n_slots=n_slots, prev_cap=prev_cap,
+               rows=torch.zeros(n_slots, D, dtype=torch.float32, device=dev),
+               slot_of=torch.full((self.N,), -1, dtype=torch.int32, device=dev) if sc is None else sc["slot_of"],
+               slot_id=torch.full((n_slots,), -1, dtype=torch.int32, device=dev),
+               free_list=torch.zeros(n_slots, dtype=torch.int32, device=dev),
+               state=torch.zeros(8, dtype=torch.int32, device=dev),
+               pull=torch.zeros(max(n_pull, 1), dtype=torch.int32, device=dev),
+               prev_plan=torch.zeros(prev_cap, dtype=torch.int64, device=dev))
+    if sc is None:
+      new["state"][4] = 1               # high-water mark: slot 0 is the zero row, everything above is free
+    else:       # grow: the slots in use keep their numbers; the new ones lie above the high-water mark, i.e. are free
+      old = sc["n_slots"]
+      new["rows"][:old] = sc["rows"]
+      new["slot_id"][:old] = sc["slot_id"]
+      new["free_list"][:old] = sc["free_list"]
+      new["state"].copy_(sc["state"])
+      new["prev_plan"][:sc["prev_cap"]] = sc["prev_plan"]
+    d = _lib.SlotCache()
+    d.rows, d.slot_of, d.slot_id, d.free_list = ptr(new["rows"]), ptr(new["slot_of"]), ptr(new["slot_id"]), ptr(new["free_list"])
+    d.state, d.pull_idx, d.prev_plan = ptr(new["state"]), ptr(new["pull"]), ptr(new["prev_plan"])
+    d.n_slots, d.prev_cap = n_slots, prev_cap
+    new["desc"] = d
+    self._sc = new
+    return new
+
+  def _leave_slot_mode(self):
+    """the history moves from the slot cache into the dense table (a step without a cache plan, a Python-dispatched
+    step): from here on the engine behaves as the reference's dense History does, until reset_state() or a restore()
+    of a backup taken in slot mode"""
+    if self._hist_dense is not None:
+      return
+    self._hist_dense = self.hist            # the materialised view becomes the table
+    self._sc = None
+    if self._native is not None:
+      check(_lib.load().orca_engine_set_slot_cache(self._native, None), "orca_engine_set_slot_cache")
+      self._rebind_native()
+
+  def _rebind_native(self):
+    """the native handle caches table pointers: drop it so that the next step rebuilds it with the current tables"""
+    L = _lib.load()
+    self.slot_epoch = int(L.orca_engine_take_epochs(self._native, 0))
+    check(L.orca_engine_drain(self._native, stream()), "orca_engine_drain")
+    self._overlay_complete = bool(L.orca_engine_get_overlay_complete(self._native))
+    L.orca_engine_destroy(self._native)
+    self._native = None
+    self._q_max = 0
+
   def set_neighbor_finder(self, csr):
     """tgn_model.py:193-195; csr is an ops.CSR (or a shim NeighborFinder carrying .csr)."""
     self.csr = getattr(csr, "csr", csr)
@@ -205,7 +295,14 @@ class OrcaEngine:
   def reset_state(self):
     for t in (self.memory, self.last_update, self.messages, self.msg_ts, self.pending, self.overlay):
       t.zero_()
-    for t in self.hist + self.cache_flag:
+    if self._slot_eligible and self._hist_dense is not None:     # back to the slot cache (empty)
+      self._hist_dense = None
+      if self._native is not None:
+        self._rebind_native()
+    self._sc = None
+    if self._native is not None and self._slot_eligible:
+      check(_lib.load().orca_engine_set_slot_cache(self._native, None), "orca_engine_set_slot_cache")
+    for t in (self._hist_dense or []) + self.cache_flag:
       t.zero_()
     self.test_mode = False
     self._sharded = False
@@ -224,14 +321,35 @@ class OrcaEngine:
   # modules/memory.py:39-43, embedding_module.py:83-91
   def backup(self):
     self.sync_replicas()
+    if self._hist_dense is None:        # the history lives in the slot cache: its arrays are the backup
+      sc = self._sc
+      hist = ("slots", None if sc is None else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sc.items() if k != "desc"})
+    else:
+      hist = [h.clone() for h in self._hist_dense]
     return ([t.clone() for t in (self.memory, self.last_update, self.messages, self.msg_ts, self.pending)],
-            [h.clone() for h in self.hist], [c.clone() for c in self.cache_flag])
+            hist, [c.clone() for c in self.cache_flag])
 
   def restore(self, b):
     for t, s in zip((self.memory, self.last_update, self.messages, self.msg_ts, self.pending), b[0]):
       t.copy_(s)
-    for t, s in zip(self.hist, b[1]):
-      t.copy_(s)
+    if isinstance(b[1], tuple) and b[1][0] == "slots":      # taken in slot mode: back into slot mode
+      if self._hist_dense is not None:
+        self._hist_dense = None
+        if self._native is not None:
+          self._rebind_native()
+      self._sc = None
+      if b[1][1] is not None:
+        new = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b[1][1].items()}
+        d = _lib.SlotCache()
+        d.rows, d.slot_of, d.slot_id, d.free_list = ptr(new["rows"]), ptr(new["slot_of"]), ptr(new["slot_id"]), ptr(new["free_list"])
+        d.state, d.pull_idx, d.prev_plan = ptr(new["state"]), ptr(new["pull"]), ptr(new["prev_plan"])
+        d.n_slots, d.prev_cap = new["n_slots"], new["prev_cap"]
+        new["desc"] = d
+        self._sc = new
+    else:
+      self._leave_slot_mode()
+      for t, s in zip(self._hist_dense, b[1]):
+        t.copy_(s)
     for t, s in zip(self.cache_flag, b[2]):
       t.copy_(s)
     self._sharded = False                  # a backup is taken from coherent replicas
@@ -295,7 +413,7 @@ class OrcaEngine:
     d.gru_blob = ptr(self.gru_blob)
     d.memory, d.last_update, d.messages = ptr(self.memory), ptr(self.last_update), ptr(self.messages)
     d.msg_ts, d.pending, d.overlay = ptr(self.msg_ts), ptr(self.pending), ptr(self.overlay)
-    for i, h in enumerate(self.hist):
+    for i, h in enumerate(self._hist_dense or []):
       d.hist[i] = ptr(h)
     d.slot, d.worklist, d.count = ptr(self.slot), ptr(self.worklist), ptr(self.count)
     d.q_max = q_max
@@ -386,11 +504,18 @@ class OrcaEngine:
     Q, K, dev = 3 * bs, self.K, self.device
     self._raise_budget_overflow(wait=False)        # the previous step's flag, copied out while it ran
     cap = int(self.budget_cap) if self.budget_cap else max(1, min(Q * K, self.N))
+    use_slots = self._hist_dense is None
+    if use_slots and plan is None:          # flags accumulate (history.py:25-30 with cache_plan None): the dense table's job
+      self._leave_slot_mode()
+      use_slots = False
     self._ensure_native(Q + cap)
+    if use_slots:
+      sc = self._slots_for(Q + cap, plan.numel(), Q * K)
+      check(L.orca_engine_set_slot_cache(self._native, ctypes.byref(sc["desc"])), "orca_engine_set_slot_cache")
     b = getattr(self, "_bw", None)
     if b is None or b["cap"] != cap or b["Q"] < Q:
       b = self._bw = dict(cap=cap, Q=Q, unc=torch.zeros(cap, dtype=torch.int64, device=dev),
-                          cnt=torch.zeros(1, dtype=torch.int32, device=dev), tmax=torch.zeros(1, dtype=torch.float64, device=dev),
+                          cnt=torch.zeros(2, dtype=torch.int32, device=dev), tmax=torch.zeros(1, dtype=torch.float64, device=dev),
                           nbr=torch.zeros(Q * K, dtype=torch.int32, device=dev), eid=torch.zeros(Q * K, dtype=torch.int32, device=dev),
                           et=torch.zeros(Q * K, dtype=torch.float32, device=dev), dt=torch.zeros(Q * K, dtype=torch.float32, device=dev),
                           err=torch.zeros(1, dtype=torch.int32, device=dev))
@@ -733,6 +858,7 @@ class OrcaEngine:
       plan = self._dev(cache_plan, torch.int64) if cache_plan is not None else None
       return self._step_budget_native(src, dst, neg, ts, eidx, train, plan)
     self.sync_replicas()
+    self._leave_slot_mode()                # (they work on the dense history tables)
     self._set_overlay_complete(False)      # the Python-dispatched paths store messages without overlay rows
     nodes = torch.cat([src, dst, neg])
     t3 = torch.cat([ts, ts, ts])
@@ -790,6 +916,7 @@ class OrcaEngine:
     self.batch_counter += 1
     self.test_mode = False
     self.sync_replicas()
+    self._leave_slot_mode()                # (train_step's forward reads the dense history tables)
     self._set_overlay_complete(False)
     bs = src.numel()
     src, dst, neg, ts, eidx = src.contiguous(), dst.contiguous(), neg.contiguous(), ts.contiguous(), eidx.contiguous()

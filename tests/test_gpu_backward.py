@@ -233,7 +233,9 @@ def test_engine_train_step_vs_autograd(ops, reuse, L, bs, drop, hgrad, budget):
   csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
   engs = []
   for _ in range(2):
-    e = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=budget, device="cuda:0", dropout=drop, seed=11, gradient=hgrad)
+    # (random cache plans below: the dense history table -- the slot cache follows plans of the planner, tests/test_gpu_engine.py)
+    e = OrcaEngine(sd, ef, N + 1, L, K, reuse=reuse, budget=budget, device="cuda:0", dropout=drop, seed=11, gradient=hgrad,
+                   slot_history=False if budget else None)
     e.set_neighbor_finder(csr)
     e.train_time_encoder = True     # the kernels' time-encoder gradient is checked too (frozen upstream: off by default)
     engs.append(e)

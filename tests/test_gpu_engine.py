@@ -15,25 +15,30 @@ torch.set_num_threads(1)
 DEV = "cuda:0"
 
 
-def _engine_and_graph(g, tag, graph):
+def _engine_and_graph(g, tag, graph, slot_history=None):
   from orca_amd import ops
   from orca_amd.engine import OrcaEngine
   meta = g[f"{tag}_meta"]
   L, reuse, budget, bs, K, n_train, n_eval, n_nodes, n_edges = [int(x) for x in meta]
   src, dst, ts, eidx = (g[f"{graph}_{k}"] for k in ("src", "dst", "ts", "eidx"))
   sd = {k[len(graph + "_sd."):]: g[k] for k in g.files if k.startswith(graph + "_sd.")}
-  eng = OrcaEngine(sd, g[f"{graph}_edge_feats"], n_nodes + 1, L, K, bool(reuse), budget, device=DEV)
+  eng = OrcaEngine(sd, g[f"{graph}_edge_feats"], n_nodes + 1, L, K, bool(reuse), budget, device=DEV, slot_history=slot_history)
   n_tr = n_train * bs
   train_csr = ops.CSR.from_edges_host(src[:n_tr], dst[:n_tr], eidx[:n_tr], ts[:n_tr], n_nodes + 1, DEV)
   full_csr = ops.CSR.from_edges_host(src, dst, eidx, ts, n_nodes + 1, DEV)
   return eng, train_csr, full_csr, (L, reuse, budget, bs, K, n_train, n_eval, n_nodes, n_edges), (src, dst, ts, eidx)
 
 
-@pytest.mark.parametrize("tag,graph", [("A1", "g172"), ("A2", "g172"), ("B2", "g172"), ("C2", "g172"),
-                                       ("B2z", "g1"), ("A1z", "g1"), ("C2z", "g1")])
-def test_tgn_paths_vs_reference_golden(golden, tag, graph):
+@pytest.mark.parametrize("tag,graph,slots", [("A1", "g172", None), ("A2", "g172", None), ("B2", "g172", None),
+                                             ("C2", "g172", False), ("C2", "g172", True), ("B2z", "g1", None),
+                                             ("A1z", "g1", None), ("C2z", "g1", False), ("C2z", "g1", True)])
+def test_tgn_paths_vs_reference_golden(golden, tag, graph, slots):
+  """slots (Path C only): the layer-1 history in the budget-bounded slot cache instead of the reference's dense table.  The
+  reference's own plans (its MRD planner) drive it; everything the reference computes must come out the same -- embeddings,
+  probabilities, memory, flags -- and the history rows of every CACHED id (the dense table also keeps the rows of ids the
+  plan dropped, which nothing reads again: those are what the slot cache does not store)."""
   g = golden("tgn.npz")
-  eng, train_csr, full_csr, meta, edges = _engine_and_graph(g, tag, graph)
+  eng, train_csr, full_csr, meta, edges = _engine_and_graph(g, tag, graph, slots)
   L, reuse, budget, bs, K, n_train, n_eval, n_nodes, n_edges = meta
   src, dst, ts, eidx = edges
   negs = g[f"{tag}_negs"]
@@ -54,7 +59,12 @@ def test_tgn_paths_vs_reference_golden(golden, tag, graph):
       assert np.array_equal(eng.pending.cpu().numpy().astype(bool), g[f"{tag}_b{b}_pending"])
       if reuse:
         hist = np.stack([h.cpu().numpy() for h in eng.hist])
-        assert_close_fp32(hist, g[f"{tag}_b{b}_hist"], 1e-5, what + " hist")
+        exp_hist = g[f"{tag}_b{b}_hist"]
+        if slots:
+          cached = g[f"{tag}_b{b}_cache_flag"].astype(bool)        # [layers - 1, n_nodes]
+          hist, exp_hist = hist[cached], exp_hist[cached]
+          assert (eng._hist_dense is None) == (phase == "train"), "slot mode while a plan drives the cache, the table afterwards"
+        assert_close_fp32(hist, exp_hist, 1e-5, what + " hist")
         if budget:
           flags = np.stack([c.cpu().numpy() for c in eng.cache_flag])
           assert np.array_equal(flags, g[f"{tag}_b{b}_cache_flag"])
@@ -385,7 +395,8 @@ def test_budget_step_native_equals_dispatched():
   csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
   engs = []
   for native in (True, False):
-    e = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=300, device=DEV)
+    # (random plans: the slot cache needs plans of the planner, see test_slot_history_equals_dense_table)
+    e = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=300, device=DEV, slot_history=False)
     e.native_budget = native
     e.set_neighbor_finder(csr)
     engs.append(e)
@@ -419,3 +430,65 @@ def test_budget_step_native_equals_dispatched():
                                 True, None)
   A.check_errors()
   assert not A.budget_overflow()
+
+
+def test_slot_history_equals_dense_table():
+  """The budget-bounded slot cache of the native Path C step (include/orca_hip.h: orca_slot_cache) against the dense
+  history table on the same batches with the MRD plans of the device planner: embeddings, memory, messages and cache
+  flags bit for bit, the history rows of every cached id bit for bit, across train batches, a backup, evaluation batches
+  without a plan (the engine moves the slots into the dense table) and the restore back into slot mode."""
+  import argparse
+  from orca_amd import api, ops, synth
+  from orca_amd.engine import OrcaEngine
+  N, E, K, d_e, bs, budget = 6000, 120000, 10, 172, 200, 150
+  src, dst, eidx, ts = synth.powerlaw_graph(N, E, DEV, seed=6)
+  ef = synth.edge_features(E, d_e, DEV)
+  sd = synth.tgn_state_dict(d_e, 2, seed=8)
+  csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
+  n_b, start = 24, 60000
+  n = n_b * bs
+  h = lambda x: x[start:start + n].cpu().numpy()
+  data = api.Data(h(src), h(dst), h(ts), h(eidx), np.zeros(n))
+  nf = api.NeighborFinder(None, None, None, device=DEV, _csr=csr)
+  pa = argparse.Namespace(bs=bs, n_degree=K, budget=budget, planner="device")
+  plans = [torch.from_numpy(p).to(DEV) for p in api.get_cache_plan(pa, data, nf, N + 1, "MRD")]
+  A = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=budget, device=DEV)                        # slot cache (default)
+  B = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=budget, device=DEV, slot_history=False)    # dense table
+  for e in (A, B):
+    e.set_neighbor_finder(csr)
+    e.budget_cap = 800          # launches (and slots) for at most 800 uncached neighbours per batch; more would raise
+  rs = np.random.RandomState(2)
+
+  def step(b, train, plan):
+    s = start + b * bs
+    neg = torch.from_numpy(rs.randint(1, N + 1, bs).astype(np.int64)).to(DEV)
+    args = (src[s:s + bs], dst[s:s + bs], neg, ts[s:s + bs], eidx[s:s + bs], train, plan)
+    ea, eb = A.compute_temporal_embeddings(*args), B.compute_temporal_embeddings(*args)
+    assert torch.equal(ea, eb), f"batch {b}: embeddings"
+    for name in ("memory", "last_update", "messages", "msg_ts", "pending"):
+      assert torch.equal(getattr(A, name), getattr(B, name)), f"batch {b}: {name}"
+    assert torch.equal(A.cache_flag[0], B.cache_flag[0]), f"batch {b}: cache flags"
+    cached = B.cache_flag[0].bool()
+    assert torch.equal(A.hist[0][cached], B.hist[0][cached]), f"batch {b}: history rows of the cached ids"
+
+  for b in range(12):
+    step(b, True, plans[b])
+  assert A._hist_dense is None and A._sc is not None, "the engine left slot mode during plan-driven training"
+  assert int(A.cache_flag[0].sum()) > 0
+  dense_bytes = (N + 1) * 100 * 4
+  assert A.history_footprint_bytes() < dense_bytes // 3 and A._sc["n_slots"] == budget + 3 * bs + 800 + 2
+  A.check_errors()
+  assert int(A._sc["state"][2].item()) == 0, "a push found no free slot"
+  ba, bb = A.backup(), B.backup()
+  for b in range(12, 15):                   # evaluation: no plan, flags accumulate -> the dense table takes over
+    step(b, False, None)
+  assert A._hist_dense is not None
+  A.restore(ba)
+  B.restore(bb)
+  assert A._hist_dense is None, "a backup taken in slot mode restores into slot mode"
+  for b in range(12, 24):
+    step(b, True, plans[b])
+  A.reset_state()
+  B.reset_state()
+  for b in range(0, 4):
+    step(b, True, plans[b])

@@ -112,7 +112,7 @@ def _worker(rank, world, port, q, full):
     if full:
       # Path C (budgeted reuse with a cache plan per batch): global set algebra on every rank, attention partitioned
       multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=dist.group.WORLD)
-      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None)
+      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None, slot_history=False)   # (random plans)
       multi.set_neighbor_finder(csr)
       single.set_neighbor_finder(csr)
       for b in range(3):
@@ -148,7 +148,7 @@ def _worker(rank, world, port, q, full):
         ok = ok and torch.equal(multi.hist[0], single.hist[0])
       # the same for the budgeted reuse path (Path C): every rank back-propagates its slice of the roots
       multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=dist.group.WORLD)
-      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None)
+      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None, slot_history=False)   # (random plans)
       multi.set_neighbor_finder(csr)
       single.set_neighbor_finder(csr)
       for b in range(3):
