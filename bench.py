@@ -409,7 +409,7 @@ def main():
       ach = flops / (ms * 1e-3) / 1e12
       out["roofline"] = {"kernel": "k_tgat_forward", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(args),
-                         "traffic_unit": "HBM bytes per launch (profiles/r02_pmc_hbm_traffic.md)",
+                         "traffic_unit": "HBM bytes per launch (profiles/r03_pmc_hbm_traffic.md)",
                          "launches": n, "avg_launch_ms": ms, "queries_per_launch": q_mean,
                          "flops_per_query": synth.tgat_flops_per_query(args.d_e, args.k),
                          "flops_executed_per_query": synth.tgat_flops_executed_per_query(args.d_e, args.k),
