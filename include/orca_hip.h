@@ -532,36 +532,39 @@ int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst,
 int orca_engine_apply(orca_engine_t* e, void* stream);
 
 /* Budget-bounded history for orca_engine_step_budget (north_star: "a GPU-resident index-and-gather with budget-bounded
- * eviction"; replaces the dense [n_nodes, ORCA_D] table of modules/history.py:11 under --budget B).  All device memory,
+ * eviction"; replaces the dense [n_nodes, ORCA_D] table of modules/history.py:11 under --budget B).  Device memory,
  * caller-owned:
- *   rows      [n_slots, ORCA_D]  slot 0 is a zero row (an id that was never pushed, the padding id 0) and is never handed out
- *   slot_of   int32 [n_nodes]    id -> slot, <= 0: none            (initialise to -1)
- *   slot_id   int32 [n_slots]    slot -> id, < 0: free             (initialise to -1)
- *   free_list int32 [n_slots]    free slots BELOW the high-water mark, ascending, handed out from state[0] on
- *   state     int32 [8]          [0] slots handed out since the last eviction, [1] entries of free_list, [2] error bits,
- *                                [3] ids in prev_plan, [4] high-water mark: every slot from it up is free
- *                                (initialise to 0, 0, 0, 0, 1)
- *   pull_idx  int32 [3*bs*K]     work buffer: the slot of every sampled neighbour of the batch
- *   prev_plan int64 [prev_cap]   the plan of the last step (whose flags the next one clears)
- * n_slots must exceed budget + 3*bs + cap (every node evaluated in a batch gets a slot until the plan decides) and is at
- * most 65536.  With a cache set, a step pushes the evaluated rows into slots, pulls through slot_of, makes cache_flag
- * exactly the plan (history.py:25-30) and frees every slot whose id the plan does not keep.  It needs a plan (plan_n >= 0):
- * a plan of the reference's planner only keeps ids that were kept before or evaluated in this batch, so every kept id has a
- * row.  Differences from the dense table, both outside what the planner produces: a flagged id WITHOUT a row reads zeros
- * (dense: whatever was pushed last, however long ago), and so does the one uncached id that embedding_module.py:212's
- * `[1:]` drops when it is not the padding id.  orca_slot_cache_materialize writes the dense view (rows of the ids that
- * hold a slot; the caller zeroes `dense` first). */
+ *   rows      [1 + 2*plan_cap + q_bound, ORCA_D]  row 0: zeros (an id that was never pushed, the padding id 0); then two
+ *                                plan regions of plan_cap rows -- region `cur` holds row i = the cached embedding of
+ *                                prev_plan[i], the other one is written by the running step's plan --; then the batch
+ *                                region, which the layer-1 attention launch writes directly (the push moves no row)
+ *   stamp     int64 [n_nodes]    id -> generation << 21 | kind << 20 | index; kind 0: evaluated in step `generation` at
+ *                                position `index` (the last position wins, SURVEY H7: an atomicMax); kind 1: kept by the plan
+ *                                of step `generation` as row `index` of the region that step wrote.  Valid for the pulls of
+ *                                step g iff generation == g (kind 0) or g - 1 (kind 1); everything else is stale -- nothing
+ *                                is ever freed or reset.  Initialise to 0.
+ *   prev_plan int64 [plan_cap]   the plan the cached rows follow (whose flags the next step clears)
+ *   pull_idx  int32 [3*bs*K]     work buffer: the row of every sampled neighbour of the batch
+ * and three host-side words the steps advance (read them back with orca_engine_get_slot_cache): gen (the generation of the
+ * next step; start at 2), cur (0 / 1), prev_n (ids in prev_plan).  plan_cap >= every plan_n, q_bound >= 3*bs + cap (< 2^20).
+ * With a cache set, a step evaluates into the batch region, pulls through the stamps, makes cache_flag exactly the plan
+ * (history.py:25-30) and copies the rows the plan keeps into the other plan region.  It needs a plan (plan_n >= 0): a plan
+ * of the reference's planner only keeps ids that were kept before or evaluated in this batch, so every kept id has a row.
+ * Differences from the dense table, both outside what the planner produces: a flagged id WITHOUT a row reads zeros (dense:
+ * whatever was pushed last, however long ago), and so does the one uncached id that embedding_module.py:212's `[1:]` drops
+ * when it is not the padding id.  orca_slot_cache_materialize writes the dense view (rows of the ids the plan keeps; the
+ * caller zeroes `dense` first). */
 typedef struct {
   float* rows;
-  int32_t* slot_of;
-  int32_t* slot_id;
-  int32_t* free_list;
-  int32_t* state;
-  int32_t* pull_idx;
+  int64_t* stamp;
   int64_t* prev_plan;
-  int64_t n_slots, prev_cap;
+  int32_t* pull_idx;
+  int64_t plan_cap, q_bound;
+  int64_t gen, prev_n;
+  int32_t cur;
 } orca_slot_cache;
 int orca_engine_set_slot_cache(orca_engine_t* e, const orca_slot_cache* cache);    /* NULL or rows == NULL: back to hist[0] */
+int orca_engine_get_slot_cache(orca_engine_t* e, orca_slot_cache* cache);          /* as the last step left it */
 int orca_slot_cache_materialize(const orca_slot_cache* cache, int64_t n_nodes, float* dense, void* stream);
 
 /* The root queries of a batch (model/tgn_model.py:99-102: nodes = [src; dst; neg], timestamps = [t; t; t]) in one launch:

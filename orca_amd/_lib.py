@@ -38,8 +38,8 @@ ORCA_ENGINE_MAX_LAYERS = 4
 
 class SlotCache(ctypes.Structure):
   """orca_slot_cache (include/orca_hip.h): the budget-bounded history of the native Path C step."""
-  _fields_ = [(n, vp) for n in ("rows", "slot_of", "slot_id", "free_list", "state", "pull_idx", "prev_plan")] + \
-             [("n_slots", i64), ("prev_cap", i64)]
+  _fields_ = [(n, vp) for n in ("rows", "stamp", "prev_plan", "pull_idx")] + \
+             [("plan_cap", i64), ("q_bound", i64), ("gen", i64), ("prev_n", i64), ("cur", ctypes.c_int32)]
 
 
 class EngineDesc(ctypes.Structure):
@@ -132,6 +132,7 @@ SIGNATURES = {
     "orca_engine_get_overlay_complete": (i32, [vp]),
     "orca_build_roots": (i32, [vp] * 4 + [i64] + [vp] * 5),
     "orca_engine_set_slot_cache": (i32, [vp, vp]),
+    "orca_engine_get_slot_cache": (i32, [vp, vp]),
     "orca_slot_cache_materialize": (i32, [vp, i64, vp, vp]),
     "orca_engine_step_budget": (i32, [vp] * 6 + [i64, i32, vp, i64, vp, vp, vp, i64] + [vp] * 9),
     "orca_engine_drain": (i32, [vp, vp]),

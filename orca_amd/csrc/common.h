@@ -67,6 +67,13 @@ int orca_message_store_winners(const int64_t* src, const int64_t* dst, const int
 int orca_find_uncached_unordered(const int32_t* nbr, int64_t n_nbr, const int64_t* batch_nodes, int64_t n_batch,
                                  const uint8_t* cache_flag, int64_t* slot, int64_t epoch, int64_t n_nodes, uint32_t* bitmap,
                                  int64_t* out, int64_t cap, int32_t* count, void* stream);
+// its two halves for a caller whose own kernel stamped the batch ids (slot[id] = epoch) and zeroed count[0..1]: the
+// marking pass, and the one-workgroup finish (drop the minimum, clear the bitmap) that also lays the evaluated set behind
+// the Q roots of nodes / nodes32 / qts: the listed ids, then id -1 / node 0 padding up to cap, at time *tmax
+int orca_uncached_mark(const int32_t* nbr, int64_t n_nbr, const uint8_t* cache_flag, const int64_t* slot, int64_t epoch,
+                       int64_t n_nodes, uint32_t* bitmap, int64_t* out, int64_t cap, int32_t* count, void* stream);
+int orca_uncached_finish_nodes(int64_t* out, int64_t cap, int32_t* count, uint32_t* bitmap, int64_t n_nodes, int64_t Q,
+                               const double* tmax, int64_t* nodes, int32_t* nodes32, double* qts, int32_t* err, void* stream);
 
 // orca_tgat_forward with the step driver's extra row writes fused in (either half may be left null):
 //  persist: a query q < persist_n whose source row was read from the overlay (src_flags[row] set) also commits it:

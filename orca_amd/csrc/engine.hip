@@ -17,6 +17,7 @@
 #include "common.h"
 #include "sampler.h"
 #include "gru_split.h"
+#include "worklist.h"
 
 struct orca_engine {
   orca_engine_desc d;
@@ -877,208 +878,251 @@ __global__ __launch_bounds__(1024) void k_budget_roots(const int64_t* __restrict
     if (tmax) *tmax = m;
   }
 }
-// the evaluated set behind the roots: entries Q .. Q+cap-1 = the uncached ids (device count), then padding -- id -1 for
-// the lists that write state (every id-indexed kernel skips it), id 0 (the padding node) where a row is gathered
-__global__ void k_budget_cnodes(const int64_t* __restrict__ unc, const int32_t* __restrict__ count, int64_t cap, int64_t Q,
-                                const double* __restrict__ tmax, int64_t* __restrict__ nodes, int32_t* __restrict__ nodes32,
-                                double* __restrict__ qts, int32_t* __restrict__ err) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && *count > cap && err) atomicOr(err, 2);        // more uncached neighbours than the launch bound
-  if (i >= cap) return;
-  const bool ok = i < *count;
-  const int64_t id = ok ? unc[i] : -1;
-  nodes[Q + i] = id;
-  nodes32[Q + i] = ok ? (int32_t)id : 0;
-  qts[Q + i] = *tmax;
+
+// The CSR as the kernels below take it
+struct budget_csr {
+  const int64_t* indptr;
+  const int32_t *nbr, *eid;
+  const double* ts;
+  int64_t n_rows;
+  orca_fences fences;
+};
+
+// First kernel of the native Path C step, two block roles:
+//  blocks 0 .. ne_m-1 : last-occurrence election of the raw-message list [src;dst] in LDS (tgn_model.py:174-176) -> a winner
+//                       byte per position; block 0 first reduces *tmax = max t and zeroes the two words of the uncached count
+//  the others         : 16 waves = 16 root queries: root i of [src;dst;neg] x [t;t;t] (tgn_model.py:99-102) is written to
+//                       nodes / qts / nodes32, stamped into `slot` (the batch-membership test of find_uncached,
+//                       embedding_module.py:200-212) and its K neighbours are sampled -- into row i of the step's sampler
+//                       buffers (the first 3*bs rows of the layer-1 launch) and of the caller's top-level copies (the keys
+//                       of layer 2)
+__global__ __launch_bounds__(ELECT_THREADS) void k_budget_begin(
+    const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
+    const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
+    int32_t* __restrict__ nodes32, double* __restrict__ tmax, int32_t* __restrict__ unc_count, uint8_t* __restrict__ win_msg,
+    int ne_m, int64_t n_nodes, budget_csr csr, int K, int64_t* __restrict__ stamp, int64_t stamp_epoch,
+    int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt,
+    int32_t* __restrict__ t_nbr, int32_t* __restrict__ t_eid, float* __restrict__ t_et, float* __restrict__ t_dt) {
+  __shared__ __align__(16) int32_t tab[2 * ELECT_SLOTS];
+  auto root = [&](int64_t i) {
+    const int64_t* a = i < bs ? src : (i < 2 * bs ? dst - bs : neg - 2 * bs);
+    return a[i];
+  };
+  if ((int)blockIdx.x < ne_m) {
+    if (blockIdx.x == 0) {
+      double* red = reinterpret_cast<double*>(tab);
+      double m = -1.0e300;
+      for (int64_t i = threadIdx.x; i < bs; i += ELECT_THREADS) { const double t = ts[i]; m = t > m ? t : m; }
+      for (int o = 32; o > 0; o >>= 1) { const double v = __shfl_xor(m, o, 64); m = v > m ? v : m; }
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int w = 1; w < ELECT_THREADS / 64; ++w) m = red[w] > m ? red[w] : m;
+        *tmax = m;
+        unc_count[0] = 0; unc_count[1] = 0;
+      }
+      __syncthreads();
+    }
+    elect_in_lds(tab, tab + ELECT_SLOTS, 2 * bs, n_nodes, root, win_msg, (int)blockIdx.x, ne_m, nullptr, nullptr);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)((int)blockIdx.x - ne_m) * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
+  if (i >= 3 * bs) return;
+  const int64_t e = i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs);
+  const int64_t v = root(i);
+  const double t = ts[e];
+  if (lane == 0) {
+    nodes[i] = v;
+    nodes32[i] = (int32_t)v;
+    qts[i] = t;
+    if (v >= 0 && v < n_nodes) stamp[v] = stamp_epoch;
+  }
+  sample_recent_wave(csr.indptr, csr.nbr, csr.eid, csr.ts, csr.fences, csr.n_rows, v, t, i, 3 * bs, K, o_nbr, o_eid, o_et, o_dt,
+                     nullptr, orca_claim{}, lane);
+  if (lane < K) {    // (a lane reads back what it wrote itself)
+    const int64_t o = i * K + lane;
+    t_nbr[o] = o_nbr[o]; t_eid[o] = o_eid[o]; t_et[o] = o_et[o]; t_dt[o] = o_dt[o];
+  }
 }
 
 // ---- budget-bounded history (slot cache) of the native Path C step ---------------------------------------------------
 // The reference keeps layer-1 embeddings in a dense [n_nodes, 100] table (modules/history.py:11) of which, under
 // --budget B, only the B rows of the current cache plan plus the rows pushed in the running batch are ever pulled
-// (embedding_module.py:186-212).  Here those rows live in `rows` [n_slots, 100] (slot 0 = a zero row: what the dense
-// table holds for an id that was never pushed, and for the padding id 0), found through slot_of [n_nodes] (id -> slot,
-// <= 0: none); slot_id [n_slots] is the inverse.  Free slots: every slot from state[4] (the high-water mark) up, plus the
-// state[1] entries of free_list below it, handed out in that order from state[0] on -- the used slots therefore stay
-// packed at the bottom of `rows`, and the eviction sweep only walks up to the mark.  BASELINE config 3
-// (1.14 M nodes, budget 1000): 3 MB of rows + 4.6 MB of index instead of 456 MB, and the pulls of layer 2 stay in L2.
-__global__ void k_slot_elect(const int64_t* __restrict__ ids, int64_t n, int64_t* slot, int64_t epoch, int64_t n_nodes) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int64_t id = ids[p];
-  if (id < 0 || id >= n_nodes) return;
-  atomicMax(reinterpret_cast<unsigned long long*>(&slot[id]), (unsigned long long)(epoch + p));
+// (embedding_module.py:186-212).  Here they live in `rows`:
+//   row 0                         zeros: what the dense table holds for an id that was never pushed, and for the padding id 0
+//   rows 1 .. 2*plan_cap          two plan regions; region `cur` holds row i = the embedding of prev_plan[i], the other one is
+//                                 written by this step's plan (so the copy never overwrites a row it still has to read)
+//   rows 1 + 2*plan_cap ..        the batch region: the layer-1 attention launch writes its output rows straight into it --
+//                                 the history push of the batch (history.py:38-40) moves no row at all
+// and are found through stamp[id] = generation << 21 | kind << 20 | index (int64 per node, zero-initialised):
+//   kind 0, generation g   : id was evaluated in step g at position `index` of the evaluated set; the LAST position wins
+//                             because the election is an atomicMax on this word
+//   kind 1, generation g   : step g's plan keeps id, as row `index` of the plan region that step wrote
+// A stamp is valid for step g's pulls iff its generation is g (kind 0) or g - 1 (kind 1): nothing is ever freed, swept or
+// reset, and what the plan does not keep simply goes stale.  BASELINE config 3 (1.14 M nodes, budget 1000, 600 + cap
+// evaluated nodes): 3.4 MB of rows + 9.1 MB of stamps instead of 456 MB, and the pulls of layer 2 stay in L2.
+constexpr int STAMP_SHIFT = 21;
+constexpr int64_t STAMP_KIND = 1ll << 20, STAMP_INDEX = STAMP_KIND - 1;
+struct slot_view {
+  int64_t* stamp;
+  int64_t gen;
+  int64_t cur_base, batch_base;     // first row of the plan region that holds the cached rows / of the batch region
+};
+__device__ __forceinline__ int64_t slot_row(int64_t val, const slot_view& sv) {
+  const int64_t g = val >> STAMP_SHIFT, idx = val & STAMP_INDEX;
+  if (val & STAMP_KIND) return g == sv.gen - 1 ? sv.cur_base + idx : 0;
+  return g == sv.gen ? sv.batch_base + idx : 0;
 }
-// history push (history.py:38-40; last occurrence wins): the winner position of every id writes its row.  A
-// thread per position finds the winners and whether they need a slot; the block takes its new slots with ONE atomicAdd
-// (a returning atomic per winner on the one counter serialised at L2: 15 us for 1500 winners), then its waves copy the
-// winners' rows.
-constexpr int SLOT_PUSH_THREADS = 256;      // positions per block: enough blocks for the row copies, few enough atomics
-__global__ __launch_bounds__(SLOT_PUSH_THREADS) void k_slot_push(const int64_t* __restrict__ ids, int64_t n,
-                                                                 const int64_t* __restrict__ elect, int64_t epoch, int64_t n_nodes,
-                                                                 const float* __restrict__ x, float* __restrict__ rows,
-                                                                 int32_t* __restrict__ slot_of, int32_t* __restrict__ slot_id,
-                                                                 const int32_t* __restrict__ free_list,
-                                                                 int32_t* __restrict__ state, int n_slots) {
-  constexpr int T = SLOT_PUSH_THREADS, NWV = T / 64;
-  __shared__ int wave_new[NWV], wave_win[NWV];
-  __shared__ int block_first, block_win;
-  __shared__ int32_t s_pos[T], s_slot[T];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t p = (int64_t)blockIdx.x * T + tid;
-  bool win = false, need = false;
-  int64_t id = -1;
-  int sl = 0;
-  if (p < n) {
-    id = ids[p];
-    win = id >= 0 && id < n_nodes && elect[id] == epoch + p;
-    if (win) { sl = slot_of[id]; need = sl <= 0; }
-  }
-  const unsigned long long m_new = __ballot(need), m_win = __ballot(win);
-  if (lane == 0) { wave_new[wave] = __popcll(m_new); wave_win[wave] = __popcll(m_win); }
-  __syncthreads();
-  if (tid == 0) {
-    int tn = 0, tw = 0;
-    for (int w = 0; w < NWV; ++w) { int c = wave_new[w]; wave_new[w] = tn; tn += c; c = wave_win[w]; wave_win[w] = tw; tw += c; }
-    block_win = tw;
-    block_first = tn ? atomicAdd(&state[0], tn) : 0;
-  }
-  __syncthreads();
-  if (need) {
-    const int k = block_first + wave_new[wave] + __popcll(m_new & ((1ull << lane) - 1ull)), n_listed = state[1];
-    sl = k < n_listed ? free_list[k] : state[4] + (k - n_listed);
-    if (sl < n_slots) {
-      slot_of[id] = sl;
-      slot_id[sl] = (int32_t)id;
-    } else {
-      atomicOr(&state[2], 1);          // no free slot: cannot happen while n_slots > budget + evaluated nodes
-      sl = 0;
+
+// Second kernel group of the step, after the evaluated set [roots; uncached; padding] is final.  Block roles, in grid order:
+//  A (slot cache)    the previous plan's cache flags are cleared (history.py:25-30; nobody reads them again in this step)
+//  B                 last-occurrence election of the push list (the evaluated set): slot cache -- atomicMax on the stamps;
+//                    dense table -- elect_in_lds -> a winner byte per position for the attention launch's fused push
+//  C (train order)   work-list claims of the roots and their neighbours (sampled by the first kernel): slot[id] = epoch + p
+//  D                 16 waves = 16 uncached nodes: sample their K neighbours at *tmax into rows 3*bs.. of the sampler
+//                    buffers, with their own work-list claims; waves past the device-side count return
+struct expand_args {
+  int nA, nB, nC;
+  const int64_t* prev_plan; int64_t prev_n; uint8_t* cache_flag;
+  int64_t* stamp; int64_t gen;                 // slot cache (else null)
+  uint8_t* win_push; int parts;                // dense table (else null)
+  orca_claim claim;                            // slot == null: no claims (evaluation order)
+  const int32_t* unc_count; int64_t cap;
+};
+__global__ __launch_bounds__(ELECT_THREADS) void k_budget_expand(
+    expand_args a, const int64_t* __restrict__ nodes, const double* __restrict__ qts, int64_t Q, int64_t n_nodes, budget_csr csr,
+    int K, int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt) {
+  __shared__ __align__(16) int32_t tab[2 * ELECT_SLOTS];
+  const int64_t Qc = Q + a.cap;
+  int blk = (int)blockIdx.x;
+  if (blk < a.nA) {
+    const int64_t j = (int64_t)blk * ELECT_THREADS + threadIdx.x;
+    if (j < a.prev_n) {
+      const int64_t id = a.prev_plan[j];
+      if (id >= 0 && id < n_nodes) a.cache_flag[id] = 0;
     }
+    return;
   }
-  if (win) {
-    const int j = wave_win[wave] + __popcll(m_win & ((1ull << lane) - 1ull));
-    s_pos[j] = tid;
-    s_slot[j] = sl;
-  }
-  __syncthreads();
-  // the winners' rows, 16 lanes a row (25 float4), four rows per wave and trip: every load of a trip is in flight at once
-  const int sub = lane & 15, grp = lane >> 4;
-  for (int j0 = wave * 4; j0 < block_win; j0 += NWV * 4) {
-    const int j = j0 + grp;
-    const bool on = j < block_win && s_slot[j < block_win ? j : 0] > 0;
-    const int jc = j < block_win ? j : 0;
-    const f32x4* src = reinterpret_cast<const f32x4*>(x + ((int64_t)blockIdx.x * T + s_pos[jc]) * ORCA_D);
-    f32x4* dst = reinterpret_cast<f32x4*>(rows + (int64_t)s_slot[jc] * ORCA_D);
-    const f32x4 a = src[sub], b2 = src[sub + 16 < ORCA_D / 4 ? sub + 16 : sub];
-    if (on) {
-      dst[sub] = a;
-      if (sub + 16 < ORCA_D / 4) dst[sub + 16] = b2;
-    }
-  }
-}
-// history pull (history.py:32-36) as an index translation: the attention kernel gathers rows[pull_idx[i]]
-__global__ void k_slot_translate(const int32_t* __restrict__ nbr, int64_t n, int64_t n_nodes, const int32_t* __restrict__ slot_of,
-                                 int32_t* __restrict__ pull_idx) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t v = nbr[i];
-  int sl = 0;
-  if (v >= 0 && v < n_nodes) sl = slot_of[v];
-  pull_idx[i] = sl > 0 ? sl : 0;
-}
-// update_flag (history.py:25-30: the flags become exactly the plan) and the eviction it implies: one workgroup clears the
-// previous plan's flags, marks the slots of the new plan's ids, frees every other used slot and rebuilds the free list
-// in slot order (deterministic), then remembers the plan for the next call.
-__global__ __launch_bounds__(1024) void k_slot_evict(const int64_t* __restrict__ plan, int64_t plan_n, int64_t n_nodes,
-                                                     int32_t* __restrict__ slot_of, int32_t* __restrict__ slot_id,
-                                                     int32_t* __restrict__ free_list, int32_t* __restrict__ state,
-                                                     int64_t n_slots, int64_t* __restrict__ prev_plan,
-                                                     uint8_t* __restrict__ cache_flag) {
-  __shared__ uint32_t keep[2048];                 // one bit per slot (n_slots <= 65536)
-  __shared__ int wave_n[16];
-  __shared__ int base, top;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // every load that depends on nothing is requested up front (one workgroup: the kernel is a chain of round trips)
-  const int s0 = state[0], s1 = state[1], s4 = state[4];
-  const int64_t prev_n = state[3];
-  constexpr int PRE = 4;                           // sweep chunks whose slot ids are fetched ahead
-  int32_t sid[PRE];
-#pragma unroll
-  for (int c = 0; c < PRE; ++c) {
-    const int64_t sl = (int64_t)c * 1024 + tid;
-    sid[c] = slot_id[sl < n_slots ? sl : n_slots - 1];
-  }
-  const int64_t my_plan = tid < plan_n ? plan[tid] : -1;
-  for (int i = tid; i < 2048; i += 1024) keep[i] = 0u;
-  for (int64_t i = tid; i < prev_n; i += 1024) {
-    const int64_t id = prev_plan[i];
-    if (id >= 0 && id < n_nodes) cache_flag[id] = 0;
-  }
-  if (tid == 0) { base = 0; top = 0; }
-  __syncthreads();
-  for (int64_t i = tid; i < plan_n; i += 1024) {
-    const int64_t id = i == tid ? my_plan : plan[i];
-    prev_plan[i] = id;
-    if (id < 0 || id >= n_nodes) continue;
-    cache_flag[id] = 1;
-    const int sl = slot_of[id];
-    if (sl > 0) { atomicOr(&keep[sl >> 5], 1u << (sl & 31)); atomicMax(&top, sl); }
-  }
-  __syncthreads();
-  // slots in use lie below the mark as the pushes of this step left it; after the sweep the mark drops to just above the
-  // highest kept slot, and the free slots below it are listed in ascending order
-  int64_t used_to = (int64_t)s4 + (s0 > s1 ? s0 - s1 : 0);
-  used_to = used_to < n_slots ? used_to : n_slots;
-  const int new_mark = top + 1;
-  for (int64_t c0 = 0; c0 < used_to; c0 += 1024) {
-    const int64_t sl = c0 + tid;
-    bool listed = false;
-    if (sl >= 1 && sl < used_to) {
-      const bool kept = (keep[sl >> 5] >> (sl & 31)) & 1u;
-      if (!kept) {
-        const int c = (int)(c0 >> 10);
-        int32_t id = c < PRE ? 0 : slot_id[sl];
-#pragma unroll
-        for (int k = 0; k < PRE; ++k) id = c == k ? sid[k] : id;
-        if (id >= 0) { slot_of[id] = -1; slot_id[sl] = -1; }
-        listed = sl < new_mark;
+  blk -= a.nA;
+  if (blk < a.nB) {
+    if (a.stamp) {
+      const int64_t p = (int64_t)blk * ELECT_THREADS + threadIdx.x;
+      if (p < Qc) {
+        const int64_t id = nodes[p];
+        if (id >= 0 && id < n_nodes)
+          atomicMax(reinterpret_cast<unsigned long long*>(&a.stamp[id]), (unsigned long long)((a.gen << STAMP_SHIFT) | p));
       }
+    } else {
+      elect_in_lds(tab, tab + ELECT_SLOTS, Qc, n_nodes, [&](int64_t p) { return nodes[p]; }, a.win_push, blk, a.parts, nullptr,
+                   nullptr);
     }
-    const unsigned long long m = __ballot(listed);
-    if (lane == 0) wave_n[wave] = __popcll(m);
-    __syncthreads();
-    int off = base, total = 0;
-    for (int w = 0; w < 16; ++w) { if (w < wave) off += wave_n[w]; total += wave_n[w]; }
-    if (listed) free_list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)sl;
-    __syncthreads();
-    if (tid == 0) base += total;
-    __syncthreads();
+    return;
   }
-  if (tid == 0) { state[0] = 0; state[1] = base; state[3] = (int32_t)plan_n; state[4] = new_mark; }
-}
-// dense[slot_id[s]] = rows[s]: the dense table of the reference (History.emb) for whoever wants to look at it
-__global__ __launch_bounds__(256) void k_slot_materialize(const float* __restrict__ rows, const int32_t* __restrict__ slot_id,
-                                                          int64_t n_slots, int64_t n_nodes, float* __restrict__ dense) {
+  blk -= a.nB;
+  if (blk < a.nC) {    // positions as the append pass numbers them: [neighbours (Qc*K) ; evaluated nodes (Qc)]
+    const int64_t i = (int64_t)blk * ELECT_THREADS + threadIdx.x;
+    if (i == 0) *a.claim.count = 0;
+    int64_t id = -1, pos = 0;
+    if (i < Q * K) { id = o_nbr[i]; pos = i; }
+    else if (i < Q * K + Q) { id = nodes[i - Q * K]; pos = Qc * K + (i - Q * K); }
+    if (id >= 0 && id < n_nodes && a.claim.flags[id]) a.claim.slot[id] = a.claim.epoch + pos;
+    return;
+  }
+  blk -= a.nC;
   const int lane = threadIdx.x & 63;
-  const int64_t sl = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (sl < 1 || sl >= n_slots) return;
-  const int64_t id = slot_id[sl];
+  const int64_t u = (int64_t)blk * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
+  const int64_t n_unc = *a.unc_count < a.cap ? *a.unc_count : a.cap;
+  if (u >= n_unc) return;
+  const int64_t q = Q + u;
+  sample_recent_wave(csr.indptr, csr.nbr, csr.eid, csr.ts, csr.fences, csr.n_rows, nodes[q], qts[q], q, Qc, K, o_nbr, o_eid, o_et,
+                     o_dt, nullptr, a.claim, lane);
+}
+
+// Third: the append pass of the work-list over [neighbours (Qc*K) ; evaluated nodes (Qc)] (train order) and, with the slot
+// cache, the history pull of layer 2 (history.py:32-36) as an index translation -- the attention launch gathers
+// rows[pull_idx[i]] exactly as it gathered hist[nbr[i]].
+__global__ __launch_bounds__(1024) void k_budget_append(int n_app, const int32_t* __restrict__ ids32, int64_t n32,
+                                                         const int64_t* __restrict__ ids64, int64_t n64,
+                                                         const uint8_t* __restrict__ flags, const int64_t* __restrict__ slot,
+                                                         int64_t epoch, int64_t n_nodes, int32_t* worklist, int32_t* count,
+                                                         slot_view sv, const int32_t* __restrict__ nbr_top, int64_t n_top,
+                                                         int32_t* __restrict__ pull_idx) {
+  __shared__ int wave_n[16];
+  __shared__ int block_base;
+  if ((int)blockIdx.x < n_app) {
+    worklist_append_block(ids32, n32, ids64, n64, flags, slot, epoch, n_nodes, worklist, count, blockIdx.x, wave_n, &block_base);
+    return;
+  }
+  const int64_t i = (int64_t)((int)blockIdx.x - n_app) * 1024 + threadIdx.x;
+  if (i >= n_top) return;
+  const int64_t v = nbr_top[i];
+  pull_idx[i] = (v >= 0 && v < n_nodes) ? (int32_t)slot_row(sv.stamp[v], sv) : 0;
+}
+
+// update_flag (history.py:25-30: the flags become exactly the plan) and what it implies for the rows: entry i of the plan
+// takes row i of the plan region this step writes -- copied from wherever the id's row is now (the batch region if it was
+// evaluated in this step, the other plan region if the previous plan kept it, the zero row otherwise), 16 lanes a row --
+// and the id is stamped (kind 1, this generation), flagged and remembered in prev_plan.
+__global__ __launch_bounds__(256) void k_slot_keep(const int64_t* __restrict__ plan, int64_t plan_n, int64_t n_nodes, slot_view sv,
+                                                   int64_t next_base, float* __restrict__ rows, int64_t* __restrict__ prev_plan,
+                                                   uint8_t* __restrict__ cache_flag) {
+  const int sub = threadIdx.x & 15;
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (i >= plan_n) return;
+  const int64_t id = plan[i];
+  const bool valid = id >= 0 && id < n_nodes;
+  const int64_t from = valid ? slot_row(sv.stamp[id], sv) : 0;
+  const f32x4* s = reinterpret_cast<const f32x4*>(rows + from * ORCA_D);
+  f32x4* d = reinterpret_cast<f32x4*>(rows + (next_base + i) * ORCA_D);
+  const f32x4 x0 = s[sub], x1 = s[sub + 16 < ORCA_D / 4 ? sub + 16 : sub];
+  d[sub] = x0;
+  if (sub + 16 < ORCA_D / 4) d[sub + 16] = x1;
+  if (sub == 0) {
+    prev_plan[i] = id;
+    if (valid) {
+      sv.stamp[id] = (sv.gen << STAMP_SHIFT) | STAMP_KIND | i;
+      cache_flag[id] = 1;
+    }
+  }
+}
+// dense[prev_plan[i]] = row i of the current plan region: the dense table of the reference (History.emb) restricted to
+// the ids the plan keeps, for whoever wants to look at it
+__global__ __launch_bounds__(256) void k_slot_materialize(const float* __restrict__ rows, const int64_t* __restrict__ prev_plan,
+                                                          int64_t prev_n, int64_t cur_base, int64_t n_nodes,
+                                                          float* __restrict__ dense) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= prev_n) return;
+  const int64_t id = prev_plan[i];
   if (id < 0 || id >= n_nodes) return;
-  for (int c = lane; c < ORCA_D; c += 64) dense[id * ORCA_D + c] = rows[sl * ORCA_D + c];
+  for (int c = lane; c < ORCA_D; c += 64) dense[id * ORCA_D + c] = rows[(cur_base + i) * ORCA_D + c];
 }
 }  // namespace
 
 ORCA_API int orca_engine_set_slot_cache(orca_engine_t* e, const orca_slot_cache* c) {
   ORCA_REQUIRE(e, "orca_engine_set_slot_cache: null handle");
   if (!c || !c->rows) { e->sc = orca_slot_cache{}; return ORCA_OK; }
-  ORCA_REQUIRE(c->slot_of && c->slot_id && c->free_list && c->state && c->pull_idx && c->prev_plan && c->n_slots >= 2 &&
-               c->n_slots <= 65536 && c->prev_cap >= 0, "orca_engine_set_slot_cache: bad descriptor");
+  ORCA_REQUIRE(c->stamp && c->pull_idx && c->prev_plan && c->plan_cap >= 1 && c->q_bound >= 1 && c->q_bound <= STAMP_INDEX,
+               "orca_engine_set_slot_cache: incomplete cache");
+  ORCA_REQUIRE(c->gen >= 2 && (c->cur == 0 || c->cur == 1) && c->prev_n >= 0 && c->prev_n <= c->plan_cap,
+               "orca_engine_set_slot_cache: generation %lld / region %d / %lld cached ids out of range", (long long)c->gen, c->cur,
+               (long long)c->prev_n);
   e->sc = *c;
   return ORCA_OK;
 }
 
+ORCA_API int orca_engine_get_slot_cache(orca_engine_t* e, orca_slot_cache* c) {
+  ORCA_REQUIRE(e && c, "orca_engine_get_slot_cache: null pointer");
+  *c = e->sc;
+  return ORCA_OK;
+}
+
 ORCA_API int orca_slot_cache_materialize(const orca_slot_cache* c, int64_t n_nodes, float* dense, void* stream) {
-  ORCA_REQUIRE(c && c->rows && c->slot_id && dense && n_nodes > 0, "orca_slot_cache_materialize: null pointer");
-  k_slot_materialize<<<(unsigned)ceil_div64(c->n_slots, 4), 256, 0, (hipStream_t)stream>>>(c->rows, c->slot_id, c->n_slots, n_nodes, dense);
+  ORCA_REQUIRE(c && c->rows && c->prev_plan && dense && n_nodes > 0, "orca_slot_cache_materialize: null pointer");
+  if (c->prev_n == 0) return ORCA_OK;
+  k_slot_materialize<<<(unsigned)ceil_div64(c->prev_n, 4), 256, 0, (hipStream_t)stream>>>(
+      c->rows, c->prev_plan, c->prev_n, 1 + (int64_t)c->cur * c->plan_cap, n_nodes, dense);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }
@@ -1106,103 +1150,151 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
                (long long)(3 * bs + cap), (long long)d.q_max);
   if (bs == 0) return ORCA_OK;
   ORCA_REQUIRE(src && dst && neg && ts && eidx && cache_flag && bitmap && unc && unc_count && tmax && nbr_top && eid_top &&
-               et_top && dt_top && out && d.csr, "orca_engine_step_budget: null pointer");
-  const bool slots = e->sc.rows != nullptr;
+               et_top && dt_top && out && d.csr && d.winners, "orca_engine_step_budget: null pointer");
+  orca_slot_cache& c = e->sc;
+  const bool slots = c.rows != nullptr;
   ORCA_REQUIRE(slots || d.hist[0], "orca_engine_step_budget: neither a history table nor a slot cache");
   ORCA_REQUIRE(!slots || plan_n >= 0, "orca_engine_step_budget: the slot cache follows a cache plan; a step without one (flags "
                "accumulate, history.py:25-30) needs the dense table -- materialise the slots and switch the cache off first");
-  ORCA_REQUIRE(!slots || (e->sc.n_slots > plan_n + 3 * bs + cap && plan_n <= e->sc.prev_cap),
-               "orca_engine_step_budget: slot cache of %lld rows / %lld plan ids is too small for plan %lld + %lld evaluated nodes",
-               (long long)e->sc.n_slots, (long long)e->sc.prev_cap, (long long)plan_n, (long long)(3 * bs + cap));
+  ORCA_REQUIRE(!slots || (plan_n <= c.plan_cap && 3 * bs + cap <= c.q_bound),
+               "orca_engine_step_budget: slot cache for plans of %lld ids / %lld evaluated nodes is too small for %lld / %lld",
+               (long long)c.plan_cap, (long long)c.q_bound, (long long)plan_n, (long long)(3 * bs + cap));
   const int64_t Q = 3 * bs, Qc = Q + cap;
   const int K = d.K;
+  auto parts_for = [](int64_t n) { return n <= ELECT_MAX / 3 ? 1 : (int)ceil_div64(n, ELECT_MAX / 2); };
+  const int parts_m = parts_for(2 * bs), parts_p = parts_for(Qc);
+  ORCA_REQUIRE(parts_m <= ELECT_PARTS_MAX && (slots || parts_p <= ELECT_PARTS_MAX),
+               "orca_engine_step_budget: a batch of %lld interactions / %lld evaluated nodes exceeds the in-kernel elections "
+               "(the dispatched path takes it)", (long long)bs, (long long)Qc);
+  uint8_t *win_push = d.winners, *win_msg = d.winners + d.q_max;
 #define STEP(expr) do { const int rc_ = (expr); if (rc_ != ORCA_OK) return rc_; } while (0)
-  // roots, their neighbours (the layer-2 keys), and which of those have no cached layer-1 embedding (:251)
   (void)hipGetLastError();      // (a status left behind by an earlier runtime call is not this step's)
-  k_budget_roots<<<1, 1024, 0, s>>>(src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32, tmax);
+  budget_csr csr{};
+  STEP(orca_csr_arrays(d.csr, &csr.n_rows, nullptr, &csr.indptr, &csr.nbr, &csr.eid, &csr.ts));
+  STEP(orca_csr_fences(d.csr, &csr.fences));
+  slot_view sv{};
+  int64_t next_base = 0;
+  float* comb = d.emb[0];
+  if (slots) {
+    sv.stamp = c.stamp; sv.gen = c.gen;
+    sv.cur_base = 1 + (int64_t)c.cur * c.plan_cap;
+    sv.batch_base = 1 + 2 * c.plan_cap;
+    next_base = 1 + (int64_t)(c.cur ^ 1) * c.plan_cap;
+    comb = c.rows + sv.batch_base * ORCA_D;        // layer 1 writes the batch region: the push moves nothing
+  }
+  // 1. roots, their neighbours (the layer-2 keys), batch stamps; the message election rides along (tgn_model.py:99-102,174-176)
+  const int64_t stamp_epoch = take_epochs(e, 1);
+  k_budget_begin<<<(unsigned)(parts_m + ceil_div64(Q, ELECT_THREADS / 64)), ELECT_THREADS, 0, s>>>(
+      src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32, tmax, unc_count, win_msg, parts_m, d.n_nodes, csr, K, d.slot, stamp_epoch,
+      d.nbr, d.eid, d.et, d.dt, nbr_top, eid_top, et_top, dt_top);
   ORCA_LAUNCH_CHECK();
-  STEP(orca_sample_recent(d.csr, d.nodes, d.qts, Q, K, nbr_top, eid_top, et_top, dt_top, nullptr, stream_));
-  STEP(orca_find_uncached_unordered(nbr_top, Q * K, d.nodes, Q, cache_flag, d.slot, take_epochs(e, 1), d.n_nodes, bitmap, unc,
-                                    cap, unc_count, stream_));
-  k_budget_cnodes<<<(unsigned)ceil_div64(cap, 256), 256, 0, s>>>(unc, unc_count, cap, Q, tmax, d.nodes, d.nodes32, d.qts, err);
+  // 2. which of those neighbours have no cached layer-1 embedding (:200-212, :251), and the evaluated set behind the roots
+  STEP(orca_uncached_mark(nbr_top, Q * K, cache_flag, d.slot, stamp_epoch, d.n_nodes, bitmap, unc, cap, unc_count, stream_));
+  STEP(orca_uncached_finish_nodes(unc, cap, unc_count, bitmap, d.n_nodes, Q, tmax, d.nodes, d.nodes32, d.qts, err, stream_));
+  // 3. their neighbours; the push election; the work-list claims of everything layer 1 reads (:224-246)
+  expand_args xa{};
+  if (slots) {
+    xa.nA = (int)ceil_div64(c.prev_n, ELECT_THREADS);
+    xa.prev_plan = c.prev_plan; xa.prev_n = c.prev_n; xa.cache_flag = cache_flag;
+    xa.nB = (int)ceil_div64(Qc, ELECT_THREADS);
+    xa.stamp = c.stamp; xa.gen = c.gen;
+  } else {
+    xa.nB = parts_p; xa.parts = parts_p; xa.win_push = win_push;
+  }
+  const int64_t cand = Qc * (K + 1);
+  int64_t claim_epoch = 0;
+  if (train) {
+    claim_epoch = take_epochs(e, cand);
+    xa.nC = (int)ceil_div64(Q * K + Q, ELECT_THREADS);
+    xa.claim = orca_claim{d.pending, d.slot, claim_epoch, d.n_nodes, d.count};
+  }
+  xa.unc_count = unc_count; xa.cap = cap;
+  k_budget_expand<<<(unsigned)(xa.nA + xa.nB + xa.nC + ceil_div64(cap, ELECT_THREADS / 64)), ELECT_THREADS, 0, s>>>(
+      xa, d.nodes, d.qts, Q, d.n_nodes, csr, K, d.nbr, d.eid, d.et, d.dt);
   ORCA_LAUNCH_CHECK();
-  // layer 1 over [roots; uncached]: neighbours, updated memory of what they read (:224-246), attention
-  STEP(orca_sample_recent(d.csr, d.nodes, d.qts, Qc, K, d.nbr, d.eid, d.et, d.dt, nullptr, stream_));
   orca_tgat_inputs in{};
   in.src_table = d.memory; in.src_idx = d.nodes32;
   in.nbr_table = d.memory; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
   in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b; in.q_folded = d.att_q_folded;
+  // 4. the work-list itself and the pulls of layer 2; updated memory of what layer 1 reads
+  if (train || slots) {
+    const int n_app = train ? (int)ceil_div64(cand, 1024) : 0;
+    k_budget_append<<<(unsigned)(n_app + (slots ? ceil_div64(Q * K, 1024) : 0)), 1024, 0, s>>>(
+        n_app, d.nbr, Qc * K, d.nodes, Qc, d.pending, d.slot, claim_epoch, d.n_nodes, d.worklist, d.count, sv, nbr_top, Q * K,
+        slots ? c.pull_idx : nullptr);
+    ORCA_LAUNCH_CHECK();
+  }
   if (train) {
-    STEP(orca_worklist_build(d.nbr, Qc * K, d.nodes, Qc, d.pending, d.slot, take_epochs(e, Qc * (K + 1)), d.n_nodes,
-                             d.worklist, d.count, stream_));
-    const int64_t bound = Qc * (K + 1) < d.n_nodes ? Qc * (K + 1) : d.n_nodes;
-    STEP(orca_gru_update(d.gru_blob, 300 + d.d_e, d.worklist, bound, d.count, d.messages, d.memory, d.overlay, nullptr,
-                         nullptr, stream_));
+    STEP(orca_gru_update(d.gru_blob, 300 + d.d_e, d.worklist, cand < d.n_nodes ? cand : d.n_nodes, d.count, d.messages, d.memory,
+                         d.overlay, nullptr, nullptr, stream_));
     in.src_overlay = d.overlay; in.src_flags = d.pending; in.nbr_overlay = d.overlay; in.nbr_flags = d.pending;
   }
-  float* comb = d.emb[0];
+  // 5. layer 1 over [roots; uncached].  Train order: the overlay holds GRU(message, memory) of every pending positive (the
+  // roots are part of the work-list), so the launch also commits those rows (memory_updater.py:25-39; the flags need no
+  // clearing: the message store raises them for exactly these ids).  Dense table: it also pushes the winners' rows.
   {
     orca_tgat_side side{};
     side.q_extra = unc_count;
     side.q_base = Q;
+    if (train) {
+      side.persist_memory = d.memory; side.persist_last_update = d.last_update; side.persist_msg_ts = d.msg_ts;
+      side.persist_n = 2 * bs;
+    }
+    if (!slots) { side.push_table = d.hist[0]; side.push_ids = d.nodes; side.push_winner = win_push; }
     STEP(orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, Qc, K, comb, nullptr, &side, stream_));
   }
-  // push them (last occurrence wins, H7) and move the cache flags on (history.py:25-30)
+  // 6. the cache flags move on (history.py:25-30)
   if (slots) {
-    // budget-bounded history: the evaluated rows go to slots (the id -> slot index decides: reuse the id's slot or take a
-    // free one), the layer-2 pulls are translated to slot numbers, and what the plan does not keep is evicted
-    const orca_slot_cache& c = e->sc;
-    const int64_t ep = take_epochs(e, Qc);
-    k_slot_elect<<<(unsigned)ceil_div64(Qc, 256), 256, 0, s>>>(d.nodes, Qc, d.slot, ep, d.n_nodes);
-    k_slot_push<<<(unsigned)ceil_div64(Qc, SLOT_PUSH_THREADS), SLOT_PUSH_THREADS, 0, s>>>(d.nodes, Qc, d.slot, ep, d.n_nodes, comb, c.rows, c.slot_of, c.slot_id,
-                                                           c.free_list, c.state, (int)c.n_slots);
-    k_slot_translate<<<(unsigned)ceil_div64(Q * K, 256), 256, 0, s>>>(nbr_top, Q * K, d.n_nodes, c.slot_of, c.pull_idx);
-    k_slot_evict<<<1, 1024, 0, s>>>(plan, plan_n, d.n_nodes, c.slot_of, c.slot_id, c.free_list, c.state, c.n_slots, c.prev_plan,
-                                    cache_flag);
-    ORCA_LAUNCH_CHECK();
-  } else {
-  STEP(orca_history_push(d.hist[0], comb, d.nodes, Qc, d.slot, take_epochs(e, Qc), d.n_nodes, stream_));
-  if (plan_n >= 0) {
+    if (plan_n > 0) {
+      k_slot_keep<<<(unsigned)ceil_div64(plan_n, 16), 256, 0, s>>>(plan, plan_n, d.n_nodes, sv, next_base, c.rows, c.prev_plan, cache_flag);
+      ORCA_LAUNCH_CHECK();
+    }
+  } else if (plan_n >= 0) {
     STEP(orca_fill_u8(cache_flag, d.n_nodes, 0, stream_));
     if (plan_n > 0) STEP(orca_set_flags(cache_flag, plan, nullptr, plan_n, nullptr, 1, d.n_nodes, stream_));
   } else {
     STEP(orca_set_flags(cache_flag, d.nodes, nullptr, Qc, nullptr, 1, d.n_nodes, stream_));
   }
-  }
-  // layer 2 over the roots: their own layer-1 rows, neighbours pulled from the history table (:273-285)
+  // 7. layer 2 over the roots: their own layer-1 rows, neighbours pulled from the history (:273-285).  Train order: it reads
+  // none of the memory / message / pending tables, so its waves also build and store the raw messages (tgn_model.py:131-141)
   orca_tgat_inputs in2{};
   in2.src_table = comb;
-  in2.nbr_table = slots ? e->sc.rows : d.hist[0];
-  in2.nbr_idx = slots ? e->sc.pull_idx : nbr_top;
+  in2.nbr_table = slots ? c.rows : d.hist[0];
+  in2.nbr_idx = slots ? c.pull_idx : nbr_top;
   in2.nbr_ids = nbr_top;
   in2.edge_table = d.edge_feats; in2.edge_idx = eid_top;
   in2.dt = dt_top; in2.time_w = d.time_w; in2.time_b = d.time_b; in2.q_folded = d.att_q_folded;
-  STEP(orca_tgat_forward_side(d.att_blob[1], d.d_e, &in2, Q, K, out, nullptr, nullptr, stream_));
-  // the state moves on (tgn_model.py:127-145): persist the positives' memory, store the raw messages -- in that order
-  // when training, the other way round in evaluation
-  auto persist = [&]() -> int {
-    // Train order: the overlay already holds GRU(message, memory) of every pending positive -- the roots are part of the
-    // work-list above -- so the rows are committed by one copy kernel, and the flags need no clearing: the message store
-    // that follows raises them for exactly these ids (as orca_engine_finish does for Path B).
-    if (train)
-      return orca_persist_overlay(d.nodes, 2 * bs, d.pending, d.overlay, d.memory, d.last_update, d.msg_ts, d.n_nodes, stream_);
-    // Evaluation order: GRU of the messages just stored, out of place into the overlay (the split kernels; in place a row
-    // would have to be read and written by one workgroup), then the commit.  The overlay rows of ids that stop being
-    // pending are dead.
+  {
+    orca_tgat_side side{};
+    if (train) {
+      side.store_bs = bs; side.store_nodes = d.nodes; side.store_ts = d.qts; side.store_eidx = eidx;
+      side.store_winner = win_msg;
+      side.store_memory = d.memory; side.store_last_update = d.last_update;
+      side.store_messages = d.messages; side.store_msg_ts = d.msg_ts; side.store_pending = d.pending;
+    }
+    STEP(orca_tgat_forward_side(d.att_blob[1], d.d_e, &in2, Q, K, out, nullptr, &side, stream_));
+  }
+  if (!train) {
+    // Evaluation order (tgn_model.py:131-145): store, then GRU of the messages just stored, out of place into the overlay
+    // (the split kernels; in place a row would have to be read and written by one workgroup), then the commit.  The
+    // overlay rows of ids that stop being pending are dead.
+    STEP(orca_message_store_winners(src, dst, eidx, ts, bs, d.memory, d.last_update, d.edge_feats, d.d_e, d.time_w, d.time_b,
+                                    win_msg, d.n_nodes, d.messages, d.msg_ts, d.pending, stream_));
     STEP(orca_worklist_build(nullptr, 0, d.nodes, 2 * bs, d.pending, d.slot, take_epochs(e, 2 * bs), d.n_nodes, d.worklist,
                              d.count, stream_));
     const int64_t bound = 2 * bs < d.n_nodes ? 2 * bs : d.n_nodes;
     STEP(orca_gru_update(d.gru_blob, 300 + d.d_e, d.worklist, bound, d.count, d.messages, d.memory, d.overlay, nullptr,
                          nullptr, stream_));
     STEP(orca_commit_rows(d.worklist, bound, d.count, d.overlay, d.memory, d.last_update, d.msg_ts, d.n_nodes, stream_));
-    return orca_set_flags(d.pending, d.nodes, nullptr, 2 * bs, nullptr, 0, d.n_nodes, stream_);
-  };
-  if (train) STEP(persist());
-  STEP(orca_message_store(src, dst, eidx, ts, bs, d.memory, d.last_update, d.edge_feats, d.d_e, d.time_w, d.time_b, d.slot,
-                          take_epochs(e, 2 * bs), d.n_nodes, d.messages, d.msg_ts, d.pending, stream_));
-  if (!train) STEP(persist());
+    STEP(orca_set_flags(d.pending, d.nodes, nullptr, 2 * bs, nullptr, 0, d.n_nodes, stream_));
+  }
 #undef STEP
+  if (slots) {      // the plan region just written holds the cached rows of the next step
+    c.gen += 1;
+    c.cur ^= 1;
+    c.prev_n = plan_n;
+  }
   e->overlay_complete = false;      // messages were stored without their overlay rows
   return ORCA_OK;
 }

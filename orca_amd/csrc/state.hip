@@ -23,14 +23,8 @@ __global__ void k_fill_u8(uint8_t* p, int64_t n, uint8_t v) {
   if (i < n) p[i] = v;
 }
 
-// Distinct-id work-list in two passes without same-address atomics (hub ids repeat thousands of times
-// in a power-law batch, and atomics on one address serialise at L2):
-//   claim : every position p stores slot[id] = epoch + p with a plain store -- some one value survives;
-//   append: the position whose value survived is the id's unique representative; representatives are
-//           appended with one atomicAdd per wavefront.
-__device__ __forceinline__ int64_t worklist_id(const int32_t* ids32, int64_t n32, const int64_t* ids64, int64_t i) {
-  return i < n32 ? (int64_t)ids32[i] : ids64[i - n32];
-}
+#include "worklist.h"
+
 __global__ void k_worklist_claim(const int32_t* __restrict__ ids32, int64_t n32, const int64_t* __restrict__ ids64,
                                  int64_t n64, const uint8_t* __restrict__ flags, int64_t* slot, int64_t epoch,
                                  int64_t n_nodes, int32_t* count) {
@@ -46,28 +40,9 @@ __global__ __launch_bounds__(1024) void k_worklist_append(const int32_t* __restr
                                                            const uint8_t* __restrict__ flags,
                                                            const int64_t* __restrict__ slot, int64_t epoch,
                                                            int64_t n_nodes, int32_t* worklist, int32_t* count) {
-  // one atomicAdd per 1024-thread workgroup: the counter is a single address, and per-wave atomics on it
-  // serialise at L2 (704 of them cost more than the rest of the kernel)
   __shared__ int wave_n[16];
   __shared__ int block_base;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool take = false;
-  int64_t id = -1;
-  if (i < n32 + n64) {
-    id = worklist_id(ids32, n32, ids64, i);
-    take = id >= 0 && id < n_nodes && (!flags || flags[id]) && slot[id] == epoch + i;
-  }
-  const unsigned long long m = __ballot(take);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) wave_n[wave] = __popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int tot = 0;
-    for (int w = 0; w < 16; ++w) { int c = wave_n[w]; wave_n[w] = tot; tot += c; }
-    block_base = tot ? atomicAdd(count, tot) : 0;
-  }
-  __syncthreads();
-  if (take) worklist[block_base + wave_n[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)id;
+  worklist_append_block(ids32, n32, ids64, n64, flags, slot, epoch, n_nodes, worklist, count, blockIdx.x, wave_n, &block_base);
 }
 
 __global__ void k_set_flags(uint8_t* flags, const int64_t* ids64, const int32_t* ids32, int64_t n,
@@ -512,9 +487,15 @@ __global__ void k_mark_append(const int32_t* __restrict__ nbr, int64_t n, const 
   }
 }
 // one workgroup: drop the smallest id of out[0 .. n) (n = *count, at most cap entries stored), clear the bitmap words of
-// every listed id; more than cap ids (the caller's overflow): the whole bitmap is cleared instead
-__global__ __launch_bounds__(1024) void k_drop_min_clear(int64_t* __restrict__ out, int64_t cap, int32_t* __restrict__ count,
-                                                         uint32_t* __restrict__ bitmap, int64_t n_words) {
+// every listed id; more than cap ids (the caller's overflow): the whole bitmap is cleared instead.  nodes != null (the
+// native Path C step): the same workgroup also lays the evaluated set behind the Q roots -- entries Q .. Q+cap-1 = the
+// listed ids, then padding: id -1 for the lists that write state (every id-indexed kernel skips it), id 0 (the padding
+// node) where a row is gathered; all at time *tmax (embedding_module.py:256-259) -- and raises bit 1 of *err on overflow.
+__global__ __launch_bounds__(1024) void k_uncached_finish(int64_t* __restrict__ out, int64_t cap, int32_t* __restrict__ count,
+                                                          uint32_t* __restrict__ bitmap, int64_t n_words, int64_t Q,
+                                                          const double* __restrict__ tmax, int64_t* __restrict__ nodes,
+                                                          int32_t* __restrict__ nodes32, double* __restrict__ qts,
+                                                          int32_t* __restrict__ err) {
   __shared__ long long wave_min[16];
   __shared__ long long the_min;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -538,14 +519,31 @@ __global__ __launch_bounds__(1024) void k_drop_min_clear(int64_t* __restrict__ o
     the_min = m2;
   }
   __syncthreads();
-  if (n <= 0 || zero_seen) return;               // (zero_seen: the count is already that of the set without its first element)
-  // (with more ids than cap the true minimum may be among the ones that were not stored: the caller's overflow flag
-  // already says the step is invalid; the stored list still loses one entry so that the count stays n - 1)
-  const long long last = out[stored - 1];
+  // (zero_seen: the count is already that of the set without its first element.  With more ids than cap the true minimum
+  // may be among the ones that were not stored: the caller's overflow flag already says the step is invalid; the stored
+  // list still loses one entry so that the count stays n - 1)
+  const bool drop = n > 0 && !zero_seen;
+  const long long last = drop ? out[stored - 1] : 0;
+  const int64_t n_out = drop ? (n > cap ? n : n - 1) : n;      // (n > cap: stays above cap, which is what callers test)
+  const double t = nodes ? *tmax : 0.0;
   __syncthreads();
-  for (int64_t i = tid; i < stored; i += 1024)
-    if (out[i] == the_min) out[i] = last;       // ids are distinct: exactly one hit
-  if (tid == 0) *count = (int32_t)(n > cap ? n : n - 1);      // (n > cap: stays above cap, which is what callers test)
+  for (int64_t i = tid; i < (nodes ? cap : stored); i += 1024) {
+    long long v = -1;
+    if (i < stored) {
+      v = out[i];
+      if (drop && v == the_min) out[i] = v = last;             // ids are distinct: exactly one hit
+    }
+    if (nodes) {
+      const bool ok = i < n_out;
+      nodes[Q + i] = ok ? v : -1;
+      nodes32[Q + i] = ok ? (int32_t)v : 0;
+      qts[Q + i] = t;
+    }
+  }
+  if (tid == 0) {
+    *count = (int32_t)n_out;
+    if (nodes && err && n_out > cap) atomicOr(err, 2);         // more uncached neighbours than the launch bound
+  }
 }
 }  // namespace
 
@@ -559,7 +557,23 @@ int orca_find_uncached_unordered(const int32_t* nbr, int64_t n_nbr, const int64_
   hipStream_t st = (hipStream_t)stream;
   k_stamp_ids_zero<<<blocks(n_batch > 0 ? n_batch : 1, 256), 256, 0, st>>>(batch_nodes, n_batch, slot, epoch, n_nodes, count);
   if (n_nbr) k_mark_append<<<blocks(n_nbr, 256), 256, 0, st>>>(nbr, n_nbr, slot, epoch, cache_flag, n_nodes, bitmap, out, cap, count);
-  k_drop_min_clear<<<1, 1024, 0, st>>>(out, cap, count, bitmap, ceil_div64(n_nodes, 32));
+  k_uncached_finish<<<1, 1024, 0, st>>>(out, cap, count, bitmap, ceil_div64(n_nodes, 32), 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+
+// The two halves of the call above for the native Path C step, whose first kernel has already stamped the batch ids into
+// `slot` (epoch) and zeroed count[0..1]: the marking pass, and the one-workgroup finish that also lays out the evaluated set.
+int orca_uncached_mark(const int32_t* nbr, int64_t n_nbr, const uint8_t* cache_flag, const int64_t* slot, int64_t epoch,
+                       int64_t n_nodes, uint32_t* bitmap, int64_t* out, int64_t cap, int32_t* count, void* stream) {
+  if (n_nbr == 0) return ORCA_OK;
+  k_mark_append<<<blocks(n_nbr, 256), 256, 0, (hipStream_t)stream>>>(nbr, n_nbr, slot, epoch, cache_flag, n_nodes, bitmap, out, cap, count);
+  ORCA_LAUNCH_CHECK();
+  return ORCA_OK;
+}
+int orca_uncached_finish_nodes(int64_t* out, int64_t cap, int32_t* count, uint32_t* bitmap, int64_t n_nodes, int64_t Q,
+                               const double* tmax, int64_t* nodes, int32_t* nodes32, double* qts, int32_t* err, void* stream) {
+  k_uncached_finish<<<1, 1024, 0, (hipStream_t)stream>>>(out, cap, count, bitmap, ceil_div64(n_nodes, 32), Q, tmax, nodes, nodes32, qts, err);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

@@ -208,13 +208,13 @@ class OrcaEngine:
   @property
   def hist(self):
     """the dense [n_nodes, 100] history tables of the reference (History.emb).  While the history lives in the slot cache
-    this is a MATERIALISED VIEW built on every access (rows of the ids that hold a slot, zeros elsewhere): for tests and
-    for the drop-in mirror, not for the hot path."""
+    this is a MATERIALISED VIEW built on every access (rows of the ids the cache plan keeps, zeros elsewhere): for tests
+    and for the drop-in mirror, not for the hot path."""
     if self._hist_dense is not None:
       return self._hist_dense
     dense = torch.zeros(self.N, D, dtype=torch.float32, device=self.device)
     if self._sc is not None:
-      check(_lib.load().orca_slot_cache_materialize(ctypes.byref(self._sc["desc"]), self.N, ptr(dense), stream()),
+      check(_lib.load().orca_slot_cache_materialize(ctypes.byref(self._slot_desc()), self.N, ptr(dense), stream()),
             "orca_slot_cache_materialize")
     return [dense]
 
@@ -224,44 +224,85 @@ class OrcaEngine:
       return sum(t.numel() * 4 for t in self._hist_dense)
     if self._sc is None:
       return 0
-    return sum(self._sc[k].numel() * self._sc[k].element_size() for k in ("rows", "slot_of", "slot_id", "free_list", "prev_plan"))
+    return sum(self._sc[k].numel() * self._sc[k].element_size() for k in ("rows", "stamp", "prev_plan"))
+
+  def _slot_desc(self):
+    """the slot cache as the native driver last left it (generation, plan region, cached ids: the steps advance them)"""
+    sc = self._sc
+    if self._native is not None and sc.get("bound"):
+      check(_lib.load().orca_engine_get_slot_cache(self._native, ctypes.byref(sc["desc"])), "orca_engine_get_slot_cache")
+    return sc["desc"]
 
   def _slots_for(self, need_rows, plan_n, n_pull):
-    """the slot cache, (re)allocated for `need_rows` evaluated nodes per batch and plans of plan_n ids"""
+    """the slot cache (include/orca_hip.h, orca_slot_cache), (re)allocated for `need_rows` evaluated nodes per batch and
+    plans of plan_n ids, and bound to the native handle"""
     dev = self.device
     sc = self._sc
-    n_slots = int(self.budget) + int(need_rows) + 2
-    n_slots = max(n_slots, int(plan_n) + int(need_rows) + 2)
-    if n_slots > 65536:
-      raise OrcaError(f"OrcaEngine: a slot cache of {n_slots} rows exceeds 65536 (budget {self.budget} + {need_rows} evaluated "
-                      "nodes per batch): construct the engine with slot_history=False, or lower budget_cap")
-    prev_cap = max(int(self.budget), int(plan_n), 1)
-    if sc is not None and sc["n_slots"] >= n_slots and sc["prev_cap"] >= prev_cap and sc["pull"].numel() >= n_pull:
+    plan_cap = max(int(self.budget), int(plan_n), 1)
+    if sc is not None and sc["q_bound"] >= need_rows and sc["plan_cap"] >= plan_cap and sc["pull"].numel() >= n_pull:
+      if not sc.get("bound"):
+        check(_lib.load().orca_engine_set_slot_cache(self._native, ctypes.byref(sc["desc"])), "orca_engine_set_slot_cache")
+        sc["bound"] = True
       return sc
-    new = dict(n_slots=n_slots, prev_cap=prev_cap,
-               rows=torch.zeros(n_slots, D, dtype=torch.float32, device=dev),
-               slot_of=torch.full((self.N,), -1, dtype=torch.int32, device=dev) if sc is None else sc["slot_of"],
-               slot_id=torch.full((n_slots,), -1, dtype=torch.int32, device=dev),
-               free_list=torch.zeros(n_slots, dtype=torch.int32, device=dev),
-               state=torch.zeros(8, dtype=torch.int32, device=dev),
+    if need_rows >= (1 << 20):
+      raise OrcaError(f"OrcaEngine: {need_rows} evaluated nodes per batch exceed the slot cache's 2^20 positions: construct "
+                      "the engine with slot_history=False, or lower budget_cap")
+    q_bound = int(need_rows) if sc is None else max(int(need_rows), sc["q_bound"])
+    new = dict(plan_cap=plan_cap, q_bound=q_bound,
+               rows=torch.zeros(1 + 2 * plan_cap + q_bound, D, dtype=torch.float32, device=dev),
+               stamp=torch.zeros(self.N, dtype=torch.int64, device=dev) if sc is None else sc["stamp"],
                pull=torch.zeros(max(n_pull, 1), dtype=torch.int32, device=dev),
-               prev_plan=torch.zeros(prev_cap, dtype=torch.int64, device=dev))
-    if sc is None:
-      new["state"][4] = 1               # high-water mark: slot 0 is the zero row, everything above is free
-    else:       # grow: the slots in use keep their numbers; the new ones lie above the high-water mark, i.e. are free
-      old = sc["n_slots"]
-      new["rows"][:old] = sc["rows"]
-      new["slot_id"][:old] = sc["slot_id"]
-      new["free_list"][:old] = sc["free_list"]
-      new["state"].copy_(sc["state"])
-      new["prev_plan"][:sc["prev_cap"]] = sc["prev_plan"]
+               prev_plan=torch.zeros(plan_cap, dtype=torch.int64, device=dev))
     d = _lib.SlotCache()
-    d.rows, d.slot_of, d.slot_id, d.free_list = ptr(new["rows"]), ptr(new["slot_of"]), ptr(new["slot_id"]), ptr(new["free_list"])
-    d.state, d.pull_idx, d.prev_plan = ptr(new["state"]), ptr(new["pull"]), ptr(new["prev_plan"])
-    d.n_slots, d.prev_cap = n_slots, prev_cap
+    d.gen, d.prev_n, d.cur = 2, 0, 0
+    if sc is not None:      # grow: the cached rows move to region 0 of the new array, and their stamps follow
+      old = self._slot_desc()
+      n, base = int(old.prev_n), 1 + int(old.cur) * sc["plan_cap"]
+      new["rows"][1:1 + n] = sc["rows"][base:base + n]
+      new["prev_plan"][:n] = sc["prev_plan"][:n]
+      d.gen, d.prev_n = int(old.gen), n
+      self._restamp(new, n, d.gen)
+    d.rows, d.stamp, d.prev_plan, d.pull_idx = ptr(new["rows"]), ptr(new["stamp"]), ptr(new["prev_plan"]), ptr(new["pull"])
+    d.plan_cap, d.q_bound = plan_cap, q_bound
     new["desc"] = d
+    check(_lib.load().orca_engine_set_slot_cache(self._native, ctypes.byref(d)), "orca_engine_set_slot_cache")
+    new["bound"] = True
     self._sc = new
     return new
+
+  def _restore_slot_backup(self, bk):
+    """the slot cache holds exactly the rows of a backup taken in slot mode (None: an empty cache).  The generation moves
+    past every stamp the table may still hold, so whatever was cached or evaluated since the backup is stale."""
+    old, dev = self._sc, self.device
+    if old is None and bk is None:
+      return
+    gen = int(self._slot_desc().gen) + 2 if old is not None else 2
+    n = int(bk["ids"].numel()) if bk is not None else 0
+    plan_cap = max(int(self.budget), n, 1, old["plan_cap"] if old is not None else 1)
+    q_bound = old["q_bound"] if old is not None else 1
+    new = dict(plan_cap=plan_cap, q_bound=q_bound,
+               rows=torch.zeros(1 + 2 * plan_cap + q_bound, D, dtype=torch.float32, device=dev),
+               stamp=old["stamp"] if old is not None else torch.zeros(self.N, dtype=torch.int64, device=dev),
+               pull=old["pull"] if old is not None else torch.zeros(1, dtype=torch.int32, device=dev),
+               prev_plan=torch.zeros(plan_cap, dtype=torch.int64, device=dev))
+    if n:
+      new["rows"][1:1 + n] = bk["rows"]
+      new["prev_plan"][:n] = bk["ids"]
+    self._restamp(new, n, gen)
+    d = _lib.SlotCache()
+    d.rows, d.stamp, d.prev_plan, d.pull_idx = ptr(new["rows"]), ptr(new["stamp"]), ptr(new["prev_plan"]), ptr(new["pull"])
+    d.plan_cap, d.q_bound, d.gen, d.prev_n, d.cur = plan_cap, q_bound, gen, n, 0
+    new["desc"], new["bound"] = d, False
+    self._sc = new
+
+  @staticmethod
+  def _restamp(sc, n, gen):
+    """stamps of the n cached ids of sc['prev_plan'] as the step of generation gen - 1 would have left them (kind 1, row i)"""
+    if n:
+      ids = sc["prev_plan"][:n]
+      ok = (ids >= 0) & (ids < sc["stamp"].numel())
+      val = ((gen - 1) << 21) | (1 << 20) | torch.arange(n, dtype=torch.int64, device=ids.device)
+      sc["stamp"][ids[ok]] = val[ok]
 
   def _leave_slot_mode(self):
     """the history moves from the slot cache into the dense table (a step without a cache plan, a Python-dispatched
@@ -270,14 +311,25 @@ class OrcaEngine:
     if self._hist_dense is not None:
       return
     self._hist_dense = self.hist            # the materialised view becomes the table
+    self._drop_slots()
+    if self._native is not None:
+      self._rebind_native()
+
+  def _drop_slots(self):
     self._sc = None
     if self._native is not None:
       check(_lib.load().orca_engine_set_slot_cache(self._native, None), "orca_engine_set_slot_cache")
-      self._rebind_native()
+
+  def _unbind_slots(self):
+    """before the native handle goes away: take back the slot cache's generation / region / cached-id count"""
+    if self._sc is not None and self._sc.get("bound"):
+      self._slot_desc()
+      self._sc["bound"] = False
 
   def _rebind_native(self):
     """the native handle caches table pointers: drop it so that the next step rebuilds it with the current tables"""
     L = _lib.load()
+    self._unbind_slots()
     self.slot_epoch = int(L.orca_engine_take_epochs(self._native, 0))
     check(L.orca_engine_drain(self._native, stream()), "orca_engine_drain")
     self._overlay_complete = bool(L.orca_engine_get_overlay_complete(self._native))
@@ -299,9 +351,7 @@ class OrcaEngine:
       self._hist_dense = None
       if self._native is not None:
         self._rebind_native()
-    self._sc = None
-    if self._native is not None and self._slot_eligible:
-      check(_lib.load().orca_engine_set_slot_cache(self._native, None), "orca_engine_set_slot_cache")
+    self._drop_slots()
     for t in (self._hist_dense or []) + self.cache_flag:
       t.zero_()
     self.test_mode = False
@@ -321,9 +371,14 @@ class OrcaEngine:
   # modules/memory.py:39-43, embedding_module.py:83-91
   def backup(self):
     self.sync_replicas()
-    if self._hist_dense is None:        # the history lives in the slot cache: its arrays are the backup
+    if self._hist_dense is None:        # the history lives in the slot cache: the rows the plan keeps are the backup
       sc = self._sc
-      hist = ("slots", None if sc is None else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sc.items() if k != "desc"})
+      if sc is None:
+        hist = ("slots", None)
+      else:
+        d = self._slot_desc()
+        n, base = int(d.prev_n), 1 + int(d.cur) * sc["plan_cap"]
+        hist = ("slots", dict(rows=sc["rows"][base:base + n].clone(), ids=sc["prev_plan"][:n].clone()))
     else:
       hist = [h.clone() for h in self._hist_dense]
     return ([t.clone() for t in (self.memory, self.last_update, self.messages, self.msg_ts, self.pending)],
@@ -337,15 +392,7 @@ class OrcaEngine:
         self._hist_dense = None
         if self._native is not None:
           self._rebind_native()
-      self._sc = None
-      if b[1][1] is not None:
-        new = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b[1][1].items()}
-        d = _lib.SlotCache()
-        d.rows, d.slot_of, d.slot_id, d.free_list = ptr(new["rows"]), ptr(new["slot_of"]), ptr(new["slot_id"]), ptr(new["free_list"])
-        d.state, d.pull_idx, d.prev_plan = ptr(new["state"]), ptr(new["pull"]), ptr(new["prev_plan"])
-        d.n_slots, d.prev_cap = new["n_slots"], new["prev_cap"]
-        new["desc"] = d
-        self._sc = new
+      self._restore_slot_backup(b[1][1])
     else:
       self._leave_slot_mode()
       for t, s in zip(self._hist_dense, b[1]):
@@ -373,6 +420,7 @@ class OrcaEngine:
       return
     L = _lib.load()
     if self._native is not None:
+      self._unbind_slots()
       self.slot_epoch = int(L.orca_engine_take_epochs(self._native, 0))
       check(L.orca_engine_drain(self._native, stream()), "orca_engine_drain")   # the ids the last step stored
       self._overlay_complete = bool(L.orca_engine_get_overlay_complete(self._native))
@@ -510,8 +558,7 @@ class OrcaEngine:
       use_slots = False
     self._ensure_native(Q + cap)
     if use_slots:
-      sc = self._slots_for(Q + cap, plan.numel(), Q * K)
-      check(L.orca_engine_set_slot_cache(self._native, ctypes.byref(sc["desc"])), "orca_engine_set_slot_cache")
+      self._slots_for(Q + cap, plan.numel(), Q * K)
     b = getattr(self, "_bw", None)
     if b is None or b["cap"] != cap or b["Q"] < Q:
       b = self._bw = dict(cap=cap, Q=Q, unc=torch.zeros(cap, dtype=torch.int64, device=dev),
