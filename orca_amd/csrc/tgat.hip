@@ -672,13 +672,11 @@ __device__ __forceinline__ void load_key_rows(KeyRows<ME>& R, KeyTimes& T, const
 }
 
 // cos(dt*w + b) for the chunk's slots (model/time_encoding.py:26-27), kept in registers
+// (wa, ba / wb, bb: time_w, time_b of this lane's columns lane and lane + 64 -- lanes past the width carry the values of
+// column 0 and compute a surplus value: no lane-conditional code)
 __device__ __forceinline__ void encode_key_times(KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S, int j0,
-                                                 int K, int lane) {
+                                                 int K, int lane, float wa, float ba, float wb, float bb) {
   if (!in.dt) return;
-  const int c1 = lane + 64;
-  const int cb = c1 < D ? c1 : 0;      // (lanes past the width compute a surplus value: no lane-conditional code)
-  const float wa = in.time_w[lane], ba = in.time_b[lane];
-  const float wb = in.time_w[cb], bb = in.time_b[cb];
 #pragma unroll
   for (int j = 0; j < KC; ++j) {
     if (j0 + j < K) {
@@ -785,55 +783,88 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   const int a_off = (lane & 15), a_k = 4 * (lane >> 4);
   const int NT200 = pw_tiles(QD), NT100 = pw_tiles(D);
 
-  // LayerNorm affine parameters (P8) and the q-projection weights depend on nothing: fetch them right away
-  const float ln_ga = blob[L.ln_w + lane], ln_ba = blob[L.ln_b + lane];
-  const float ln_gb = blob[c1 < D ? L.ln_w + c1 : L.ln_w], ln_bb = blob[c1 < D ? L.ln_b + c1 : L.ln_b];
   // QK: gather mode with a blob completed by orca_tgat_pack_gather: q~ comes straight from src (no P1)
   constexpr bool qk = QK;
   const int h2 = wave & 1;                        // P2: wave (h2, slot = wave >> 1)
   WaveGemm<1, 7, 13, true> g1;
   WaveGemm<3, 3, 7, FOLD_ALL, true> g2;      // reduction length 100 = 6 k-blocks + 4 columns
-  if constexpr (qk)
-    g2.prefetch(blob4 + (L.pw_qk + (int64_t)h2 * pw_floats(kdim + 1, D)) / 4, NT100, wave >> 1, NW / 2, L.NTk, lane,
-                blob + L.b_qk + h2 * KPS);
-  else
-    g1.prefetch(blob4 + L.pw_q / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_q);
 
   // ---- T0: this wave's query: neighbour slots, source row, L2 touches, time encodings ------------
+  // The stage is a chain of dependent gathers, and what it costs is the number of round trips on that chain.  Its loads
+  // are therefore issued LEVEL BY LEVEL -- everything that depends on the query number alone, then everything that depends
+  // on those values, then the row touches -- and unconditionally: an optional array that is absent is replaced by a valid
+  // address (the weight blob) and its value discarded, dead waves and lanes load clamped positions.  Written with an `if`
+  // per optional input, every load was waited for where it was issued: ten serial round trips instead of three.
   const int64_t q = q0 + wave;
   const bool live_q = q < Q;
+  const int64_t qc = live_q ? q : Q - 1;
+  const bool slot = live_q && lane < K;
+  const int64_t pc = qc * K + (lane < K ? lane : 0);
+  const int32_t* any32 = reinterpret_cast<const int32_t*>(blob);
+  const uint8_t* any8 = reinterpret_cast<const uint8_t*>(blob);
+  const int cb = c1 < D ? c1 : 0;                 // (column c1 is stored only where c1 < D)
+  // level 1
+  const int nr1 = (in.nbr_idx ? in.nbr_idx : any32)[in.nbr_idx ? pc : 0];
+  const int er1 = (in.edge_idx ? in.edge_idx : any32)[in.edge_idx ? pc : 0];
+  const int id1 = (in.nbr_ids ? in.nbr_ids : any32)[in.nbr_ids ? pc : 0];
+  const uint8_t mk1 = (in.nbr_ids ? any8 : in.mask)[in.nbr_ids ? 0 : pc];
+  const float dt1 = (in.dt ? in.dt : blob)[in.dt ? pc : 0];
+  const int sr1 = (in.src_idx ? in.src_idx : any32)[in.src_idx ? qc : 0];
+  const float* twp = in.dt ? in.time_w : blob;
+  const float* tbp = in.dt ? in.time_b : blob;
+  const float tw_a = twp[lane], tb_a = tbp[lane], tw_b = twp[cb], tb_b = tbp[cb];
+  // (fused raw-message store of position q, common.h: its batch arrays are read with the slots)
+  const int64_t st_bs = side.store_bs;
+  const bool st_on = st_bs > 0, st_q = st_on && q < 2 * st_bs;
+  const int64_t sq = st_q ? q : 0, sp = st_q ? (q < st_bs ? q + st_bs : q - st_bs) : 0, se = st_q ? (q < st_bs ? q : q - st_bs) : 0;
+  const int64_t* st_nodes = st_on ? side.store_nodes : reinterpret_cast<const int64_t*>(blob);
+  const uint8_t st_w = (st_on ? side.store_winner : any8)[sq];
+  const int64_t st_id = st_nodes[sq], st_partner = st_nodes[sp];
+  const int64_t st_eidx = (st_on ? side.store_eidx : reinterpret_cast<const int64_t*>(blob))[se];
+  const double st_t = (st_on ? side.store_ts : reinterpret_cast<const double*>(blob))[sq];
   QuerySlots S{0, 0, 0, 0.f, true};
-  if (live_q && lane < K) {
-    const int64_t p = q * K + lane;
-    S.nrow = in.nbr_idx ? in.nbr_idx[p] : (int)p;
-    S.erow = in.edge_idx ? in.edge_idx[p] : (int)p;
-    S.masked = in.nbr_ids ? (in.nbr_ids[p] == 0) : (in.mask[p] != 0);
-    if (in.dt) S.dt = in.dt[p];
-    if (in.nbr_flags) S.ovl = in.nbr_flags[S.nrow] ? 1 : 0;
+  if (slot) {
+    S.nrow = in.nbr_idx ? nr1 : (int)pc;
+    S.erow = in.edge_idx ? er1 : (int)pc;
+    S.masked = in.nbr_ids ? (id1 == 0) : (mk1 != 0);
+    if (in.dt) S.dt = dt1;
   }
+  const int64_t row = in.src_idx ? (int64_t)sr1 : qc;
+  // level 2: the overlay flags of the neighbours and of the source, BOTH candidate source rows (blended bit-wise below:
+  // flag -> table -> row would be one more round trip), the persist's timestamp
+  const uint8_t nf1 = (in.nbr_flags ? in.nbr_flags : any8)[in.nbr_flags ? S.nrow : 0];
+  const uint8_t sf1 = (in.src_flags ? in.src_flags : any8)[in.src_flags ? row : 0];
+  const float* s_ovl = in.src_flags ? in.src_overlay : in.src_table;
+  const float ta_ = in.src_table[row * D + lane], tb_ = in.src_table[row * D + cb];
+  const float oa_ = s_ovl[row * D + lane], ob_ = s_ovl[row * D + cb];
+  const float pts1 = (side.persist_memory ? side.persist_msg_ts : blob)[side.persist_memory ? row : 0];
+  const bool st_do = st_q && st_w && st_id >= 0;
+  constexpr int MME = DE ? ME : 1;      // (a run-time edge width keeps message_store_wave's own loads: MAXE registers spill)
+  float m_lu = 0.f, m_sa = 0.f, m_sb = 0.f, m_da = 0.f, m_db = 0.f, m_e[MME];
+#pragma unroll
+  for (int i = 0; i < MME; ++i) m_e[i] = 0.f;
+  if (DE != 0 && st_on) {    // launch-uniform; a wave without a message to store reads the rows of node 0
+    const int64_t idc = st_do ? st_id : 0, pac = st_do ? st_partner : 0, ec = st_do ? st_eidx : 0;
+    m_lu = side.store_last_update[idc];
+    m_sa = side.store_memory[idc * D + lane]; m_sb = side.store_memory[idc * D + cb];
+    m_da = side.store_memory[pac * D + lane]; m_db = side.store_memory[pac * D + cb];
+#pragma unroll
+    for (int i = 0; i < MME; ++i) {
+      const int c = lane + 64 * i;
+      m_e[i] = in.edge_table[ec * d_e + (c < d_e ? c : 0)];
+    }
+  }
+  if (in.nbr_flags && slot) S.ovl = nf1 ? 1 : 0;
   // source row [src(100) | src_time(100)] of query m = wave and the merger's copy of src
   float sa = 0.f, sb = 0.f, sta = 0.f, stb = 0.f;
   if (live_q) {
-    const int64_t row = in.src_idx ? (int64_t)in.src_idx[q] : q;
-    const int cb = c1 < D ? c1 : 0;               // (column c1 is stored only where c1 < D)
-    bool from_overlay = false;
-    if (in.src_flags) {
-      // the flag and BOTH candidate rows are requested together and blended bit-wise afterwards: flag -> table -> row is
-      // one dependent round trip more on the critical path of this stage
-      const unsigned m = in.src_flags[row] ? ~0u : 0u;
-      const float ta_ = in.src_table[row * D + lane], tb_ = in.src_table[row * D + cb];
-      const float oa_ = in.src_overlay[row * D + lane], ob_ = in.src_overlay[row * D + cb];
-      sa = __uint_as_float((__float_as_uint(oa_) & m) | (__float_as_uint(ta_) & ~m));
-      sb = __uint_as_float((__float_as_uint(ob_) & m) | (__float_as_uint(tb_) & ~m));
-      from_overlay = m != 0u;
-    } else {
-      sa = in.src_table[row * D + lane];
-      sb = in.src_table[row * D + cb];
-    }
-    if (side.persist_memory && q < side.persist_n && from_overlay) {   // fused memory persist (common.h)
+    const unsigned m = (in.src_flags && sf1) ? ~0u : 0u;
+    sa = __uint_as_float((__float_as_uint(oa_) & m) | (__float_as_uint(ta_) & ~m));
+    sb = __uint_as_float((__float_as_uint(ob_) & m) | (__float_as_uint(tb_) & ~m));
+    if (side.persist_memory && q < side.persist_n && m != 0u) {   // fused memory persist (common.h)
       side.persist_memory[row * D + lane] = sa;
       if (c1 < D) side.persist_memory[row * D + c1] = sb;
-      if (lane == 0) side.persist_last_update[row] = side.persist_msg_ts[row];
+      if (lane == 0) side.persist_last_update[row] = pts1;
     }
     if (side.src_rows_out) {
       side.src_rows_out[q * D + lane] = sa;
@@ -842,14 +873,14 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     if constexpr (qk) {
       // the source's time encoding is a constant already inside the folded map: nothing to compute
     } else if (in.dt) {    // embedding_module.py:126: the source's own time encoding is cos(0*w + b)
-      sta = orca_cosf(orca_time_arg(0.0f, in.time_w[lane], in.time_b[lane]));
-      stb = c1 < D ? orca_cosf(orca_time_arg(0.0f, in.time_w[c1], in.time_b[c1])) : 0.f;
+      sta = orca_cosf(orca_time_arg(0.0f, tw_a, tb_a));
+      stb = c1 < D ? orca_cosf(orca_time_arg(0.0f, tw_b, tb_b)) : 0.f;
     } else {
       sta = in.src_time[q * D + lane];
       stb = c1 < D ? in.src_time[q * D + c1] : 0.f;
     }
   }
-  // touch every 128-B line of the K neighbour and edge rows now (one dword per line, two VGPRs held):
+  // level 3: touch every 128-B line of the K neighbour and edge rows now (one dword per line, two VGPRs held):
   // the lines travel HBM -> L2 while the projection phases run, and the row loads of P3 then hit L2
   float touch0 = 0.f, touch1 = 0.f;
   if (live_q) {
@@ -868,18 +899,44 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       }
     }
   }
-  // (the store's own loads and stores ride along with the gathers of this stage)
-  if (q < 2 * side.store_bs && side.store_winner[q]) {   // fused raw-message store of position q (common.h)
-    const int64_t bs = side.store_bs;
-    const int64_t id = side.store_nodes[q], partner = side.store_nodes[q < bs ? q + bs : q - bs];
-    if (id >= 0)
-      message_store_wave(id, partner, side.store_eidx[q < bs ? q : q - bs], side.store_ts[q], side.store_memory,
-                         side.store_last_update, in.edge_table, d_e, in.time_w, in.time_b, side.store_messages,
-                         side.store_msg_ts, side.store_pending, lane);
+  // the message itself (model/tgn_model.py:172-191 + modules/memory.py:25-28, as message_store_wave builds it), while
+  // the touches are in flight
+  if (DE == 0 && st_do) {
+    message_store_wave(st_id, st_partner, st_eidx, st_t, side.store_memory, side.store_last_update, in.edge_table, d_e,
+                       in.time_w, in.time_b, side.store_messages, side.store_msg_ts, side.store_pending, lane);
+  } else if (st_do) {
+    float* mrow = side.store_messages + st_id * (3 * D + d_e);
+    const float tf = (float)st_t;
+    const float delta = tf - m_lu;
+    mrow[lane] = m_sa;
+    mrow[D + lane] = m_da;
+    mrow[2 * D + d_e + lane] = orca_cosf(orca_time_arg(delta, tw_a, tb_a));
+    if (c1 < D) {
+      mrow[c1] = m_sb;
+      mrow[D + c1] = m_db;
+      mrow[2 * D + d_e + c1] = orca_cosf(orca_time_arg(delta, tw_b, tb_b));
+    }
+#pragma unroll
+    for (int i = 0; i < MME; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d_e) mrow[2 * D + c] = m_e[i];
+    }
+    if (lane == 0) {
+      side.store_msg_ts[st_id] = tf;
+      side.store_pending[st_id] = 1;
+    }
   }
+  // The first weights of the next GEMM stage are requested HERE, behind the gathers of this stage and ahead of its
+  // cosines: loads return in order, so 144 KB of weights requested at kernel entry stood between every dependent
+  // level of the gathers above and its consumer.
+  if constexpr (qk)
+    g2.prefetch(blob4 + (L.pw_qk + (int64_t)h2 * pw_floats(kdim + 1, D)) / 4, NT100, wave >> 1, NW / 2, L.NTk, lane,
+                blob + L.b_qk + h2 * KPS);
+  else
+    g1.prefetch(blob4 + L.pw_q / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_q);
   // the time encodings of slots 0..KC-1 need only dt: all VALU, computed while the loads above are in flight
   KeyTimes T;
-  if (live_q) encode_key_times(T, in, S, 0, K, lane);
+  if (live_q) encode_key_times(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b);
   {
     const int m = wave;
     bufQ[m * ASTR + lane] = sa;
@@ -987,7 +1044,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       sc[0] = scores();
       if (K > KC) {
         load_key_rows(R, T, in, S, q, KC, K, d_e, lane);
-        encode_key_times(T, in, S, KC, K, lane);
+        encode_key_times(T, in, S, KC, K, lane, tw_a, tb_a, tw_b, tb_b);
         sc[1] = scores();
       } else {
         sc[1] = 0.f;
@@ -1056,7 +1113,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       if (K > KC) {          // the registers hold slots KC..K-1: use them, then fetch slots 0..KC-1 again (L2 hits)
         accumulate(a_c1);
         load_key_rows(R, T, in, S, q, 0, K, d_e, lane);
-        encode_key_times(T, in, S, 0, K, lane);
+        encode_key_times(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b);
       }
       accumulate(a_c0);
       xb0[lane] = an0; xb1[lane] = an1;
@@ -1100,6 +1157,10 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   }
   WaveGemm<1, 7, 7, true> g7;
   g7.prefetch(blob4 + L.pw_2 / 4, NT100, wave < NT100 ? wave : -1, NW, NT100, lane, blob + L.b_2);
+  // LayerNorm affine parameters (P8), requested with the fc2 weights (at kernel entry they were one more round trip -- and
+  // a spilled register -- ahead of the gathers)
+  const float ln_ga = blob[L.ln_w + lane], ln_ba = blob[L.ln_b + lane];
+  const float ln_gb = blob[c1 < D ? L.ln_w + c1 : L.ln_w], ln_bb = blob[c1 < D ? L.ln_b + c1 : L.ln_b];
   __syncthreads();
   stamp();
   for (int e = tid; e < TQ * 112; e += NW * 64) {
