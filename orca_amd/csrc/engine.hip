@@ -17,7 +17,6 @@
 #include "common.h"
 #include "sampler.h"
 #include "gru_split.h"
-#include "worklist.h"
 
 struct orca_engine {
   orca_engine_desc d;
@@ -888,18 +887,22 @@ struct budget_csr {
   orca_fences fences;
 };
 
-// First kernel of the native Path C step, two block roles:
-//  blocks 0 .. ne_m-1 : last-occurrence election of the raw-message list [src;dst] in LDS (tgn_model.py:174-176) -> a winner
-//                       byte per position; block 0 first reduces *tmax = max t and zeroes the two words of the uncached count
+// First kernel of the native Path C step, three block roles:
+//  (GRU role)         : the eager overlay of the ids the previous step stored, as in k_begin_queries (blocks ahead of all others)
+//  ne_m blocks        : last-occurrence election of the raw-message list [src;dst] in LDS (tgn_model.py:174-176) -> a winner
+//                       byte per position, and this step's list of distinct stored ids; the first of them also reduces
+//                       *tmax = max t and zeroes the two words of the uncached count
 //  the others         : 16 waves = 16 root queries: root i of [src;dst;neg] x [t;t;t] (tgn_model.py:99-102) is written to
 //                       nodes / qts / nodes32, stamped into `slot` (the batch-membership test of find_uncached,
 //                       embedding_module.py:200-212) and its K neighbours are sampled -- into row i of the step's sampler
 //                       buffers (the first 3*bs rows of the layer-1 launch) and of the caller's top-level copies (the keys
 //                       of layer 2)
+template <int GRU_MSG>
 __global__ __launch_bounds__(ELECT_THREADS) void k_budget_begin(
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
     int32_t* __restrict__ nodes32, double* __restrict__ tmax, int32_t* __restrict__ unc_count, uint8_t* __restrict__ win_msg,
+    int32_t* __restrict__ msg_list, int32_t* __restrict__ msg_count, begin_gru gru,
     int ne_m, int64_t n_nodes, budget_csr csr, int K, int64_t* __restrict__ stamp, int64_t stamp_epoch,
     int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid, float* __restrict__ o_et, float* __restrict__ o_dt,
     int32_t* __restrict__ t_nbr, int32_t* __restrict__ t_eid, float* __restrict__ t_et, float* __restrict__ t_dt) {
@@ -908,8 +911,16 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_budget_begin(
     const int64_t* a = i < bs ? src : (i < 2 * bs ? dst - bs : neg - 2 * bs);
     return a[i];
   };
-  if ((int)blockIdx.x < ne_m) {
-    if (blockIdx.x == 0) {
+  constexpr bool WITH_GRU = GRU_MSG != 0;
+  if (WITH_GRU && (int)blockIdx.x < gru.n_blocks) {     // the eager overlay, as in k_begin_queries
+    gru_split_workgroup<WITH_GRU ? GRU_MSG : 3 * ORCA_D + 172, 2, 1, GRU_SUBS>(gru.blob, gru.ids, gru.n_max, gru.n_dev, gru.x, gru.h, gru.out, nullptr,
+                                                          nullptr, (int)blockIdx.x * GRU_SUBS, gru.n_wg,
+                                                          reinterpret_cast<f32x4 (*)[1][3][64]>(tab), nullptr);
+    return;
+  }
+  const int blk0 = (int)blockIdx.x - gru.n_blocks;
+  if (blk0 < ne_m) {
+    if (blk0 == 0) {
       double* red = reinterpret_cast<double*>(tab);
       double m = -1.0e300;
       for (int64_t i = threadIdx.x; i < bs; i += ELECT_THREADS) { const double t = ts[i]; m = t > m ? t : m; }
@@ -923,11 +934,11 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_budget_begin(
       }
       __syncthreads();
     }
-    elect_in_lds(tab, tab + ELECT_SLOTS, 2 * bs, n_nodes, root, win_msg, (int)blockIdx.x, ne_m, nullptr, nullptr);
+    elect_in_lds(tab, tab + ELECT_SLOTS, 2 * bs, n_nodes, root, win_msg, blk0, ne_m, msg_list, msg_count);
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)((int)blockIdx.x - ne_m) * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
+  const int64_t i = (int64_t)(blk0 - ne_m) * (ELECT_THREADS / 64) + (threadIdx.x >> 6);
   if (i >= 3 * bs) return;
   const int64_t e = i < bs ? i : (i < 2 * bs ? i - bs : i - 2 * bs);
   const int64_t v = root(i);
@@ -1039,34 +1050,31 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_budget_expand(
                      o_dt, nullptr, a.claim, lane);
 }
 
-// Third: the append pass of the work-list over [neighbours (Qc*K) ; evaluated nodes (Qc)] (train order) and, with the slot
-// cache, the history pull of layer 2 (history.py:32-36) as an index translation -- the attention launch gathers
-// rows[pull_idx[i]] exactly as it gathered hist[nbr[i]].
-__global__ __launch_bounds__(1024) void k_budget_append(int n_app, const int32_t* __restrict__ ids32, int64_t n32,
-                                                         const int64_t* __restrict__ ids64, int64_t n64,
-                                                         const uint8_t* __restrict__ flags, const int64_t* __restrict__ slot,
-                                                         int64_t epoch, int64_t n_nodes, int32_t* worklist, int32_t* count,
-                                                         slot_view sv, const int32_t* __restrict__ nbr_top, int64_t n_top,
-                                                         int32_t* __restrict__ pull_idx) {
-  __shared__ int wave_n[16];
-  __shared__ int block_base;
-  if ((int)blockIdx.x < n_app) {
-    worklist_append_block(ids32, n32, ids64, n64, flags, slot, epoch, n_nodes, worklist, count, blockIdx.x, wave_n, &block_base);
-    return;
-  }
-  const int64_t i = (int64_t)((int)blockIdx.x - n_app) * 1024 + threadIdx.x;
-  if (i >= n_top) return;
-  const int64_t v = nbr_top[i];
-  pull_idx[i] = (v >= 0 && v < n_nodes) ? (int32_t)slot_row(sv.stamp[v], sv) : 0;
-}
-
 // update_flag (history.py:25-30: the flags become exactly the plan) and what it implies for the rows: entry i of the plan
 // takes row i of the plan region this step writes -- copied from wherever the id's row is now (the batch region if it was
 // evaluated in this step, the other plan region if the previous plan kept it, the zero row otherwise), 16 lanes a row --
 // and the id is stamped (kind 1, this generation), flagged and remembered in prev_plan.
-__global__ __launch_bounds__(256) void k_slot_keep(const int64_t* __restrict__ plan, int64_t plan_n, int64_t n_nodes, slot_view sv,
-                                                   int64_t next_base, float* __restrict__ rows, int64_t* __restrict__ prev_plan,
-                                                   uint8_t* __restrict__ cache_flag) {
+// The blocks behind the n_keep plan blocks translate the history pull of layer 2 (history.py:32-36) into row numbers -- the
+// attention launch gathers rows[pull_idx[i]] exactly as it gathered hist[nbr[i]].  The two roles race on the stamps of the
+// ids the plan keeps, harmlessly: such a neighbour resolves to its old row or to its copy in the region being written,
+// and by the time layer 2 runs both hold the same values.
+__global__ __launch_bounds__(256) void k_slot_keep(int n_keep, const int64_t* __restrict__ plan, int64_t plan_n, int64_t n_nodes,
+                                                   slot_view sv, int64_t next_base, float* __restrict__ rows,
+                                                   int64_t* __restrict__ prev_plan, uint8_t* __restrict__ cache_flag,
+                                                   const int32_t* __restrict__ nbr_top, int64_t n_top,
+                                                   int32_t* __restrict__ pull_idx) {
+  if ((int)blockIdx.x >= n_keep) {
+    const int64_t i = (int64_t)((int)blockIdx.x - n_keep) * 256 + threadIdx.x;
+    if (i >= n_top) return;
+    const int64_t v = nbr_top[i];
+    int64_t r = 0;
+    if (v >= 0 && v < n_nodes) {
+      const int64_t val = __hip_atomic_load(&sv.stamp[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      r = ((val & STAMP_KIND) && (val >> STAMP_SHIFT) == sv.gen) ? next_base + (val & STAMP_INDEX) : slot_row(val, sv);
+    }
+    pull_idx[i] = (int32_t)r;
+    return;
+  }
   const int sub = threadIdx.x & 15;
   const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   if (i >= plan_n) return;
@@ -1182,12 +1190,44 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
     next_base = 1 + (int64_t)(c.cur ^ 1) * c.plan_cap;
     comb = c.rows + sv.batch_base * ORCA_D;        // layer 1 writes the batch region: the push moves nothing
   }
+  // Eager overlay, as in orca_engine_begin: while `overlay_complete` holds, GRU(message, memory) of a pending id is
+  // computed once, right after its message is stored -- by the next step's first kernel, over the list this step's
+  // message election emits -- and no batch needs a work-list of the ids it reads.
+  e->cur ^= 1;
+  const bool lists = d.eager_ids && d.eager_count;
+  int32_t* my_list = lists ? d.eager_ids + (int64_t)e->cur * d.q_max : nullptr;
+  int32_t* my_count = lists ? d.eager_count + e->cur : nullptr;
+  int32_t* next_count = lists ? d.eager_count + (e->cur ^ 1) : nullptr;     // consumed below: restarts at zero for the next step
+  begin_gru gru{};
+  if (e->have_list) {
+    e->have_list = false;
+    if (e->overlay_complete) {
+      const int32_t* ids = d.eager_ids + (int64_t)(e->cur ^ 1) * d.q_max;
+      const int64_t tiles = ceil_div64(e->list_bound, 16);
+      if ((d.d_e == 172 || d.d_e == 1) && e->fuse_gru && tiles <= GRU_SPLIT_TILES) {
+        gru.n_wg = (int)tiles * GRU_NWG;
+        gru.n_blocks = (int)ceil_div64(gru.n_wg, GRU_SUBS);
+        gru.blob = d.gru_blob; gru.ids = ids; gru.n_max = e->list_bound; gru.n_dev = d.eager_count + (e->cur ^ 1);
+        gru.x = d.messages; gru.h = d.memory; gru.out = d.overlay;
+      } else {
+        STEP(orca_gru_update(d.gru_blob, 3 * ORCA_D + d.d_e, ids, e->list_bound, d.eager_count + (e->cur ^ 1), d.messages,
+                             d.memory, d.overlay, nullptr, nullptr, stream_));
+      }
+    }
+  }
+  const bool lazy = train && !e->overlay_complete;      // the per-batch work-list of the ids layer 1 reads
   // 1. roots, their neighbours (the layer-2 keys), batch stamps; the message election rides along (tgn_model.py:99-102,174-176)
   const int64_t stamp_epoch = take_epochs(e, 1);
-  k_budget_begin<<<(unsigned)(parts_m + ceil_div64(Q, ELECT_THREADS / 64)), ELECT_THREADS, 0, s>>>(
-      src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32, tmax, unc_count, win_msg, parts_m, d.n_nodes, csr, K, d.slot, stamp_epoch,
-      d.nbr, d.eid, d.et, d.dt, nbr_top, eid_top, et_top, dt_top);
-  ORCA_LAUNCH_CHECK();
+  {
+    const unsigned grid = (unsigned)(gru.n_blocks + parts_m + ceil_div64(Q, ELECT_THREADS / 64));
+#define BEGIN_ARGS src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32, tmax, unc_count, win_msg, my_list, my_count, gru, parts_m, \
+                   d.n_nodes, csr, K, d.slot, stamp_epoch, d.nbr, d.eid, d.et, d.dt, nbr_top, eid_top, et_top, dt_top
+    if (gru.n_blocks && d.d_e == 1) k_budget_begin<3 * ORCA_D + 1><<<grid, ELECT_THREADS, 0, s>>>(BEGIN_ARGS);
+    else if (gru.n_blocks) k_budget_begin<3 * ORCA_D + 172><<<grid, ELECT_THREADS, 0, s>>>(BEGIN_ARGS);
+    else k_budget_begin<0><<<grid, ELECT_THREADS, 0, s>>>(BEGIN_ARGS);
+#undef BEGIN_ARGS
+    ORCA_LAUNCH_CHECK();
+  }
   // 2. which of those neighbours have no cached layer-1 embedding (:200-212, :251), and the evaluated set behind the roots
   STEP(orca_uncached_mark(nbr_top, Q * K, cache_flag, d.slot, stamp_epoch, d.n_nodes, bitmap, unc, cap, unc_count, stream_));
   STEP(orca_uncached_finish_nodes(unc, cap, unc_count, bitmap, d.n_nodes, Q, tmax, d.nodes, d.nodes32, d.qts, err, stream_));
@@ -1203,7 +1243,7 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
   }
   const int64_t cand = Qc * (K + 1);
   int64_t claim_epoch = 0;
-  if (train) {
+  if (lazy) {
     claim_epoch = take_epochs(e, cand);
     xa.nC = (int)ceil_div64(Q * K + Q, ELECT_THREADS);
     xa.claim = orca_claim{d.pending, d.slot, claim_epoch, d.n_nodes, d.count};
@@ -1217,19 +1257,13 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
   in.nbr_table = d.memory; in.nbr_idx = d.nbr; in.nbr_ids = d.nbr;
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
   in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b; in.q_folded = d.att_q_folded;
-  // 4. the work-list itself and the pulls of layer 2; updated memory of what layer 1 reads
-  if (train || slots) {
-    const int n_app = train ? (int)ceil_div64(cand, 1024) : 0;
-    k_budget_append<<<(unsigned)(n_app + (slots ? ceil_div64(Q * K, 1024) : 0)), 1024, 0, s>>>(
-        n_app, d.nbr, Qc * K, d.nodes, Qc, d.pending, d.slot, claim_epoch, d.n_nodes, d.worklist, d.count, sv, nbr_top, Q * K,
-        slots ? c.pull_idx : nullptr);
-    ORCA_LAUNCH_CHECK();
-  }
-  if (train) {
+  // 4. (no eager overlay) the work-list itself and GRU(message, memory) of what layer 1 reads
+  if (lazy) {
+    STEP(orca_worklist_append(d.nbr, Qc * K, d.nodes, Qc, d.pending, d.slot, claim_epoch, d.n_nodes, d.worklist, d.count, stream_));
     STEP(orca_gru_update(d.gru_blob, 300 + d.d_e, d.worklist, cand < d.n_nodes ? cand : d.n_nodes, d.count, d.messages, d.memory,
                          d.overlay, nullptr, nullptr, stream_));
-    in.src_overlay = d.overlay; in.src_flags = d.pending; in.nbr_overlay = d.overlay; in.nbr_flags = d.pending;
   }
+  if (train) { in.src_overlay = d.overlay; in.src_flags = d.pending; in.nbr_overlay = d.overlay; in.nbr_flags = d.pending; }
   // 5. layer 1 over [roots; uncached].  Train order: the overlay holds GRU(message, memory) of every pending positive (the
   // roots are part of the work-list), so the launch also commits those rows (memory_updater.py:25-39; the flags need no
   // clearing: the message store raises them for exactly these ids).  Dense table: it also pushes the winners' rows.
@@ -1237,6 +1271,7 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
     orca_tgat_side side{};
     side.q_extra = unc_count;
     side.q_base = Q;
+    side.zero_word = next_count;
     if (train) {
       side.persist_memory = d.memory; side.persist_last_update = d.last_update; side.persist_msg_ts = d.msg_ts;
       side.persist_n = 2 * bs;
@@ -1246,10 +1281,10 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
   }
   // 6. the cache flags move on (history.py:25-30)
   if (slots) {
-    if (plan_n > 0) {
-      k_slot_keep<<<(unsigned)ceil_div64(plan_n, 16), 256, 0, s>>>(plan, plan_n, d.n_nodes, sv, next_base, c.rows, c.prev_plan, cache_flag);
-      ORCA_LAUNCH_CHECK();
-    }
+    const int n_keep = (int)ceil_div64(plan_n, 16);
+    k_slot_keep<<<(unsigned)(n_keep + ceil_div64(Q * K, 256)), 256, 0, s>>>(n_keep, plan, plan_n, d.n_nodes, sv, next_base, c.rows, c.prev_plan,
+                                                                            cache_flag, nbr_top, Q * K, c.pull_idx);
+    ORCA_LAUNCH_CHECK();
   } else if (plan_n >= 0) {
     STEP(orca_fill_u8(cache_flag, d.n_nodes, 0, stream_));
     if (plan_n > 0) STEP(orca_set_flags(cache_flag, plan, nullptr, plan_n, nullptr, 1, d.n_nodes, stream_));
@@ -1295,7 +1330,14 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
     c.cur ^= 1;
     c.prev_n = plan_n;
   }
-  e->overlay_complete = false;      // messages were stored without their overlay rows
+  if (train) {      // the ids that now hold a fresh message: the election listed them for the next step's first kernel
+    if (lists) {
+      e->have_list = true;
+      e->list_bound = 2 * bs < d.q_max ? 2 * bs : d.q_max;
+    } else {
+      e->overlay_complete = false;
+    }
+  }
   return ORCA_OK;
 }
 

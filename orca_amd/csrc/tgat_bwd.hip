@@ -720,15 +720,27 @@ struct Slots {
   float dt;
   bool masked;
 };
+// (Two levels of loads, each issued as a whole and unconditionally -- an optional array that is absent is replaced by a
+// valid address and its value discarded, lanes past K load slot 0: written with an `if` per optional input every load
+// was waited for where it was issued, five dependent round trips instead of two.)
 __device__ __forceinline__ Slots load_slots(const orca_tgat_inputs& in, int64_t q, int K, int lane) {
+  const int64_t p = q * K + (lane < K ? lane : 0);
+  const int32_t* any32 = reinterpret_cast<const int32_t*>(in.edge_table);
+  const uint8_t* any8 = reinterpret_cast<const uint8_t*>(in.edge_table);
+  const int nr = (in.nbr_idx ? in.nbr_idx : any32)[in.nbr_idx ? p : 0];
+  const int er = (in.edge_idx ? in.edge_idx : any32)[in.edge_idx ? p : 0];
+  const int id = (in.nbr_ids ? in.nbr_ids : any32)[in.nbr_ids ? p : 0];
+  const uint8_t mk = (in.nbr_ids ? any8 : in.mask)[in.nbr_ids ? 0 : p];
+  const float dt = (in.dt ? in.dt : in.edge_table)[in.dt ? p : 0];
   Slots S{0, 0, 0, 0.f, true};
+  const int nrow = in.nbr_idx ? nr : (int)p;
+  const uint8_t fl = (in.nbr_flags ? in.nbr_flags : any8)[in.nbr_flags ? nrow : 0];
   if (lane < K) {
-    const int64_t p = q * K + lane;
-    S.nrow = in.nbr_idx ? in.nbr_idx[p] : (int)p;
-    S.erow = in.edge_idx ? in.edge_idx[p] : (int)p;
-    S.masked = in.nbr_ids ? (in.nbr_ids[p] == 0) : (in.mask[p] != 0);
-    if (in.dt) S.dt = in.dt[p];
-    if (in.nbr_flags) S.ovl = in.nbr_flags[S.nrow] ? 1 : 0;
+    S.nrow = nrow;
+    S.erow = in.edge_idx ? er : (int)p;
+    S.masked = in.nbr_ids ? (id == 0) : (mk != 0);
+    if (in.dt) S.dt = dt;
+    if (in.nbr_flags) S.ovl = fl ? 1 : 0;
   }
   return S;
 }

@@ -574,7 +574,7 @@ class OrcaEngine:
                                     int(plan.numel()) if plan is not None else -1, ptr(self.cache_flag[0]), ptr(self._bitmap),
                                     ptr(b["unc"]), cap, ptr(b["cnt"]), ptr(b["tmax"]), ptr(b["nbr"]), ptr(b["eid"]), ptr(b["et"]),
                                     ptr(b["dt"]), ptr(out), ptr(b["err"]), stream()), "orca_engine_step_budget")
-    self._overlay_complete = False
+    self._overlay_complete = bool(L.orca_engine_get_overlay_complete(self._native))
     # the overflow word travels to pinned host memory behind the step (no synchronisation here): whoever looks next
     # -- the next native step, check_errors() -- raises if it was set
     if getattr(self, "_berr_host", None) is None:
