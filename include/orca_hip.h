@@ -577,9 +577,14 @@ int orca_build_roots(const int64_t* src, const int64_t* dst, const int64_t* neg,
  * over [roots; uncached] (a launch sized for 3*bs + cap queries that evaluates 3*bs + *unc_count of them) -> history
  * push, cache flags (history.py:25-30: the plan's ids when plan_n >= 0, else every evaluated id) -> layer 2 over the
  * roots -> memory persist + raw-message store (tgn_model.py:127-145, order by `train`).  out [3*bs, ORCA_D].  Uses the
- * tables and work buffers of the engine's descriptor (3*bs + cap <= q_max); cache_flag uint8 [n_nodes]; bitmap as in
- * orca_find_uncached; unc_count device int [2] (word 0 = the count, word 1 scratch); tmax device double [1].  More uncached ids than `cap` set bit 1 of *err (device int, may be
- * NULL): the step then evaluated only the first `cap` of them. */
+ * tables and work buffers of the engine's descriptor (3*bs + cap <= q_max; `winners` is required, `eager_ids` /
+ * `eager_count` enable the eager overlay below); the history is hist[0] or, when one is set, the slot cache above.
+ * cache_flag uint8 [n_nodes]; bitmap as in orca_find_uncached; unc_count device int [2] (word 0 = the count, word 1
+ * scratch); tmax device double [1].  More uncached ids than `cap` set bit 1 of *err (device int, may be NULL): the step then
+ * evaluated only the first `cap` of them.  Train order follows the eager-overlay protocol of orca_engine_begin (below): while
+ * the state is overlay-complete the step applies the GRU to the ids the previous step stored and builds no work-list;
+ * otherwise it builds the work-list of the ids layer 1 reads.  The memory persist rides in the layer-1 attention launch
+ * and the message store in the layer-2 launch; evaluation order runs them, and the positives' GRU, after the embedding. */
 int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* neg,
                             const double* ts, const int64_t* eidx, int64_t bs, int train, const int64_t* plan,
                             int64_t plan_n, uint8_t* cache_flag, uint32_t* bitmap, int64_t* unc, int64_t cap,
