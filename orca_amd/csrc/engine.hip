@@ -33,6 +33,7 @@ struct orca_engine {
   int64_t per;                 // owner-computes step: interactions per rank of the current batch = ceil(bs / world)
   int64_t epoch_push, epoch_msg;   // owner-computes step: the election values begin() claimed on slot / slot_m
   int fuse_gru;                // 1: the eager GRU rides in the first kernel (env ORCA_FUSE_GRU=0 keeps it a launch of its own)
+  int gru_subs;                // 0: 4-wave GRU groups per block of that kernel chosen per launch (gru_subs_for); env ORCA_GRU_SUBS=1|2|4 pins it
   int sampling;                // ORCA_SAMPLE_*
   uint64_t seed;               // uniform sampling: seed of the next step
   bool store_done;             // the raw-message store of the batch was fused into the last attention layer
@@ -215,7 +216,16 @@ struct begin_sample {
 // longest chain of the launch): GRU(message, memory) -> overlay for the ids the previous step stored.  It shares no
 // data with the other roles (they touch the batch, the CSR and the other half of the list buffers), and both are
 // latency-bound launches that leave most of the chip idle: side by side they cost the longer of the two.
-constexpr int GRU_SUBS = ELECT_THREADS / (GRU_KW * 64);       // 4-wave GRU groups per block
+constexpr int GRU_SUBS_MAX = ELECT_THREADS / (GRU_KW * 64);   // 4-wave GRU groups a block can hold
+// Groups per block (SUBS) is a launch-time choice.  Every wave of a CU shares its four matrix pipes, so four groups in one
+// block take four times as long over their chains as one group alone.  A launch whose blocks all fit on the chip at once
+// (the reference's batch size: 175 groups + 40 other blocks on 256 CUs) gives every group a block of its own -- twelve of
+// its sixteen waves return at once: 17.9 -> 9.6 us for the kernel, 70 -> 61 us per step at BASELINE config 2's shape.  The
+// bench's batches (1,197 groups for the bound of 2,730 rows, 392 of them with rows, + 252 other blocks) take two to a
+// block: 16.1 -> 13.9 us (one: 17.0 -- the sampler's blocks queue behind the GRU's; four: 16.1).
+__host__ inline int gru_subs_for(int groups, int other_blocks) {
+  return groups + other_blocks <= 256 ? 1 : groups / 2 + other_blocks <= 1024 ? 2 : GRU_SUBS_MAX;
+}
 struct begin_gru {
   int n_blocks, n_wg;
   const float* blob;
@@ -227,7 +237,7 @@ struct begin_gru {
 };
 // GRU_MSG: the message width of the GRU role (472 = the 172-d datasets, 301 = the zero-feature ones; 0 = no GRU role:
 // it raises the register count of the whole kernel, and the plain variant keeps its occupancy)
-template <int GRU_MSG>
+template <int GRU_MSG, int SUBS>
 __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
@@ -244,9 +254,10 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
   };
   constexpr bool WITH_GRU = GRU_MSG != 0;
   if (WITH_GRU && (int)blockIdx.x < gru.n_blocks) {
-    static_assert(sizeof(tab) >= sizeof(f32x4) * GRU_SUBS * (GRU_KW - 1) * 3 * 64, "GRU partial sums must fit the election tables");
-    gru_split_workgroup<WITH_GRU ? GRU_MSG : 3 * ORCA_D + 172, 2, 1, GRU_SUBS>(gru.blob, gru.ids, gru.n_max, gru.n_dev, gru.x, gru.h, gru.out, nullptr,
-                                                          nullptr, (int)blockIdx.x * GRU_SUBS, gru.n_wg,
+    static_assert(sizeof(tab) >= sizeof(f32x4) * GRU_SUBS_MAX * (GRU_KW - 1) * 3 * 64, "GRU partial sums must fit the election tables");
+    if ((int)threadIdx.x >= SUBS * GRU_KW * 64) return;       // (waves that leave do not count at the group's barriers)
+    gru_split_workgroup<WITH_GRU ? GRU_MSG : 3 * ORCA_D + 172, 2, 1, SUBS>(gru.blob, gru.ids, gru.n_max, gru.n_dev, gru.x, gru.h, gru.out, nullptr,
+                                                          nullptr, (int)blockIdx.x * SUBS, gru.n_wg,
                                                           reinterpret_cast<f32x4 (*)[1][3][64]>(tab), nullptr);
     return;
   }
@@ -502,6 +513,8 @@ ORCA_API int orca_engine_create(const orca_engine_desc* desc, orca_engine_t** ou
   {
     const char* v = getenv("ORCA_FUSE_GRU");
     e->fuse_gru = !(v && v[0] == '0');
+    const char* g = getenv("ORCA_GRU_SUBS");      // A/B switch of the profiles
+    e->gru_subs = (g && (g[0] == '1' || g[0] == '2' || g[0] == '4') && !g[1]) ? g[0] - '0' : 0;
   }
   e->sc = orca_slot_cache{};
   e->eidx = nullptr;
@@ -683,8 +696,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
       const int64_t tiles = ceil_div64(e->list_bound, 16);
       if ((d.d_e == 172 || d.d_e == 1) && e->fuse_gru && !e->timed_step && tiles <= GRU_SPLIT_TILES) {
         // a role of the first kernel (begin_gru): every tile has its GRU_NWG groups, so a group loops at most once
-        gru.n_wg = (int)tiles * GRU_NWG;
-        gru.n_blocks = (int)ceil_div64(gru.n_wg, GRU_SUBS);
+        gru.n_wg = (int)tiles * GRU_NWG;      // (n_blocks: at the launch, when the other roles' blocks are known)
         gru.blob = d.gru_blob; gru.ids = ids; gru.n_max = e->list_bound; gru.n_dev = d.eager_count + (e->cur ^ 1);
         gru.x = d.messages; gru.h = d.memory; gru.out = d.overlay;
       } else {
@@ -726,18 +738,16 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     begin_sample smp{e->sampling, e->seed, {}};
     if ((rc = orca_csr_fences(d.csr, &smp.fences)) != ORCA_OK) return rc;
     Timed t(e, ORCA_PROF_SAMPLE, stream);
-    if (gru.n_blocks && d.d_e == 1)
-      ORCA_LAUNCH_TIMED(k_begin_queries<3 * ORCA_D + 1>, (unsigned)(gru.n_blocks + nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
-                        bs, d.nodes, d.qts, d.nodes32, gru, el, nbs, d.n_nodes,
-                        indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
-    else if (gru.n_blocks)
-      ORCA_LAUNCH_TIMED(k_begin_queries<3 * ORCA_D + 172>, (unsigned)(gru.n_blocks + nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
-                        bs, d.nodes, d.qts, d.nodes32, gru, el, nbs, d.n_nodes,
-                        indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
-    else
-      ORCA_LAUNCH_TIMED(k_begin_queries<0>, (unsigned)(nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts,
-                        bs, d.nodes, d.qts, d.nodes32, gru, el, nbs, d.n_nodes,
-                        indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim);
+    const int subs = gru.n_wg ? (e->gru_subs ? e->gru_subs : gru_subs_for(gru.n_wg, nb + el.ne)) : 1;
+    gru.n_blocks = gru.n_wg ? (int)ceil_div64(gru.n_wg, subs) : 0;
+#define BEGIN_LAUNCH(MSG, SUBS) \
+      ORCA_LAUNCH_TIMED((k_begin_queries<MSG, SUBS>), (unsigned)(gru.n_blocks + nb + el.ne), ELECT_THREADS, 0, stream, src, dst, neg, ts, \
+                        bs, d.nodes, d.qts, d.nodes32, gru, el, nbs, d.n_nodes, \
+                        indptr, c_nbr, c_eid, c_ts, n_rows, lo, hi, e->sharded ? 1 : 0, K, smp, d.nbr, d.eid, d.et, d.dt, claim)
+    if (!gru.n_wg) BEGIN_LAUNCH(0, 1);
+    else if (d.d_e == 1) { if (subs == 1) BEGIN_LAUNCH(3 * ORCA_D + 1, 1); else if (subs == 2) BEGIN_LAUNCH(3 * ORCA_D + 1, 2); else BEGIN_LAUNCH(3 * ORCA_D + 1, 4); }
+    else { if (subs == 1) BEGIN_LAUNCH(3 * ORCA_D + 172, 1); else if (subs == 2) BEGIN_LAUNCH(3 * ORCA_D + 172, 2); else BEGIN_LAUNCH(3 * ORCA_D + 172, 4); }
+#undef BEGIN_LAUNCH
     ORCA_LAUNCH_CHECK();
   }
   // the other half of the list buffers (consumed above) is the next step's: its counter restarts at zero
@@ -897,7 +907,7 @@ struct budget_csr {
 //                       embedding_module.py:200-212) and its K neighbours are sampled -- into row i of the step's sampler
 //                       buffers (the first 3*bs rows of the layer-1 launch) and of the caller's top-level copies (the keys
 //                       of layer 2)
-template <int GRU_MSG>
+template <int GRU_MSG, int SUBS>
 __global__ __launch_bounds__(ELECT_THREADS) void k_budget_begin(
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
     const double* __restrict__ ts, int64_t bs, int64_t* __restrict__ nodes, double* __restrict__ qts,
@@ -913,8 +923,9 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_budget_begin(
   };
   constexpr bool WITH_GRU = GRU_MSG != 0;
   if (WITH_GRU && (int)blockIdx.x < gru.n_blocks) {     // the eager overlay, as in k_begin_queries
-    gru_split_workgroup<WITH_GRU ? GRU_MSG : 3 * ORCA_D + 172, 2, 1, GRU_SUBS>(gru.blob, gru.ids, gru.n_max, gru.n_dev, gru.x, gru.h, gru.out, nullptr,
-                                                          nullptr, (int)blockIdx.x * GRU_SUBS, gru.n_wg,
+    if ((int)threadIdx.x >= SUBS * GRU_KW * 64) return;
+    gru_split_workgroup<WITH_GRU ? GRU_MSG : 3 * ORCA_D + 172, 2, 1, SUBS>(gru.blob, gru.ids, gru.n_max, gru.n_dev, gru.x, gru.h, gru.out, nullptr,
+                                                          nullptr, (int)blockIdx.x * SUBS, gru.n_wg,
                                                           reinterpret_cast<f32x4 (*)[1][3][64]>(tab), nullptr);
     return;
   }
@@ -1206,7 +1217,6 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
       const int64_t tiles = ceil_div64(e->list_bound, 16);
       if ((d.d_e == 172 || d.d_e == 1) && e->fuse_gru && tiles <= GRU_SPLIT_TILES) {
         gru.n_wg = (int)tiles * GRU_NWG;
-        gru.n_blocks = (int)ceil_div64(gru.n_wg, GRU_SUBS);
         gru.blob = d.gru_blob; gru.ids = ids; gru.n_max = e->list_bound; gru.n_dev = d.eager_count + (e->cur ^ 1);
         gru.x = d.messages; gru.h = d.memory; gru.out = d.overlay;
       } else {
@@ -1219,13 +1229,17 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
   // 1. roots, their neighbours (the layer-2 keys), batch stamps; the message election rides along (tgn_model.py:99-102,174-176)
   const int64_t stamp_epoch = take_epochs(e, 1);
   {
-    const unsigned grid = (unsigned)(gru.n_blocks + parts_m + ceil_div64(Q, ELECT_THREADS / 64));
-#define BEGIN_ARGS src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32, tmax, unc_count, win_msg, my_list, my_count, gru, parts_m, \
-                   d.n_nodes, csr, K, d.slot, stamp_epoch, d.nbr, d.eid, d.et, d.dt, nbr_top, eid_top, et_top, dt_top
-    if (gru.n_blocks && d.d_e == 1) k_budget_begin<3 * ORCA_D + 1><<<grid, ELECT_THREADS, 0, s>>>(BEGIN_ARGS);
-    else if (gru.n_blocks) k_budget_begin<3 * ORCA_D + 172><<<grid, ELECT_THREADS, 0, s>>>(BEGIN_ARGS);
-    else k_budget_begin<0><<<grid, ELECT_THREADS, 0, s>>>(BEGIN_ARGS);
-#undef BEGIN_ARGS
+    const int other = parts_m + (int)ceil_div64(Q, ELECT_THREADS / 64);
+    const int subs = gru.n_wg ? (e->gru_subs ? e->gru_subs : gru_subs_for(gru.n_wg, other)) : 1;
+    gru.n_blocks = gru.n_wg ? (int)ceil_div64(gru.n_wg, subs) : 0;
+    const unsigned grid = (unsigned)(gru.n_blocks + other);
+#define BEGIN_LAUNCH(MSG, SUBS) k_budget_begin<MSG, SUBS><<<grid, ELECT_THREADS, 0, s>>>( \
+        src, dst, neg, ts, bs, d.nodes, d.qts, d.nodes32, tmax, unc_count, win_msg, my_list, my_count, gru, parts_m, d.n_nodes, csr, K, \
+        d.slot, stamp_epoch, d.nbr, d.eid, d.et, d.dt, nbr_top, eid_top, et_top, dt_top)
+    if (!gru.n_wg) BEGIN_LAUNCH(0, 1);
+    else if (d.d_e == 1) { if (subs == 1) BEGIN_LAUNCH(3 * ORCA_D + 1, 1); else if (subs == 2) BEGIN_LAUNCH(3 * ORCA_D + 1, 2); else BEGIN_LAUNCH(3 * ORCA_D + 1, 4); }
+    else { if (subs == 1) BEGIN_LAUNCH(3 * ORCA_D + 172, 1); else if (subs == 2) BEGIN_LAUNCH(3 * ORCA_D + 172, 2); else BEGIN_LAUNCH(3 * ORCA_D + 172, 4); }
+#undef BEGIN_LAUNCH
     ORCA_LAUNCH_CHECK();
   }
   // 2. which of those neighbours have no cached layer-1 embedding (:200-212, :251), and the evaluated set behind the roots
