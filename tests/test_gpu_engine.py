@@ -300,6 +300,47 @@ def test_native_driver_long_run_vs_dispatched_path():
       assert torch.equal(native.msg_ts, plain.msg_ts)
 
 
+@pytest.mark.parametrize("d_e", [172, 1])
+def test_eager_gru_groups_per_block(monkeypatch, d_e):
+  """The eager GRU rides in the step's first kernel as 4-wave groups, one, two or four to a 1024-thread block -- chosen
+  per launch from the block count (engine.hip, gru_subs_for) -- or runs as a launch of its own (ORCA_FUSE_GRU=0).  All
+  four forms are the same arithmetic: embeddings and every state table bit for bit, over train batches with an
+  evaluation batch in between, for both message widths (472 and the zero-feature datasets' 301)."""
+  from orca_amd import ops, synth
+  from orca_amd.engine import OrcaEngine
+  N, E, bs, K = 20_000, 600_000, 700, 10
+  src, dst, eidx, ts = synth.powerlaw_graph(N, E, "cuda:0", seed=12)
+  ef = synth.edge_features(E, d_e, "cuda:0", zero=d_e == 1)
+  sd = synth.tgn_state_dict(d_e, 2, seed=6)
+  csr = ops.CSR.from_edges_device(src, dst, eidx, ts, N + 1)
+  start = int(0.5 * E)
+
+  def run(env):
+    for k in ("ORCA_FUSE_GRU", "ORCA_GRU_SUBS"):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    eng = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=0, device="cuda:0")      # (the handle reads the switches)
+    eng.set_neighbor_finder(csr)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(1)
+    outs = []
+    for b in range(7):
+      s = start + b * bs
+      neg = torch.randint(1, N + 1, (bs,), generator=g, device="cuda:0")
+      outs.append(eng.compute_temporal_embeddings(src[s:s + bs], dst[s:s + bs], neg, ts[s:s + bs], eidx[s:s + bs], b != 4))
+    eng.check_errors()
+    return outs, [t.clone() for t in (eng.memory, eng.last_update, eng.messages, eng.msg_ts, eng.pending, eng.hist[0])]
+
+  ref_out, ref_tabs = run({"ORCA_FUSE_GRU": "0"})
+  for subs in ("1", "2", "4"):
+    out, tabs = run({"ORCA_GRU_SUBS": subs})
+    for b, (x, y) in enumerate(zip(out, ref_out)):
+      assert torch.equal(x, y), f"{subs} groups per block: embeddings of batch {b}"
+    for i, (x, y) in enumerate(zip(tabs, ref_tabs)):
+      assert torch.equal(x, y), f"{subs} groups per block: state table {i}"
+
+
 @pytest.mark.parametrize("native", [True, False])
 def test_uniform_k20_engine_vs_oracle(golden, native):
   """BASELINE config 5's sampler in the step driver: K = 20 seeded-uniform neighbours (not in the reference:
