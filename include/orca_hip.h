@@ -157,6 +157,13 @@ typedef struct {
   float dropout_p;
   uint64_t dropout_seed;
   int64_t dropout_q0;
+  /* Launch shape.  0 or 1: one wavefront per query, 16 queries per workgroup -- the form for batches that fill the chip.
+   * 4: four wavefronts share a query (each takes every fourth neighbour slot through the per-query stages; the parts meet
+   * in LDS) and a workgroup holds 4 queries: for launches of <= ~1000 queries (the reference's batch size of 200
+   * interactions), where one workgroup's latency is what the launch costs.  Honoured for K = 10, d_e = 172 or 1, a folded q
+   * and the plain forward (not orca_tgat_forward_saving); ignored otherwise.  Same function; the sums over the slots are
+   * taken in another order, so results agree with the one-wave form to rounding, not to the bit. */
+  int32_t waves_per_query;
 } orca_tgat_inputs;
 /* mult[q][h][j] (float [Q, ORCA_HEADS, K]) = 0 or 1 / (1 - p): the dropout multipliers orca_tgat_forward /
  * orca_tgat_backward apply for (seed, q0) */
@@ -414,7 +421,11 @@ int orca_adam_step(int n, float* const* params, const float* const* grads, float
 typedef struct orca_engine orca_engine_t;
 typedef struct {
   int64_t n_nodes;                 /* rows of the state tables (args.n_nodes, train.py:129) */
-  int32_t n_layers, K, d_e, reserved;
+  int32_t n_layers, K, d_e;
+  int32_t small_batch;             /* nonzero: attention launches of <= 1024 queries take the four-waves-per-query form
+                                      (orca_tgat_inputs.waves_per_query = 4): faster at the reference's batch size, equal to
+                                      the default form to rounding, not to the bit.  One rank only (an N-rank run is held
+                                      bit-equal to one rank in the default form) */
   const orca_csr_t* csr;           /* may be NULL here and set later (orca_engine_set_csr) */
   const float* edge_feats;         /* [n_edges+1, d_e] */
   const float* time_w;             /* [ORCA_D] time_encoder.w.weight */

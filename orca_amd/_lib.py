@@ -24,7 +24,8 @@ class TgatInputs(ctypes.Structure):
       "nbr_table", "nbr_idx", "nbr_overlay", "nbr_flags",
       "nbr_ids", "mask", "edge_table", "edge_idx",
       "dt", "time_w", "time_b", "src_time", "nbr_time")] + [("q_folded", ctypes.c_int32), ("dropout_p", ctypes.c_float),
-                                                                     ("dropout_seed", ctypes.c_uint64), ("dropout_q0", ctypes.c_int64)]
+                                                                     ("dropout_seed", ctypes.c_uint64), ("dropout_q0", ctypes.c_int64),
+                                                                     ("waves_per_query", ctypes.c_int32)]
 
 
 class TgatParams(ctypes.Structure):
@@ -45,7 +46,7 @@ class SlotCache(ctypes.Structure):
 class EngineDesc(ctypes.Structure):
   """orca_engine_desc (include/orca_hip.h)."""
   _fields_ = ([("n_nodes", i64), ("n_layers", ctypes.c_int32), ("K", ctypes.c_int32), ("d_e", ctypes.c_int32),
-               ("reserved", ctypes.c_int32), ("csr", vp), ("edge_feats", vp), ("time_w", vp), ("time_b", vp),
+               ("small_batch", ctypes.c_int32), ("csr", vp), ("edge_feats", vp), ("time_w", vp), ("time_b", vp),
                ("att_blob", vp * ORCA_ENGINE_MAX_LAYERS), ("gru_blob", vp), ("memory", vp), ("last_update", vp),
                ("messages", vp), ("msg_ts", vp), ("pending", vp), ("overlay", vp),
                ("hist", vp * (ORCA_ENGINE_MAX_LAYERS - 1)), ("slot", vp), ("worklist", vp), ("count", vp),

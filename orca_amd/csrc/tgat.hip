@@ -635,13 +635,15 @@ struct QuerySlots {   // lane j (< K) describes neighbour slot j of this wave's 
 };
 
 // Issues the global loads of slots j0 .. j0+KC-1 (all in flight at once; nothing here waits on them).
+// own: bit j set = this wave handles slot j0 + j (all ones for a wave that has its query to itself; with several waves per
+// query each takes every NQW-th slot and the others' registers stay zero)
 template <int ME>
 __device__ __forceinline__ void load_key_rows(KeyRows<ME>& R, KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S,
-                                              int64_t q, int j0, int K, int d_e, int lane) {
+                                              int64_t q, int j0, int K, int d_e, int lane, unsigned own = ~0u) {
   const int c1 = lane + 64;
 #pragma unroll
   for (int j = 0; j < KC; ++j) {
-    if (j0 + j < K) {   // wave-uniform
+    if (j0 + j < K && ((own >> j) & 1u)) {   // wave-uniform
       const int nr = __builtin_amdgcn_readlane(S.nrow, j0 + j);
       const int er = __builtin_amdgcn_readlane(S.erow, j0 + j);
       const int ov = __builtin_amdgcn_readlane(S.ovl, j0 + j);
@@ -675,11 +677,11 @@ __device__ __forceinline__ void load_key_rows(KeyRows<ME>& R, KeyTimes& T, const
 // (wa, ba / wb, bb: time_w, time_b of this lane's columns lane and lane + 64 -- lanes past the width carry the values of
 // column 0 and compute a surplus value: no lane-conditional code)
 __device__ __forceinline__ void encode_key_times(KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S, int j0,
-                                                 int K, int lane, float wa, float ba, float wb, float bb) {
+                                                 int K, int lane, float wa, float ba, float wb, float bb, unsigned own = ~0u) {
   if (!in.dt) return;
 #pragma unroll
   for (int j = 0; j < KC; ++j) {
-    if (j0 + j < K) {
+    if (j0 + j < K && ((own >> j) & 1u)) {
       const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.dt), j0 + j));
       T.ta[j] = orca_cosf(orca_time_arg(d, wa, ba));
       T.tb[j] = orca_cosf(orca_time_arg(d, wb, bb));
@@ -739,7 +741,14 @@ __device__ __forceinline__ float half_sum(float v) {
 // the second-chunk code fold away) or 0 = run-time K <= ORCA_MAX_K.
 // DE = compile-time edge width (172, the Wikipedia / Reddit / benchmark width: every k-block count of the
 // projection chains becomes a constant) or 0 = run-time d_e <= ORCA_MAX_DE.
-template <int KT, int DE, bool QK>
+// NQW = waves per query.  1: a wave has its query to itself and the workgroup holds TQ = 16 queries -- the form for a batch
+// that fills the chip (one workgroup per CU at 4095 queries).  4: the workgroup holds 4 queries (still one MFMA M-tile in
+// the GEMM stages: twelve of its rows idle), and the four waves of a query split its K slots in the per-query stages
+// (time encodings, key rows, scores, weighted sums; partial results meet in LDS) -- the form for the reference's own batch
+// size, where 600 queries are 38 workgroups on 256 CUs and what a step costs is ONE workgroup's latency: the per-query
+// stages are a quarter as long, and four times as many CUs stream the weights.  K <= KC, gather mode with a folded q, no
+// saving of intermediates; sums over the slots are taken in another order than NQW = 1 (same bars, not the same bits).
+template <int KT, int DE, bool QK, int NQW = 1>
 __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restrict__ blob, int d_e_rt,
                                                           orca_tgat_inputs in, int64_t Q, int K_rt,
                                                           float* __restrict__ out, float* __restrict__ out_w,
@@ -756,7 +765,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   if (side.q_extra) {               // block-uniform, ahead of every barrier
     const int64_t lim = side.q_base + *side.q_extra;
     Q = lim < Q ? lim : Q;
-    if ((int64_t)blockIdx.x * TQ >= Q) return;
+    if ((int64_t)blockIdx.x * (TQ / NQW) >= Q) return;
   }
   if (side.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *side.zero_word = 0;
   const int K = KT ? KT : K_rt;
@@ -777,7 +786,15 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;                      // wave m owns query q0 + m in the per-query stages
-  const int64_t q0 = (int64_t)blockIdx.x * TQ;
+  constexpr int TQW = TQ / NQW;                    // queries of this workgroup
+  static_assert(NQW == 1 || (KT != 0 && KT <= KC && QK), "several waves per query: compile-time K <= KC, folded q");
+  const int64_t q0 = (int64_t)blockIdx.x * TQW;
+  const int qm = wave / NQW;                       // this wave's query (row of the M-tile) ...
+  const int qr = __builtin_amdgcn_readfirstlane(wave % NQW);     // ... and its part of the slots: qr, qr + NQW, ... (a scalar)
+  const bool lead = qr == 0;                       // the wave that does what is done once per query
+  constexpr int NSL = (KC + NQW - 1) / NQW;        // slots of a wave when several share a query
+  // LDS row this wave fills in the staging stage: its query's row, or (not the lead) one of the idle rows, with zeros
+  const int lrow = lead ? qm : TQW + wave - qm - 1;
   const f32x4* blob4 = reinterpret_cast<const f32x4*>(blob);
   const int c1 = lane + 64;
   const int a_off = (lane & 15), a_k = 4 * (lane >> 4);
@@ -795,7 +812,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   // on those values, then the row touches -- and unconditionally: an optional array that is absent is replaced by a valid
   // address (the weight blob) and its value discarded, dead waves and lanes load clamped positions.  Written with an `if`
   // per optional input, every load was waited for where it was issued: ten serial round trips instead of three.
-  const int64_t q = q0 + wave;
+  const int64_t q = q0 + qm;
   const bool live_q = q < Q;
   const int64_t qc = live_q ? q : Q - 1;
   const bool slot = live_q && lane < K;
@@ -815,7 +832,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   const float tw_a = twp[lane], tb_a = tbp[lane], tw_b = twp[cb], tb_b = tbp[cb];
   // (fused raw-message store of position q, common.h: its batch arrays are read with the slots)
   const int64_t st_bs = side.store_bs;
-  const bool st_on = st_bs > 0, st_q = st_on && q < 2 * st_bs;
+  const bool st_on = st_bs > 0, st_q = st_on && lead && q < 2 * st_bs;
   const int64_t sq = st_q ? q : 0, sp = st_q ? (q < st_bs ? q + st_bs : q - st_bs) : 0, se = st_q ? (q < st_bs ? q : q - st_bs) : 0;
   const int64_t* st_nodes = st_on ? side.store_nodes : reinterpret_cast<const int64_t*>(blob);
   const uint8_t st_w = (st_on ? side.store_winner : any8)[sq];
@@ -861,12 +878,12 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     const unsigned m = (in.src_flags && sf1) ? ~0u : 0u;
     sa = __uint_as_float((__float_as_uint(oa_) & m) | (__float_as_uint(ta_) & ~m));
     sb = __uint_as_float((__float_as_uint(ob_) & m) | (__float_as_uint(tb_) & ~m));
-    if (side.persist_memory && q < side.persist_n && m != 0u) {   // fused memory persist (common.h)
+    if (lead && side.persist_memory && q < side.persist_n && m != 0u) {   // fused memory persist (common.h)
       side.persist_memory[row * D + lane] = sa;
       if (c1 < D) side.persist_memory[row * D + c1] = sb;
       if (lane == 0) side.persist_last_update[row] = pts1;
     }
-    if (side.src_rows_out) {
+    if (lead && side.src_rows_out) {
       side.src_rows_out[q * D + lane] = sa;
       if (c1 < D) side.src_rows_out[q * D + c1] = sb;
     }
@@ -889,9 +906,10 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int idx = lane + 64 * r;
-      if (idx < total) {
-        const int j = idx / per, ln = idx - j * per;
-        const int nr = __shfl(S.nrow, j, 64), er = __shfl(S.erow, j, 64), ov = __shfl(S.ovl, j, 64);
+      const int j = idx < total ? idx / per : 0, ln = idx - j * per;
+      // (every lane takes part in the shuffles: a pulled-from lane must be active)
+      const int nr = __shfl(S.nrow, j, 64), er = __shfl(S.erow, j, 64), ov = __shfl(S.ovl, j, 64);
+      if (idx < total && j % NQW == qr) {
         const float* p = ln < nl ? (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D + ln * 32
                                  : in.edge_table + (int64_t)er * d_e + (ln - nl) * 32;
         const float v = *p;
@@ -936,9 +954,24 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     g1.prefetch(blob4 + L.pw_q / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_q);
   // the time encodings of slots 0..KC-1 need only dt: all VALU, computed while the loads above are in flight
   KeyTimes T;
-  if (live_q) encode_key_times(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b);
+  float lta[NSL], ltb[NSL];                      // (several waves per query: the encodings of this wave's slots)
+  if constexpr (NQW == 1) {
+    if (live_q) encode_key_times(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b);
+  } else {
+#pragma unroll
+    for (int jl = 0; jl < NSL; ++jl) {
+      const int j = qr + NQW * jl;
+      lta[jl] = ltb[jl] = 0.f;
+      if (live_q && j < K) {
+        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.dt), j));
+        lta[jl] = orca_cosf(orca_time_arg(d, tw_a, tb_a));
+        ltb[jl] = orca_cosf(orca_time_arg(d, tw_b, tb_b));
+      }
+    }
+  }
+  if (!lead) { sa = sb = sta = stb = 0.f; }       // (an idle row of the M-tile)
   {
-    const int m = wave;
+    const int m = lrow;
     bufQ[m * ASTR + lane] = sa;
     bufQ[m * ASTR + D + lane] = sta;
     float* trow = bufT + m * RS + 2 * KPS;        // the merger's copy of src, behind the two x-bar blocks
@@ -977,6 +1010,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
 
   // ---- P3: this wave's query: scores, masked softmax, weighted key sum ---------------------------
   asm volatile("" ::"v"(touch0), "v"(touch1));   // the touches are complete (and kept) up to here
+  if constexpr (NQW == 1)
   {
     const int m = wave;
     float* xb0 = bufT + m * RS;
@@ -1134,6 +1168,159 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       }
     }
   }
+  else {
+    // Several waves per query: each takes its slots through the same arithmetic as above -- key rows, time encodings,
+    // scores, weighted sums -- and the parts meet in LDS twice: the scores before the softmax (every wave of the query
+    // then computes the same weights), the partial weighted sums after it (the lead wave adds them in wave order).
+    float* xb0 = bufT + qm * RS;
+    float* xb1 = xb0 + KPS;
+    float* xpart = bufT + TQ * RS;                    // [TQ waves][2 * KPS] partial x-bar rows
+    float* scx = xpart + TQ * 2 * KPS;                // [TQW][2][KC] scores
+    const int tb = D + d_e;
+    const int hs = held_slot(lane);
+    float lna[NSL], lnb[NSL], le[NSL][ME];
+    unsigned long long livebits = 1ull;
+    bool invalid = false;
+    if (live_q) {
+#pragma unroll
+      for (int jl = 0; jl < NSL; ++jl) {
+        const int j = qr + NQW * jl;
+        lna[jl] = lnb[jl] = 0.f;
+#pragma unroll
+        for (int i = 0; i < ME; ++i) le[jl][i] = 0.f;
+        if (j < K) {      // wave-uniform; clamped columns as in load_key_rows
+          const int nr = __builtin_amdgcn_readlane(S.nrow, j), er = __builtin_amdgcn_readlane(S.erow, j);
+          const int ov = __builtin_amdgcn_readlane(S.ovl, j);
+          const float* np = (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D;
+          const float* ep = in.edge_table + (int64_t)er * d_e;
+          lna[jl] = np[lane];
+          lnb[jl] = np[c1 < D ? c1 : 0];
+#pragma unroll
+          for (int i = 0; i < ME; ++i) {
+            const int c = lane + 64 * i;
+            le[jl][i] = ep[c < d_e ? c : 0];
+          }
+        }
+      }
+      livebits = __ballot(lane < K && !S.masked);
+      invalid = livebits == 0ull;                                        // temporal_attention.py:46
+      if (invalid) livebits = 1ull;                                      // :47 un-masks slot 0
+      const float qn0a = xb0[lane], qn1a = xb1[lane];
+      const float qn0b = c1 < D ? xb0[c1] : 0.f, qn1b = c1 < D ? xb1[c1] : 0.f;
+      float qe0[ME], qe1[ME];
+#pragma unroll
+      for (int i = 0; i < ME; ++i) {
+        const int c = lane + 64 * i;
+        qe0[i] = c < d_e ? xb0[D + c] : 0.f;
+        qe1[i] = c < d_e ? xb1[D + c] : 0.f;
+      }
+      const float qt0a = xb0[tb + lane], qt1a = xb1[tb + lane];
+      const float qt0b = c1 < D ? xb0[tb + c1] : 0.f, qt1b = c1 < D ? xb1[tb + c1] : 0.f;
+      const float off = (lane & 32) ? xb1[kdim] : xb0[kdim];
+      // this lane's partial dot products of the wave's slots, placed at their slots of the 2 x KC reduction
+      float l0[NSL], l1[NSL];
+#pragma unroll
+      for (int jl = 0; jl < NSL; ++jl) {
+        l0[jl] = lna[jl] * qn0a + lnb[jl] * qn0b + lta[jl] * qt0a + ltb[jl] * qt0b;
+        l1[jl] = lna[jl] * qn1a + lnb[jl] * qn1b + lta[jl] * qt1a + ltb[jl] * qt1b;
+#pragma unroll
+        for (int i = 0; i < ME; ++i) {
+          l0[jl] += le[jl][i] * qe0[i];
+          l1[jl] += le[jl][i] * qe1[i];
+        }
+      }
+      float p0[KC], p1[KC];
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        p0[j] = 0.f; p1[j] = 0.f;
+#pragma unroll
+        for (int jl = 0; jl < NSL; ++jl)
+          if (j == qr + NQW * jl) { p0[j] = l0[jl]; p1[j] = l1[jl]; }     // (uniform)
+      }
+      const float sc_own = reduce_2xKC(p0, p1, lane) + off;
+      if (hs >= 0 && !(lane & 1) && hs % NQW == qr) scx[(qm * 2 + (lane >> 5)) * KC + hs] = sc_own;
+    }
+    __syncthreads();            // (also: every wave of the query has read q~ before the lead overwrites the row below)
+    float an0 = 0.f, an1 = 0.f, bn0 = 0.f, bn1 = 0.f, at0 = 0.f, at1 = 0.f, bt0 = 0.f, bt1 = 0.f;
+    float ae0[ME], ae1[ME];
+#pragma unroll
+    for (int i = 0; i < ME; ++i) { ae0[i] = 0.f; ae1[i] = 0.f; }
+    float wsum = 0.f;
+    if (live_q) {
+      const float sc0 = scx[(qm * 2 + (lane >> 5)) * KC + (hs < 0 ? 0 : hs)];
+      // masked softmax per head = per 32-lane half; every real slot sits in two lanes of its half
+      const bool lv0 = hs >= 0 && ((livebits >> hs) & 1ull);
+      const float mx = half_max(lv0 ? sc0 : -INFINITY);
+      const float e0 = lv0 ? expf(sc0 - mx) : 0.f;
+      const float inv = invalid ? 0.f : 1.0f / (half_sum(e0) * 0.5f);
+      float a_c0 = e0 * inv;
+      wsum = invalid ? 0.f : 1.f;
+      if (in.dropout_p > 0.f) {
+        const float sc_ = 1.0f / (1.0f - in.dropout_p);
+        a_c0 *= orca_dropout_mult(in.dropout_seed, in.dropout_q0 + q, lane >> 5, hs < 0 ? 0 : hs, in.dropout_p, sc_);
+        wsum = half_sum(a_c0) * 0.5f;
+      }
+      if (out_w) {                                                       // :51-53 (head average); wave-uniform
+        const int jj = lane < K ? lane : 0;
+        int hl = 0;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) hl = (jj == j) ? holder_lane(0, j) : hl;
+        const float w0 = __shfl(a_c0, hl, 64), w1 = __shfl(a_c0, hl + 32, 64);
+        if (lead && lane < K) out_w[q * K + lane] = invalid ? 0.f : (w0 + w1) * 0.5f;
+      }
+      // this wave's slots: the weight of slot j sits in lanes holder_lane(h, j) -- picked by a chain of uniform selects
+#pragma unroll
+      for (int jl = 0; jl < NSL; ++jl) {
+        float w0 = 0.f, w1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+          if (j == qr + NQW * jl) {
+            w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_c0), holder_lane(0, j)));
+            w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_c0), holder_lane(1, j)));
+          }
+        }
+        an0 += w0 * lna[jl]; an1 += w1 * lna[jl]; bn0 += w0 * lnb[jl]; bn1 += w1 * lnb[jl];
+        at0 += w0 * lta[jl]; at1 += w1 * lta[jl]; bt0 += w0 * ltb[jl]; bt1 += w1 * ltb[jl];
+#pragma unroll
+        for (int i = 0; i < ME; ++i) { ae0[i] += w0 * le[jl][i]; ae1[i] += w1 * le[jl][i]; }
+      }
+    }
+    {
+      float* xp0 = xpart + wave * 2 * KPS;
+      float* xp1 = xp0 + KPS;
+      xp0[lane] = an0; xp1[lane] = an1;
+      if (c1 < D) { xp0[c1] = bn0; xp1[c1] = bn1; }
+#pragma unroll
+      for (int i = 0; i < ME; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d_e) { xp0[D + c] = ae0[i]; xp1[D + c] = ae1[i]; }
+      }
+      xp0[tb + lane] = at0; xp1[tb + lane] = at1;
+      if (c1 < D) { xp0[tb + c1] = bt0; xp1[tb + c1] = bt1; }
+    }
+    __syncthreads();
+    if (lead) {
+      const float* xs = xpart + (qm * NQW) * 2 * KPS;
+      auto total = [&](int col) {
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < NQW; ++r) { v0 += xs[r * 2 * KPS + col]; v1 += xs[r * 2 * KPS + KPS + col]; }
+        xb0[col] = v0; xb1[col] = v1;
+      };
+      total(lane);
+      if (c1 < D) total(c1);
+#pragma unroll
+      for (int i = 0; i < ME; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d_e) total(D + c);
+      }
+      total(tb + lane);
+      if (c1 < D) total(tb + c1);
+      // constant columns of the tail: each head's value-bias term times its weight sum, the out-projection bias once
+      const float ws1 = __shfl(wsum, 32, 64);
+      if (lane == 0) { xb0[kdim] = wsum; xb1[kdim] = ws1; xb0[2 * KPS + D] = (invalid || !live_q) ? 0.f : 1.f; }
+    }
+  }
   // ---- P4: h1 = relu(F [x-bar_0 | x-bar_1 | src] + b1), F = the folded value map / out-proj / fc1 ----------
   // 7 n-tiles x KBT k-blocks cut into 16 equal-cost pieces, 4 per SIMD: waves 0..11 take half the reduction of
   // tiles 0..5, waves 12..15 a quarter of tile 6.  Partial tiles meet in LDS (the q / 0.1q buffers are dead by
@@ -1181,8 +1368,8 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   stamp();
 
   // ---- P8: LayerNorm(100), eps 1e-5, biased variance (:55): wave m normalises query m ------------
-  if (live_q) {
-    const int m = wave;
+  if (live_q && lead) {
+    const int m = qm;
     float ya = bufQ[m * ASTR + lane];
     float yb = c1 < D ? bufQ[m * ASTR + c1] : 0.f;
     float mean = wave_sum(ya + yb) * (1.0f / D);
@@ -1275,14 +1462,28 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
                          (const void*)k_tgat_forward<10, 0, false>,   (const void*)k_tgat_forward<10, 0, true>,
                          (const void*)k_tgat_forward<0, 0, false>,    (const void*)k_tgat_forward<0, 0, true>,
                          (const void*)k_tgat_forward<10, 1, false>,   (const void*)k_tgat_forward<10, 1, true>,
-                         (const void*)k_tgat_forward<20, 1, false>,   (const void*)k_tgat_forward<20, 1, true>};
+                         (const void*)k_tgat_forward<20, 1, false>,   (const void*)k_tgat_forward<20, 1, true>,
+                         (const void*)k_tgat_forward<10, 172, true, 4>, (const void*)k_tgat_forward<10, 1, true, 4>};
     for (const void* f : fns) ORCA_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
   ORCA_REQUIRE(lds_bytes <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds_bytes);
   ORCA_REQUIRE(!in->q_folded || in->dt, "orca_tgat_forward: q_folded needs gather-mode time inputs (dt)");
   ORCA_REQUIRE(in->dropout_p >= 0.f && in->dropout_p < 1.f, "orca_tgat_forward: dropout_p=%g outside [0,1)", (double)in->dropout_p);
-  const unsigned grid = (unsigned)ceil_div64(Q, TQ);
   hipStream_t st = (hipStream_t)stream;
+  if (in->waves_per_query == 4 && K == 10 && (d_e == 172 || d_e == 1) && in->q_folded && !side.save_qt) {
+    const size_t lds4 = lds_bytes + (size_t)(TQ * 2 * L.KP + TQ * 2 * KC) * sizeof(float);     // partial x-bar rows, scores
+    ORCA_REQUIRE(lds4 <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds4);
+    const unsigned grid4 = (unsigned)ceil_div64(Q, TQ / 4);
+    if (d_e == 172)
+      ORCA_LAUNCH_TIMED((k_tgat_forward<10, 172, true, 4>), grid4, NW * 64, lds4, st, blob, d_e, *in, Q, K, out, out_weights, side,
+                        g_phase_clock);
+    else
+      ORCA_LAUNCH_TIMED((k_tgat_forward<10, 1, true, 4>), grid4, NW * 64, lds4, st, blob, d_e, *in, Q, K, out, out_weights, side,
+                        g_phase_clock);
+    ORCA_LAUNCH_CHECK();
+    return ORCA_OK;
+  }
+  const unsigned grid = (unsigned)ceil_div64(Q, TQ);
 #define ORCA_TGAT_LAUNCH(KT_, DE_)                                                                              \
   do {                                                                                                          \
     if (in->q_folded)                                                                                           \

@@ -36,14 +36,14 @@ D = ORCA_D
 class OrcaEngine:
   def __init__(self, state_dict, edge_feats, n_nodes, n_layers, n_neighbors, reuse=False, budget=0,
                device="cuda:0", group=None, sampling="recent", seed=0, exchange_cap=None, pretend=None, dropout=0.0,
-               gradient=False, slot_history=None):
+               gradient=False, slot_history=None, small_batch=None):
     """state_dict: the TGN state_dict of the reference (key names of SURVEY §8b); edge_feats
     [n_edges+1, d_e] (row 0 = padding); n_nodes = number of table rows (args.n_nodes, train.py:129).
     sampling: "recent" (the reference's NeighborFinder) or "uniform" (seeded, not in the reference: BASELINE
     config 5) with `seed`.  exchange_cap: rows a rank can send per owner-computes step (default: 1.25 x its even
     share of the batch's positives + 256, at most all of them); a batch that gives one owner more raises at the
     next check_errors().  pretend=(rank, world): measurement aid (tools/slice_probe.py) -- behave as that rank of
-    a world with the exchanges stubbed out.  slot_history: Path C keeps its layer-1 history in a budget-bounded slot
+    a world with the exchanges stubbed out.  small_batch: attention launches of at most 1024 queries take four waves per query (default: with one rank; equal to the default form to rounding, not to the bit).  slot_history: Path C keeps its layer-1 history in a budget-bounded slot
     cache (budget + one batch of rows and an id -> slot index) instead of the dense [n_nodes, 100] table of
     modules/history.py:11 -- None = wherever the native Path C step runs (budget > 0, two layers, one rank); it needs
     cache plans of the planner (include/orca_hip.h, orca_slot_cache) and falls back to the dense table, materialised from
@@ -104,6 +104,11 @@ class OrcaEngine:
     self.overlay = torch.zeros(self.N, D, **f32)
     # modules/history.py:11-20
     nh = self.L - 1 if self.reuse else 0
+    # attention launches of <= 1024 queries in the four-waves-per-query form (orca_tgat_inputs.waves_per_query): on by default
+    # with one rank; an N-rank run is held bit-equal to one rank in the default form
+    self.small_batch = bool(self.world == 1 if small_batch is None else small_batch)
+    if self.small_batch and self.world > 1:
+      raise OrcaError("OrcaEngine: small_batch is a one-rank launch shape")
     self._slot_eligible = bool(self.reuse and self.budget > 0 and self.L == 2 and self.world == 1 and
                                (slot_history is None or slot_history))
     if slot_history and not self._slot_eligible:
@@ -454,6 +459,7 @@ class OrcaEngine:
         self.slot_m = torch.zeros(self.N, dtype=torch.int64, device=dev)
     d = _lib.EngineDesc()
     d.n_nodes, d.n_layers, d.K, d.d_e = self.N, self.L, K, self.d_e
+    d.small_batch = int(self.small_batch)
     d.csr = self.csr._h if self.csr is not None else None
     d.edge_feats, d.time_w, d.time_b = ptr(self.edge_feats), ptr(self.time_w), ptr(self.time_b)
     for i, b in enumerate(self.att_blobs):
@@ -750,12 +756,18 @@ class OrcaEngine:
     return dict(dropout_p=self.dropout, dropout_q0=int(q0),
                 dropout_seed=(self.seed * 0x2545F4914F6CDD1D + self.batch_counter * 0x9E3779B97F4A7C15 + layer) & 0xFFFFFFFFFFFFFFFF)
 
-  def _attend(self, layer, Q, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr_idx, from_memory, drop=None, save=None):
+  def _wpq(self, n):
+    """orca_tgat_inputs.waves_per_query of an attention launch of n queries: the rule of the native driver (engine.hip,
+    waves_per_query), so that the dispatched launches take the same form"""
+    return 4 if (self.small_batch and self.world == 1 and n <= 1024) else 0
+
+  def _attend(self, layer, Q, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr_idx, from_memory, drop=None, save=None,
+              shape_n=None):
     """embedding_module.py:318-329 (aggregate) fused with the gathers of :123,133,172-174 and the
-    time encodings of :126,132."""
+    time encodings of :126,132.  shape_n: the query count the launch shape is chosen for (default Q)."""
     kw = dict(src_table=src_table, src_idx=src_idx, nbr_table=nbr_table, nbr_idx=nbr_idx, nbr_ids=nbr,
               edge_table=self.edge_feats, edge_idx=eid, dt=dt, time_w=self.time_w, time_b=self.time_b,
-              q_folded=True)
+              q_folded=True, waves_per_query=0 if save is not None else self._wpq(Q if shape_n is None else shape_n))
     if from_memory and train:
       kw.update(src_overlay=self.overlay, src_flags=self.pending, nbr_overlay=self.overlay, nbr_flags=self.pending)
     if drop:
@@ -823,12 +835,13 @@ class OrcaEngine:
       self._bitmap = torch.zeros((self.N + 31) // 32, dtype=torch.int32, device=self.device)
     return ops.find_uncached(nbr, nodes, self.cache_flag[0], self.slot, self._slot_epoch(1), self._bitmap)
 
-  def _attend_partitioned(self, layer, n, nbr, eid, dt, train, src_table, src_idx, nbr_table, from_memory, drop=False):
+  def _attend_partitioned(self, layer, n, nbr, eid, dt, train, src_table, src_idx, nbr_table, from_memory, drop=False,
+                          shape_n=None):
     """_attend over this rank's contiguous share of the n queries, rows all-gathered back to [n, D].  drop: apply
     train_step's attention-weight dropout (keyed by the row's index among the n queries, whatever the slicing)."""
     if self.world == 1:
       return self._attend(layer, n, nbr, eid, dt, train, src_table, src_idx, nbr_table, nbr, from_memory,
-                          drop=self._dropout_kw(layer, 0) if drop else None)
+                          drop=self._dropout_kw(layer, 0) if drop else None, shape_n=shape_n)
     lo, hi, per = self._slice(n)
     if src_idx is None:                               # dense source rows: row q belongs to query q
       src_table = src_table[lo:hi]
@@ -841,7 +854,7 @@ class OrcaEngine:
   # Path C: embedding_module.py:215-285.  Its control flow depends on global sets (which neighbours are cached), so
   # every rank samples all the queries and derives the same sets; the attention evaluations -- the cost -- are cut
   # into per-rank query slices and their rows all-gathered.
-  def _embed_budget(self, nodes, ts, n_layers, cache_plan, train, rec=None):
+  def _embed_budget(self, nodes, ts, n_layers, cache_plan, train, rec=None, shape_n=None):
     """rec (train_step): a list that receives, innermost layer first, what the backward re-reads of every attention
     evaluation -- (layer, samples, source ids or rows, history table) -- and switches train_step's dropout on."""
     n = nodes.numel()
@@ -853,14 +866,16 @@ class OrcaEngine:
       if rec is not None:
         self._cnt_ready = self._fetch_count()
         rec.append((1, (nbr, eid, dt), (nodes, n32), None))
-      return self._attend_partitioned(1, n, nbr, eid, dt, train, self.memory, n32, self.memory, True, drop=rec is not None)
+      return self._attend_partitioned(1, n, nbr, eid, dt, train, self.memory, n32, self.memory, True, drop=rec is not None,
+                                      shape_n=shape_n)
     unc = self._find_uncached(nodes, nbr)             # :251
     if unc.numel():                                   # :253-260
       c_nodes = torch.cat([nodes, unc])
       c_ts = torch.cat([ts, ts.max().expand(unc.numel())])
     else:
       c_nodes, c_ts = nodes, ts
-    comb = self._embed_budget(c_nodes, c_ts, n_layers - 1, cache_plan, train, rec)   # :273
+    # (the inner launch takes the shape the native driver gives it: chosen for the roots plus a nominal 256 uncached nodes)
+    comb = self._embed_budget(c_nodes, c_ts, n_layers - 1, cache_plan, train, rec, shape_n=n + 256)   # :273
     h = self.hist[n_layers - 2]
     ops.history_push(h, comb, c_nodes, self.slot, self._slot_epoch(c_nodes.numel()))  # :186-197
     flag = self.cache_flag[n_layers - 2]

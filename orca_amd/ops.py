@@ -232,7 +232,7 @@ def tgat_pack_layers(sds, d_e, device, blobs=None, time_b=None):
 
 def tgat_forward(blob, d_e, Q, K, out=None, want_weights=False, save=None, **kw):
   """orca_tgat_forward.  kw: the fields of orca_tgat_inputs (tensors or None; q_folded: bool; dropout_p, dropout_seed,
-  dropout_q0: attention-weight dropout, off by default).  save: a one-element list that receives the buffer of
+  dropout_q0: attention-weight dropout, off by default; waves_per_query: the launch shape, 0 = the default).  save: a one-element list that receives the buffer of
   orca_tgat_forward_saving (what tgat_backward(saved=...) then does not recompute)."""
   inp, keep = _tgat_inputs(kw, "tgat_forward")
   dev = blob.device
@@ -268,6 +268,7 @@ def _tgat_inputs(kw, who):
   inp.dropout_p = float(kw.pop("dropout_p", 0.0) or 0.0)
   inp.dropout_seed = int(kw.pop("dropout_seed", 0) or 0) & 0xFFFFFFFFFFFFFFFF
   inp.dropout_q0 = int(kw.pop("dropout_q0", 0) or 0)
+  inp.waves_per_query = int(kw.pop("waves_per_query", 0) or 0)
   keep = []
   for name, ty in _lib.TgatInputs._fields_:
     if ty is not _lib.vp:

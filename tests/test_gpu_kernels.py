@@ -190,12 +190,13 @@ def test_pack_layers_equals_pack(ops, d_e, gather):
     assert same_bits(again[i], ops.tgat_pack(sds[i], d_e, DEV, time_b=tb)), f"re-packed layer {i}"
 
 
-@pytest.mark.parametrize("folded", [False, True])
-@pytest.mark.parametrize("d_e,K,Q", [(172, 10, 1000), (1, 10, 333), (172, 20, 130), (64, 7, 17)])
-def test_attention_gather_mode_vs_oracle(ops, golden, d_e, K, Q, folded):
+@pytest.mark.parametrize("folded,waves", [(False, 0), (True, 0), (True, 4)])
+@pytest.mark.parametrize("d_e,K,Q", [(172, 10, 1000), (1, 10, 333), (172, 20, 130), (64, 7, 17), (172, 10, 5), (1, 10, 2)])
+def test_attention_gather_mode_vs_oracle(ops, golden, d_e, K, Q, folded, waves):
   """The fused path: rows gathered by index, time encodings computed in-kernel, overlay rows.  folded: the blob
   completed by orca_tgat_pack_gather (q projection multiplied into the key map), with a non-zero time bias so
-  that the constant part of the fold is exercised."""
+  that the constant part of the fold is exercised.  waves = 4: the four-waves-per-query launch shape
+  (orca_tgat_inputs.waves_per_query; the shapes it is not built for must fall back to the default form)."""
   g = golden("attention.npz")
   tag = "de172_K10_"
   sd = {k[len(tag + "sd."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "sd.")}
@@ -222,7 +223,7 @@ def test_attention_gather_mode_vs_oracle(ops, golden, d_e, K, Q, folded):
   w_time = O.time_encode_weights(100)
   b_time = torch.from_numpy(rs.uniform(-3, 3, 100).astype(np.float32)) if folded else torch.zeros(100)
   blob = ops.tgat_pack(sd, d_e, DEV, time_b=b_time if folded else None)
-  out, w = ops.tgat_forward(blob, d_e, Q, K, want_weights=True, q_folded=folded,
+  out, w = ops.tgat_forward(blob, d_e, Q, K, want_weights=True, q_folded=folded, waves_per_query=waves,
                             src_table=_t(table), src_idx=_t(nodes), src_overlay=_t(overlay), src_flags=_t(flags),
                             nbr_table=_t(table), nbr_idx=_t(nbr), nbr_overlay=_t(overlay), nbr_flags=_t(flags),
                             nbr_ids=_t(nbr), edge_table=_t(edge_feats), edge_idx=_t(eid), dt=_t(dt),

@@ -56,9 +56,11 @@ def _worker(rank, world, port, q, full):
       s, e = 50000 + b * bs, 50000 + (b + 1) * bs
       return src[s:e], dst[s:e], torch.randint(1, N + 1, (bs,), generator=g, device=dev), ts[s:e], eidx[s:e]
 
+    # (small_batch=False on the one-rank engines: bit equality is between EQUAL launch shapes -- a rank's attention launches
+    # keep the one-wave-per-query form, which one rank alone would trade for the four-wave form at these batch sizes)
     for reuse in ((True, False) if full else (True,)):
       multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=reuse, device=dev, group=dist.group.WORLD)
-      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=reuse, device=dev, group=None)
+      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=reuse, device=dev, group=None, small_batch=False)
       multi.set_neighbor_finder(csr)
       single.set_neighbor_finder(csr)
       for b in range(9):
@@ -88,7 +90,7 @@ def _worker(rank, world, port, q, full):
     ef1 = torch.zeros(E + 1, 1, device=dev)
     sd3 = synth.tgn_state_dict(1, 3, seed=4)
     multi = OrcaEngine(sd3, ef1, N + 1, 3, 20, reuse=True, device=dev, group=dist.group.WORLD, sampling="uniform", seed=77)
-    single = OrcaEngine(sd3, ef1, N + 1, 3, 20, reuse=True, device=dev, group=None, sampling="uniform", seed=77)
+    single = OrcaEngine(sd3, ef1, N + 1, 3, 20, reuse=True, device=dev, group=None, small_batch=False, sampling="uniform", seed=77)
     multi.set_neighbor_finder(csr)
     single.set_neighbor_finder(csr)
     for b in range(4):
@@ -112,7 +114,7 @@ def _worker(rank, world, port, q, full):
     if full:
       # Path C (budgeted reuse with a cache plan per batch): global set algebra on every rank, attention partitioned
       multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=dist.group.WORLD)
-      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None, slot_history=False)   # (random plans)
+      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None, small_batch=False, slot_history=False)   # (random plans)
       multi.set_neighbor_finder(csr)
       single.set_neighbor_finder(csr)
       for b in range(3):
@@ -126,7 +128,7 @@ def _worker(rank, world, port, q, full):
       # differently from the single-rank step, so gradients are compared at 1e-5 and the state bit for bit.  Forward
       # steps in between switch the state between the owner-computes and the coherent form.
       multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, device=dev, group=dist.group.WORLD)
-      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, device=dev, group=None)
+      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, device=dev, group=None, small_batch=False)
       multi.set_neighbor_finder(csr)
       single.set_neighbor_finder(csr)
       for b in range(5):
@@ -148,7 +150,7 @@ def _worker(rank, world, port, q, full):
         ok = ok and torch.equal(multi.hist[0], single.hist[0])
       # the same for the budgeted reuse path (Path C): every rank back-propagates its slice of the roots
       multi = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=dist.group.WORLD)
-      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None, slot_history=False)   # (random plans)
+      single = OrcaEngine(sd, ef, N + 1, 2, K, reuse=True, budget=40, device=dev, group=None, small_batch=False, slot_history=False)   # (random plans)
       multi.set_neighbor_finder(csr)
       single.set_neighbor_finder(csr)
       for b in range(3):

@@ -31,6 +31,8 @@ def main():
   ap.add_argument("--q", type=int, default=4095)
   ap.add_argument("--k", type=int, default=10)
   ap.add_argument("--d-e", type=int, default=172)
+  ap.add_argument("--waves", type=int, default=0, help="orca_tgat_inputs.waves_per_query of the attention launches (0 or 4)")
+  ap.add_argument("--attention-only", action="store_true")
   a = ap.parse_args()
   dev = "cuda:0"
   N, E, Q, K, d_e = a.nodes, a.edges, a.q, a.k, a.d_e
@@ -62,19 +64,20 @@ def main():
   res["tgat_layer1_gather_overlay"] = timeit(lambda: ops.tgat_forward(
       blob, d_e, Q, K, out=out, src_table=memory, src_idx=n32, src_overlay=overlay, src_flags=pending, nbr_table=memory,
       nbr_idx=nbr, nbr_overlay=overlay, nbr_flags=pending, nbr_ids=nbr, edge_table=ef, edge_idx=eid, dt=dt, time_w=tw,
-      time_b=tb, q_folded=True))
+      time_b=tb, q_folded=True, waves_per_query=a.waves))
   emb = torch.randn(Q, 100, device=dev)
   res["tgat_layer2_history"] = timeit(lambda: ops.tgat_forward(
       blob, d_e, Q, K, out=out, src_table=emb, nbr_table=memory, nbr_idx=nbr, nbr_ids=nbr, edge_table=ef, edge_idx=eid,
-      dt=dt, time_w=tw, time_b=tb, q_folded=True))
+      dt=dt, time_w=tw, time_b=tb, q_folded=True, waves_per_query=a.waves))
   # phase breakdown of the attention kernel (100 MHz counter -> us), median over workgroups
   from orca_amd import _lib
-  nwg = (Q + 15) // 16
+  qpw = 4 if a.waves == 4 else 16
+  nwg = (Q + qpw - 1) // qpw
   clk = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
   _lib.load().orca_debug_tgat_phase_clock(clk.data_ptr())
   ops.tgat_forward(blob, d_e, Q, K, out=out, src_table=memory, src_idx=n32, src_overlay=overlay, src_flags=pending,
                    nbr_table=memory, nbr_idx=nbr, nbr_overlay=overlay, nbr_flags=pending, nbr_ids=nbr, edge_table=ef,
-                   edge_idx=eid, dt=dt, time_w=tw, time_b=tb, q_folded=True)
+                   edge_idx=eid, dt=dt, time_w=tw, time_b=tb, q_folded=True, waves_per_query=a.waves)
   torch.cuda.synchronize()
   _lib.load().orca_debug_tgat_phase_clock(None)
   c = clk.view(nwg, 16).cpu().double()
@@ -83,6 +86,10 @@ def main():
   print("tgat phases (median us over workgroups):", {n: round(float(d[:, i].median()), 2) for i, n in enumerate(names)})
   print("tgat workgroup span us: median", float(((c[:, 8] - c[:, 0]) / 100).median()), "chip span",
         float((c[:, 8].max() - c[:, 0].min()) / 100), " start skew", float((c[:, 0].max() - c[:, 0].min()) / 100))
+  if a.attention_only:
+    for k, v in res.items():
+      print(f"{k:45s} {v:8.1f} us")
+    return
   stamp = torch.zeros(N + 1, dtype=torch.int64, device=dev)
   wl = torch.zeros(N + 1, dtype=torch.int32, device=dev)
   cnt = torch.zeros(1, dtype=torch.int32, device=dev)
