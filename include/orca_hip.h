@@ -146,9 +146,18 @@ typedef struct {
   const float* time_b;
   const float* src_time;
   const float* nbr_time;
-  /* nonzero (gather mode only): the caller states that `blob` was completed by orca_tgat_pack_gather with these
-   * time_b values; the kernel then takes q~ straight from the source rows.  0 = the general path. */
+  /* bit 0 set (gather mode only): the caller states that `blob` was completed by orca_tgat_pack_gather with these
+   * time_b values; the kernel then takes q~ straight from the source rows.  0 = the general path.
+   * Bits 8-15: the launch shape, ORCA_TGAT_WAVES(q_folded) = waves per query.  0 or 1: one wavefront per query, 16 queries
+   * per workgroup -- the form for batches that fill the chip.  4 (q_folded = 1 | 4 << 8): four wavefronts share a query (each
+   * takes every fourth neighbour slot through the per-query stages; the parts meet in LDS) and a workgroup holds 4 queries:
+   * for launches of <= ~1000 queries (the reference's batch size of 200 interactions), where one workgroup's latency is what
+   * the launch costs.  Honoured for K = 10, d_e = 172 or 1, a folded q and the plain forward (not orca_tgat_forward_saving);
+   * ignored otherwise.  Same function; the sums over the slots are taken in another order, so results agree with the
+   * one-wave form to rounding, not to the bit.  (Kept inside this word: the struct travels as a kernel argument, and the
+   * bench's launches lost 1 % to eight more bytes of it.) */
   int32_t q_folded;
+#define ORCA_TGAT_WAVES(q_folded) (((q_folded) >> 8) & 0xff)
   /* Attention-weight dropout of nn.MultiheadAttention (model/temporal_attention.py:17-21; train.py:30 default 0.4):
    * weight (query q, head h, slot j) is kept with probability 1 - dropout_p and scaled by 1 / (1 - dropout_p).  The
    * keep decision is a counter RNG keyed (dropout_seed, q0 + q, h, j) -- orca_tgat_dropout_mask writes the same
@@ -157,13 +166,6 @@ typedef struct {
   float dropout_p;
   uint64_t dropout_seed;
   int64_t dropout_q0;
-  /* Launch shape.  0 or 1: one wavefront per query, 16 queries per workgroup -- the form for batches that fill the chip.
-   * 4: four wavefronts share a query (each takes every fourth neighbour slot through the per-query stages; the parts meet
-   * in LDS) and a workgroup holds 4 queries: for launches of <= ~1000 queries (the reference's batch size of 200
-   * interactions), where one workgroup's latency is what the launch costs.  Honoured for K = 10, d_e = 172 or 1, a folded q
-   * and the plain forward (not orca_tgat_forward_saving); ignored otherwise.  Same function; the sums over the slots are
-   * taken in another order, so results agree with the one-wave form to rounding, not to the bit. */
-  int32_t waves_per_query;
 } orca_tgat_inputs;
 /* mult[q][h][j] (float [Q, ORCA_HEADS, K]) = 0 or 1 / (1 - p): the dropout multipliers orca_tgat_forward /
  * orca_tgat_backward apply for (seed, q0) */
@@ -423,7 +425,7 @@ typedef struct {
   int64_t n_nodes;                 /* rows of the state tables (args.n_nodes, train.py:129) */
   int32_t n_layers, K, d_e;
   int32_t small_batch;             /* nonzero: attention launches of <= 1024 queries take the four-waves-per-query form
-                                      (orca_tgat_inputs.waves_per_query = 4): faster at the reference's batch size, equal to
+                                      (ORCA_TGAT_WAVES of orca_tgat_inputs.q_folded = 4): faster at the reference's batch size, equal to
                                       the default form to rounding, not to the bit.  One rank only (an N-rank run is held
                                       bit-equal to one rank in the default form) */
   const orca_csr_t* csr;           /* may be NULL here and set later (orca_engine_set_csr) */

@@ -24,8 +24,7 @@ class TgatInputs(ctypes.Structure):
       "nbr_table", "nbr_idx", "nbr_overlay", "nbr_flags",
       "nbr_ids", "mask", "edge_table", "edge_idx",
       "dt", "time_w", "time_b", "src_time", "nbr_time")] + [("q_folded", ctypes.c_int32), ("dropout_p", ctypes.c_float),
-                                                                     ("dropout_seed", ctypes.c_uint64), ("dropout_q0", ctypes.c_int64),
-                                                                     ("waves_per_query", ctypes.c_int32)]
+                                                                     ("dropout_seed", ctypes.c_uint64), ("dropout_q0", ctypes.c_int64)]
 
 
 class TgatParams(ctypes.Structure):

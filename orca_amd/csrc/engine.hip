@@ -61,7 +61,7 @@ struct orca_engine {
 
 thread_local orca_launch_events orca_armed_events = {nullptr, nullptr};
 
-// orca_tgat_inputs.waves_per_query of an attention launch of n queries (include/orca_hip.h, orca_engine_desc.small_batch);
+// the launch shape (ORCA_TGAT_WAVES of orca_tgat_inputs.q_folded) of an attention launch of n queries (include/orca_hip.h, orca_engine_desc.small_batch);
 // OrcaEngine._wpq is the same rule for the Python-dispatched launches
 static inline int waves_per_query(const orca_engine_desc& d, int64_t n) {
   return (d.small_batch && d.world <= 1 && n <= 1024) ? 4 : 0;
@@ -809,7 +809,7 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   }
   // owner-computes step: rank-major rows (3 * per rows per rank) instead of the batch's root order
   float* out = d.emb[0] + (e->sharded ? 3 * e->per * d.rank : lo) * ORCA_D;
-  in.waves_per_query = waves_per_query(d, n);
+  in.q_folded |= waves_per_query(d, n) << 8;
   Timed t(e, ORCA_PROF_TGAT, stream);
   return orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, n, K, out, nullptr, &side, stream_);   // :177 / :181
 }
@@ -863,7 +863,7 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
     side.store_messages = d.messages; side.store_msg_ts = d.msg_ts; side.store_pending = d.pending;
     e->store_done = true;
   }
-  in.waves_per_query = waves_per_query(d, hi - lo);
+  in.q_folded |= waves_per_query(d, hi - lo) << 8;
   Timed t(e, ORCA_PROF_TGAT, (hipStream_t)stream_);
   return orca_tgat_forward_side(d.att_blob[layer - 1], d.d_e, &in, hi - lo, d.K, next + lo * ORCA_D, nullptr, &side, stream_);
 }
@@ -1301,7 +1301,7 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
     if (!slots) { side.push_table = d.hist[0]; side.push_ids = d.nodes; side.push_winner = win_push; }
     // (the launch is sized for the bound Qc; what it evaluates is the roots and the uncached few: the shape follows the
     // roots plus a nominal 256 -- OrcaEngine._embed_budget applies the same rule to the dispatched launch)
-    in.waves_per_query = waves_per_query(d, Q + 256);
+    in.q_folded |= waves_per_query(d, Q + 256) << 8;
     STEP(orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, Qc, K, comb, nullptr, &side, stream_));
   }
   // 6. the cache flags move on (history.py:25-30)
@@ -1333,7 +1333,7 @@ ORCA_API int orca_engine_step_budget(orca_engine_t* e, const int64_t* src, const
       side.store_memory = d.memory; side.store_last_update = d.last_update;
       side.store_messages = d.messages; side.store_msg_ts = d.msg_ts; side.store_pending = d.pending;
     }
-    in2.waves_per_query = waves_per_query(d, Q);
+    in2.q_folded |= waves_per_query(d, Q) << 8;
     STEP(orca_tgat_forward_side(d.att_blob[1], d.d_e, &in2, Q, K, out, nullptr, &side, stream_));
   }
   if (!train) {

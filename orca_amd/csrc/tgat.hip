@@ -790,11 +790,13 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   static_assert(NQW == 1 || (KT != 0 && KT <= KC && QK), "several waves per query: compile-time K <= KC, folded q");
   const int64_t q0 = (int64_t)blockIdx.x * TQW;
   const int qm = wave / NQW;                       // this wave's query (row of the M-tile) ...
-  const int qr = __builtin_amdgcn_readfirstlane(wave % NQW);     // ... and its part of the slots: qr, qr + NQW, ... (a scalar)
-  const bool lead = qr == 0;                       // the wave that does what is done once per query
+  // ... and its part of the slots: qr, qr + NQW, ... (a scalar; spelled as a constant for NQW = 1, or the default form pays
+  // for branches that can never be taken)
+  const int qr = NQW == 1 ? 0 : __builtin_amdgcn_readfirstlane(wave % NQW);
+  const bool lead = NQW == 1 || qr == 0;           // the wave that does what is done once per query
   constexpr int NSL = (KC + NQW - 1) / NQW;        // slots of a wave when several share a query
   // LDS row this wave fills in the staging stage: its query's row, or (not the lead) one of the idle rows, with zeros
-  const int lrow = lead ? qm : TQW + wave - qm - 1;
+  const int lrow = NQW == 1 ? wave : (lead ? qm : TQW + wave - qm - 1);
   const f32x4* blob4 = reinterpret_cast<const f32x4*>(blob);
   const int c1 = lane + 64;
   const int a_off = (lane & 15), a_k = 4 * (lane >> 4);
@@ -906,14 +908,25 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int idx = lane + 64 * r;
-      const int j = idx < total ? idx / per : 0, ln = idx - j * per;
-      // (every lane takes part in the shuffles: a pulled-from lane must be active)
-      const int nr = __shfl(S.nrow, j, 64), er = __shfl(S.erow, j, 64), ov = __shfl(S.ovl, j, 64);
-      if (idx < total && j % NQW == qr) {
-        const float* p = ln < nl ? (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D + ln * 32
-                                 : in.edge_table + (int64_t)er * d_e + (ln - nl) * 32;
-        const float v = *p;
-        if (r == 0) touch0 = v; else touch1 = v;
+      if constexpr (NQW == 1) {
+        if (idx < total) {
+          const int j = idx / per, ln = idx - j * per;
+          const int nr = __shfl(S.nrow, j, 64), er = __shfl(S.erow, j, 64), ov = __shfl(S.ovl, j, 64);
+          const float* p = ln < nl ? (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D + ln * 32
+                                   : in.edge_table + (int64_t)er * d_e + (ln - nl) * 32;
+          const float v = *p;
+          if (r == 0) touch0 = v; else touch1 = v;
+        }
+      } else {
+        const int j = idx < total ? idx / per : 0, ln = idx - j * per;
+        // (every lane takes part in the shuffles: a pulled-from lane must be active, and this wave's slots are not 0..)
+        const int nr = __shfl(S.nrow, j, 64), er = __shfl(S.erow, j, 64), ov = __shfl(S.ovl, j, 64);
+        if (idx < total && j % NQW == qr) {
+          const float* p = ln < nl ? (ov ? in.nbr_overlay : in.nbr_table) + (int64_t)nr * D + ln * 32
+                                   : in.edge_table + (int64_t)er * d_e + (ln - nl) * 32;
+          const float v = *p;
+          if (r == 0) touch0 = v; else touch1 = v;
+        }
       }
     }
   }
@@ -1470,7 +1483,7 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
   ORCA_REQUIRE(!in->q_folded || in->dt, "orca_tgat_forward: q_folded needs gather-mode time inputs (dt)");
   ORCA_REQUIRE(in->dropout_p >= 0.f && in->dropout_p < 1.f, "orca_tgat_forward: dropout_p=%g outside [0,1)", (double)in->dropout_p);
   hipStream_t st = (hipStream_t)stream;
-  if (in->waves_per_query == 4 && K == 10 && (d_e == 172 || d_e == 1) && in->q_folded && !side.save_qt) {
+  if (ORCA_TGAT_WAVES(in->q_folded) == 4 && K == 10 && (d_e == 172 || d_e == 1) && (in->q_folded & 1) && !side.save_qt) {
     const size_t lds4 = lds_bytes + (size_t)(TQ * 2 * L.KP + TQ * 2 * KC) * sizeof(float);     // partial x-bar rows, scores
     ORCA_REQUIRE(lds4 <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds4);
     const unsigned grid4 = (unsigned)ceil_div64(Q, TQ / 4);
@@ -1486,7 +1499,7 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
   const unsigned grid = (unsigned)ceil_div64(Q, TQ);
 #define ORCA_TGAT_LAUNCH(KT_, DE_)                                                                              \
   do {                                                                                                          \
-    if (in->q_folded)                                                                                           \
+    if (in->q_folded & 1)                                                                                       \
       ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, \
                         out_weights, side, g_phase_clock);                                                      \
     else                                                                                                        \

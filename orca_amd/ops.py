@@ -264,11 +264,10 @@ def tgat_dropout_mask(seed, q0, Q, K, p, device):
 
 def _tgat_inputs(kw, who):
   inp = _lib.TgatInputs()
-  inp.q_folded = int(bool(kw.pop("q_folded", False)))
+  inp.q_folded = int(bool(kw.pop("q_folded", False))) | ((int(kw.pop("waves_per_query", 0) or 0) & 0xff) << 8)
   inp.dropout_p = float(kw.pop("dropout_p", 0.0) or 0.0)
   inp.dropout_seed = int(kw.pop("dropout_seed", 0) or 0) & 0xFFFFFFFFFFFFFFFF
   inp.dropout_q0 = int(kw.pop("dropout_q0", 0) or 0)
-  inp.waves_per_query = int(kw.pop("waves_per_query", 0) or 0)
   keep = []
   for name, ty in _lib.TgatInputs._fields_:
     if ty is not _lib.vp:
