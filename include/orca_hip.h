@@ -154,8 +154,8 @@ typedef struct {
    * for launches of <= ~1000 queries (the reference's batch size of 200 interactions), where one workgroup's latency is what
    * the launch costs.  Honoured for K = 10, d_e = 172 or 1, a folded q and the plain forward (not orca_tgat_forward_saving);
    * ignored otherwise.  Same function; the sums over the slots are taken in another order, so results agree with the
-   * one-wave form to rounding, not to the bit.  (Kept inside this word: the struct travels as a kernel argument, and the
-   * bench's launches lost 1 % to eight more bytes of it.) */
+   * one-wave form to rounding, not to the bit.  (Kept inside this word: as a field of its own it cost the bench's launches
+   * 1 %, reproducibly and for a reason that was not isolated -- padding the kernel's argument list alone does not.) */
   int32_t q_folded;
 #define ORCA_TGAT_WAVES(q_folded) (((q_folded) >> 8) & 0xff)
   /* Attention-weight dropout of nn.MultiheadAttention (model/temporal_attention.py:17-21; train.py:30 default 0.4):
