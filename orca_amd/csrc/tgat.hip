@@ -637,7 +637,9 @@ struct QuerySlots {   // lane j (< K) describes neighbour slot j of this wave's 
 // Issues the global loads of slots j0 .. j0+KC-1 (all in flight at once; nothing here waits on them).
 // own: bit j set = this wave handles slot j0 + j (all ones for a wave that has its query to itself; with several waves per
 // query each takes every NQW-th slot and the others' registers stay zero)
-template <int ME>
+// GIVEN_TIMES: the launch may be one whose time features are given (dense boundary, in.dt == nullptr); false for the
+// folded-q instantiations, which the host only takes with in.dt (the per-slot test and its loads are then not compiled)
+template <int ME, bool GIVEN_TIMES = true>
 __device__ __forceinline__ void load_key_rows(KeyRows<ME>& R, KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S,
                                               int64_t q, int j0, int K, int d_e, int lane, unsigned own = ~0u) {
   const int c1 = lane + 64;
@@ -659,7 +661,7 @@ __device__ __forceinline__ void load_key_rows(KeyRows<ME>& R, KeyTimes& T, const
         const int c = lane + 64 * i;
         R.e[j][i] = ep[c < d_e ? c : 0];
       }
-      if (!in.dt) {     // dense boundary: time features are given
+      if (GIVEN_TIMES && !in.dt) {     // dense boundary: time features are given
         const float* tp = in.nbr_time + (q * K + j0 + j) * D;
         T.ta[j] = tp[lane];
         T.tb[j] = tp[c1 < D ? c1 : 0];
@@ -668,7 +670,7 @@ __device__ __forceinline__ void load_key_rows(KeyRows<ME>& R, KeyTimes& T, const
       R.na[j] = R.nb[j] = 0.f;
 #pragma unroll
       for (int i = 0; i < ME; ++i) R.e[j][i] = 0.f;
-      if (!in.dt) T.ta[j] = T.tb[j] = 0.f;
+      if (GIVEN_TIMES && !in.dt) T.ta[j] = T.tb[j] = 0.f;
     }
   }
 }
@@ -676,9 +678,10 @@ __device__ __forceinline__ void load_key_rows(KeyRows<ME>& R, KeyTimes& T, const
 // cos(dt*w + b) for the chunk's slots (model/time_encoding.py:26-27), kept in registers
 // (wa, ba / wb, bb: time_w, time_b of this lane's columns lane and lane + 64 -- lanes past the width carry the values of
 // column 0 and compute a surplus value: no lane-conditional code)
+template <bool GIVEN_TIMES = true>
 __device__ __forceinline__ void encode_key_times(KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S, int j0,
                                                  int K, int lane, float wa, float ba, float wb, float bb, unsigned own = ~0u) {
-  if (!in.dt) return;
+  if (GIVEN_TIMES && !in.dt) return;
 #pragma unroll
   for (int j = 0; j < KC; ++j) {
     if (j0 + j < K && ((own >> j) & 1u)) {
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   KeyTimes T;
   float lta[NSL], ltb[NSL];                      // (several waves per query: the encodings of this wave's slots)
   if constexpr (NQW == 1) {
-    if (live_q) encode_key_times(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b);
+    if (live_q) encode_key_times<!QK>(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b);
   } else {
 #pragma unroll
     for (int jl = 0; jl < NSL; ++jl) {
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       for (int c = lane; c < 2 * KPS; c += 64) xb0[c] = 0.0f;
     } else {
       KeyRows<ME> R;
-      load_key_rows(R, T, in, S, q, 0, K, d_e, lane);
+      load_key_rows<ME, !QK>(R, T, in, S, q, 0, K, d_e, lane);
       unsigned long long livebits = __ballot(lane < K && !S.masked);
       const bool invalid = livebits == 0ull;                           // temporal_attention.py:46
       if (invalid) {
@@ -1090,8 +1093,8 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       float sc[2];
       sc[0] = scores();
       if (K > KC) {
-        load_key_rows(R, T, in, S, q, KC, K, d_e, lane);
-        encode_key_times(T, in, S, KC, K, lane, tw_a, tb_a, tw_b, tb_b);
+        load_key_rows<ME, !QK>(R, T, in, S, q, KC, K, d_e, lane);
+        encode_key_times<!QK>(T, in, S, KC, K, lane, tw_a, tb_a, tw_b, tb_b);
         sc[1] = scores();
       } else {
         sc[1] = 0.f;
@@ -1159,8 +1162,8 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       };
       if (K > KC) {          // the registers hold slots KC..K-1: use them, then fetch slots 0..KC-1 again (L2 hits)
         accumulate(a_c1);
-        load_key_rows(R, T, in, S, q, 0, K, d_e, lane);
-        encode_key_times(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b);
+        load_key_rows<ME, !QK>(R, T, in, S, q, 0, K, d_e, lane);
+        encode_key_times<!QK>(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b);
       }
       accumulate(a_c0);
       xb0[lane] = an0; xb1[lane] = an1;
