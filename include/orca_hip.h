@@ -33,6 +33,7 @@ extern "C" {
 #define ORCA_HEADS 2
 #define ORCA_MAX_DE 192     /* widest supported edge feature row */
 #define ORCA_MAX_K 20       /* most neighbours per query in orca_tgat_forward */
+#define ORCA_MAX_WORLD 64   /* most ranks of an owner-computes step (orca_engine_desc) */
 
 #define ORCA_OK 0
 #define ORCA_EINVAL -1      /* bad argument (ValueError / assert upstream) */
@@ -467,11 +468,20 @@ typedef struct {
    *          ITS INTERACTIONS [lo, hi) = [rank*per, ...) (rows [src | dst | neg] of that range, the layout a
    *          data-parallel link decoder wants, and the same mix of hub and random roots on every rank); layer l
    *          reads the gathered emb[l&1] -- the history push is applied from it on every rank's replica;
-   *   xm    : world chunks of orca_engine_xm_chunk_words(xm_cap) 32-bit words: [count, 63 unused | ids[xm_cap] |
-   *          rows[xm_cap][ORCA_D]]: GRU(message, memory) of the ids a rank owns among the batch's positives.
+   *   xm    : GRU(message, memory) of the ids a rank owns among the batch's positives.  A chunk of R rows is
+   *          orca_engine_xm_chunk_words(R) 32-bit words: [count, 63 unused | R records of (id, 3 unused, the ORCA_D
+   *          floats of the row)].  finish() packs this rank's chunk into xm_own (sized for xm_cap rows; record r lies
+   *          at the same place whatever R); the caller picks this step's R -- any R with max over the owners of
+   *          their count <= R <= xm_cap, the same on every rank -- all-gathers the first orca_engine_xm_chunk_words(R)
+   *          words of every rank's xm_own into xm (rank-major, chunk c at word c * orca_engine_xm_chunk_words(R)) and
+   *          passes R to orca_engine_apply.  orca_engine_xm_rows gives that R: with n_layers >= 2 begin() counts, for
+   *          every owner, a number that is at least the distinct positives of the batch it owns (and rarely more) --
+   *          every rank from the same global id list, so no collective is needed to agree on R; with one layer
+   *          R = xm_cap.  A rank whose count exceeds xm_cap sets bit 0 of *err and sends xm_cap rows.
    * world <= 1: all of these may be 0 / NULL. */
   int32_t world, rank;
-  int32_t* xm;
+  int32_t* xm;                     /* [world * orca_engine_xm_chunk_words(xm_cap)] the gathered chunks */
+  int32_t* xm_own;                 /* [orca_engine_xm_chunk_words(xm_cap)] this rank's chunk */
   int64_t xm_cap;                  /* rows a rank can send per step; more owned ids than this set bit 0 of *err */
   int32_t* own_ids;                /* [q_max] the distinct ids this rank owns among the batch's positives */
   int32_t* own_pos;                /* [q_max] the position of the last occurrence of each in [src;dst] */
@@ -479,7 +489,7 @@ typedef struct {
   int64_t* slot_m;                 /* [n_nodes] second election table (message list; `slot` serves the history push) */
   int32_t* err;                    /* [1] device error word, zero-initialised by the caller (bit 0: xm overflow) */
 } orca_engine_desc;
-int64_t orca_engine_xm_chunk_words(int64_t cap);
+int64_t orca_engine_xm_chunk_words(int64_t rows);
 
 /* Neighbour sampling of the step driver: ORCA_SAMPLE_RECENT (utils/util.py:134-151, the reference's only mode) or
  * ORCA_SAMPLE_UNIFORM (orca_sample_uniform: not in the reference, BASELINE config 5) with the seed of the NEXT
@@ -541,8 +551,15 @@ int orca_engine_train_capture(orca_engine_t* e, int on, float* const* saved, flo
  * batch was begun with.  tgn_model.py:127-145 */
 int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst, const int64_t* eidx,
                        const double* ts, void* stream);
-/* owner-computes step: after the xm all-gather, overlay[id] = row and pending[id] = 1 for every id any rank sent */
-int orca_engine_apply(orca_engine_t* e, void* stream);
+/* owner-computes step: the rows per chunk to all-gather in this step (orca_engine_desc: xm): the largest of the owners'
+ * counts for the batch begun last, in 64s, at most xm_cap -- the same number on every rank.  begin()'s second kernel
+ * leaves the counts in host memory of the engine's own; this call waits for that kernel (a host wait for work enqueued
+ * before attention layer 1) and adds them up.  xm_cap when there are no counts (one layer; ORCA_XM_SIZED=0 in the
+ * environment, for comparisons). */
+int orca_engine_xm_rows(orca_engine_t* e, int64_t* rows);
+/* owner-computes step: after the xm all-gather of chunks of `rows` rows (orca_engine_desc), overlay[id] = row and
+ * pending[id] = 1 for every id any rank sent */
+int orca_engine_apply(orca_engine_t* e, int64_t rows, void* stream);
 
 /* Budget-bounded history for orca_engine_step_budget (north_star: "a GPU-resident index-and-gather with budget-bounded
  * eviction"; replaces the dense [n_nodes, ORCA_D] table of modules/history.py:11 under --budget B).  Device memory,

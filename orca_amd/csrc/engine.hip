@@ -31,6 +31,14 @@ struct orca_engine {
   int pushed_layer;            // output of this layer is already in its history table (fused push), 0 = none
   bool sharded;                // owner-computes step (several ranks, train order): see orca_engine_begin
   int64_t per;                 // owner-computes step: interactions per rank of the current batch = ceil(bs / world)
+  // owner-computes step: every owner's count of the batch begun last, as partial counts per workgroup of k_owner_list in
+  // host memory; the event behind that kernel; the row count they gave (orca_engine_xm_rows)
+  uint32_t* counts_host = nullptr;   // [counts_blocks][ORCA_MAX_WORLD], pinned, written by k_owner_list
+  int64_t counts_cap = 0;            // workgroups it is sized for
+  int64_t counts_blocks = 0;         // workgroups of the last launch
+  hipEvent_t counted = nullptr;
+  bool count_pending = false;
+  int64_t xm_rows = 0;
   int64_t epoch_push, epoch_msg;   // owner-computes step: the election values begin() claimed on slot / slot_m
   int fuse_gru;                // 1: the eager GRU rides in the first kernel (env ORCA_FUSE_GRU=0 keeps it a launch of its own)
   int gru_subs;                // 0: 4-wave GRU groups per block of that kernel chosen per launch (gru_subs_for); env ORCA_GRU_SUBS=1|2|4 pins it
@@ -321,9 +329,13 @@ __global__ __launch_bounds__(ELECT_THREADS) void k_begin_queries(
 }
 
 // ---- owner-computes step (several ranks): kernels over the exchange buffers ---------------------------------
-constexpr int XM_HEADER = 64;      // 32-bit words ahead of the ids of an xm chunk (word 0 = count)
-__host__ __device__ inline int64_t xm_ids_words(int64_t cap) { return ((cap + 63) / 64) * 64; }
-__host__ __device__ inline int64_t xm_chunk_words(int64_t cap) { return XM_HEADER + xm_ids_words(cap) + cap * ORCA_D; }
+// An xm chunk is a header of XM_HEADER 32-bit words (word 0 = count) and then one record per row: [id, 3 unused | the
+// ORCA_D floats of the row].  Records, not an id array followed by a row array: where record r lies does not depend on
+// how many rows the chunk is sized for, so the owner packs its rows before anyone knows how many rows this step's
+// all-gather will carry (the caller sizes it from the owners' counts, include/orca_hip.h).
+constexpr int XM_HEADER = 64;
+constexpr int XM_REC = ORCA_D + 4;
+__host__ __device__ inline int64_t xm_chunk_words(int64_t rows) { return XM_HEADER + rows * XM_REC; }
 
 // History push of the all-gathered layer outputs (embedding_module.py:103-113, H7 last occurrence wins): the row of
 // root i = k*bs + e goes to hist[nodes[i]] iff begin()'s election found i to be the last occurrence of its id.  The
@@ -350,21 +362,47 @@ __global__ __launch_bounds__(256) void k_xpush_write(const int64_t* __restrict__
 
 // The last occurrences of the ids this rank owns in [src;dst] (begin()'s election on slot_m) -> the lists the
 // owner's kernels walk: positions (own_pos) and ids (own_ids), *count of them; one atomicAdd per workgroup.
+// counts (with slot_push): for EVERY owner o, a bound on the distinct positives o holds in this batch, from which every
+// rank derives the same row count for this step's xm all-gather without a collective of its own.  The message election
+// is run per owner (a rank elects only its own ids), but the election of the history push runs over all the batch's
+// roots on every rank: position p of [src;dst] is counted if it is the last occurrence of its id among ALL roots, or
+// if that last occurrence is a negative (then every positive occurrence of the id is counted: an over-count, rare --
+// negatives are uniform draws -- and on the safe side).  counts is HOST memory the device can write ([gridDim.x]
+// [ORCA_MAX_WORLD]): each workgroup stores its own partial counts there and the host adds them up -- no device-side
+// total, no copy engine pass between this kernel and the attention launch behind it.
 __global__ __launch_bounds__(1024) void k_owner_list(const int64_t* __restrict__ nodes, int64_t n,
                                                      const int64_t* __restrict__ slot, int64_t epoch, int64_t n_nodes,
                                                      int own_world, int own_rank, int32_t* __restrict__ own_pos,
-                                                     int32_t* __restrict__ own_ids, int32_t* __restrict__ count) {
+                                                     int32_t* __restrict__ own_ids, int32_t* __restrict__ count,
+                                                     const int64_t* __restrict__ slot_push, int64_t epoch_push,
+                                                     uint32_t* __restrict__ counts) {
   __shared__ int wave_n[16];
   __shared__ int block_base;
+  __shared__ unsigned owner_n[ORCA_MAX_WORLD];
+  if (threadIdx.x < ORCA_MAX_WORLD) owner_n[threadIdx.x] = 0u;
+  __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t id = -1;
+  int owner = -1;                     // of a counted position
   bool take = false;
   if (p < n) {
     id = nodes[p];
-    take = id >= 0 && id < n_nodes && (int)((uint32_t)id % (uint32_t)own_world) == own_rank && slot[id] == epoch + p;
+    if (id >= 0 && id < n_nodes) {
+      const int o = (int)((uint32_t)id % (uint32_t)own_world);
+      take = o == own_rank && slot[id] == epoch + p;
+      if (counts) {
+        const int64_t w = slot_push[id] - epoch_push;       // last occurrence of the id among [src;dst;neg]
+        if (w == p || w >= n) owner = o;
+      }
+    }
   }
   const unsigned long long m = __ballot(take);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (counts)
+    for (int o = 0; o < own_world; ++o) {       // one LDS add per wave and owner
+      const int c = __popcll(__ballot(owner == o));
+      if (lane == 0 && c) atomicAdd(&owner_n[o], (unsigned)c);
+    }
   if (lane == 0) wave_n[wave] = __popcll(m);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -373,6 +411,7 @@ __global__ __launch_bounds__(1024) void k_owner_list(const int64_t* __restrict__
     block_base = tot ? atomicAdd(count, tot) : 0;
   }
   __syncthreads();
+  if (counts && (int)threadIdx.x < own_world) counts[(int64_t)blockIdx.x * ORCA_MAX_WORLD + threadIdx.x] = owner_n[threadIdx.x];
   if (take) {
     const int k = block_base + wave_n[wave] + __popcll(m & ((1ull << lane) - 1ull));
     own_pos[k] = (int32_t)p;
@@ -423,7 +462,7 @@ __global__ __launch_bounds__(256) void k_owner_persist_store(
   }
 }
 
-// xm chunk of this rank <- the overlay rows of the ids it owns among the batch's positives
+// this rank's chunk (xm_own) <- the overlay rows of the ids it owns among the batch's positives
 __global__ __launch_bounds__(256) void k_pack_rows(const int32_t* __restrict__ ids, const int32_t* __restrict__ count,
                                                    int64_t cap, const float* __restrict__ overlay,
                                                    int32_t* __restrict__ chunk, int32_t* __restrict__ err) {
@@ -436,27 +475,30 @@ __global__ __launch_bounds__(256) void k_pack_rows(const int32_t* __restrict__ i
   }
   if (r >= n || r >= cap) return;
   const int32_t id = ids[r];
-  if (lane == 0) chunk[XM_HEADER + r] = id;
-  float* dst = reinterpret_cast<float*>(chunk + XM_HEADER + xm_ids_words(cap)) + r * ORCA_D;
+  int32_t* rec = chunk + XM_HEADER + r * XM_REC;
+  if (lane == 0) rec[0] = id;
+  float* dst = reinterpret_cast<float*>(rec + 4);
   const float* srcrow = overlay + (int64_t)id * ORCA_D;
   for (int c = lane; c < ORCA_D; c += 64) dst[c] = srcrow[c];
 }
 
-// after the all-gather: overlay[id] = row, pending[id] = 1 for the ids of every chunk (the own chunk: flags only)
-__global__ __launch_bounds__(256) void k_apply_rows(const int32_t* __restrict__ xm, int world, int rank, int64_t cap,
+// after the all-gather of chunks sized for `rows` records: overlay[id] = row, pending[id] = 1 for the ids of every chunk
+// (the own chunk: flags only)
+__global__ __launch_bounds__(256) void k_apply_rows(const int32_t* __restrict__ xm, int world, int rank, int64_t rows,
                                                     int64_t n_nodes, float* __restrict__ overlay,
                                                     uint8_t* __restrict__ pending, int32_t* __restrict__ own_count) {
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (w == 0 && lane == 0) *own_count = 0;       // the list this step's election filled is spent
-  const int64_t c = w / cap, r = w - c * cap;
+  const int64_t c = w / rows, r = w - c * rows;
   if (c >= world) return;
-  const int32_t* chunk = xm + c * xm_chunk_words(cap);
+  const int32_t* chunk = xm + c * xm_chunk_words(rows);
   if (r >= chunk[0]) return;
-  const int64_t id = chunk[XM_HEADER + r];
+  const int32_t* rec = chunk + XM_HEADER + r * XM_REC;
+  const int64_t id = rec[0];
   if (id < 0 || id >= n_nodes) return;
   if (c != rank) {
-    const float* row = reinterpret_cast<const float*>(chunk + XM_HEADER + xm_ids_words(cap)) + r * ORCA_D;
+    const float* row = reinterpret_cast<const float*>(rec + 4);
     for (int c2 = lane; c2 < ORCA_D; c2 += 64) overlay[id * ORCA_D + c2] = row[c2];
   }
   if (lane == 0) pending[id] = 1;
@@ -567,6 +609,8 @@ ORCA_API int orca_engine_destroy(orca_engine_t* e) {
   if (e) {
     int64_t n; double ms;
     for (int c = 0; c < ORCA_PROF_CLASSES; ++c) (void)orca_engine_profile_read(e, c, &n, &ms);
+    if (e->counted) { (void)hipEventSynchronize(e->counted); (void)hipEventDestroy(e->counted); }
+    if (e->counts_host) (void)hipHostFree(e->counts_host);
   }
   delete e;
   return ORCA_OK;
@@ -652,8 +696,9 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   e->sharded = sharded;
   e->per = ceil_div64(bs, world);
   if (e->sharded) {
-    ORCA_REQUIRE(d.xm && d.xm_cap > 0 && d.own_ids && d.own_pos && d.own_count && d.err && d.slot_m,
+    ORCA_REQUIRE(d.xm && d.xm_own && d.xm_cap > 0 && d.own_ids && d.own_pos && d.own_count && d.err && d.slot_m,
                  "orca_engine_begin: a train-ordered step of %d ranks needs the exchange buffers", world);
+    ORCA_REQUIRE(world <= ORCA_MAX_WORLD, "orca_engine_begin: %d ranks (at most %d)", world, ORCA_MAX_WORLD);
     ORCA_REQUIRE(e->overlay_complete, "orca_engine_begin: the owner-computes step needs an overlay-complete state "
                  "(rebuild the overlay rows of the pending ids first)");
     const int64_t my_lo = (int64_t)d.rank * e->per < bs ? (int64_t)d.rank * e->per : bs;
@@ -755,6 +800,31 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     else { if (subs == 1) BEGIN_LAUNCH(3 * ORCA_D + 172, 1); else if (subs == 2) BEGIN_LAUNCH(3 * ORCA_D + 172, 2); else BEGIN_LAUNCH(3 * ORCA_D + 172, 4); }
 #undef BEGIN_LAUNCH
     ORCA_LAUNCH_CHECK();
+  }
+  if (e->sharded) {   // the owner's list, and every owner's count for the caller to size the xm exchange with: here rather
+    // than in finish(), so that the counts reach the host while attention layer 1 runs
+    const int64_t blocks = ceil_div64(2 * bs, 1024);
+    const bool count = d.n_layers >= 2;      // (the counts lean on the election of the history push)
+    if (count && blocks > e->counts_cap) {
+      if (e->counted) ORCA_HIP_TRY(hipEventSynchronize(e->counted));
+      if (e->counts_host) ORCA_HIP_TRY(hipHostFree(e->counts_host));
+      e->counts_host = nullptr;
+      e->counts_cap = 0;
+      ORCA_HIP_TRY(hipHostMalloc((void**)&e->counts_host, (size_t)blocks * ORCA_MAX_WORLD * sizeof(uint32_t), hipHostMallocDefault));
+      e->counts_cap = blocks;
+      if (!e->counted) ORCA_HIP_TRY(hipEventCreateWithFlags(&e->counted, hipEventDisableTiming));
+    }
+    uint32_t* counts_dev = nullptr;
+    if (count) ORCA_HIP_TRY(hipHostGetDevicePointer((void**)&counts_dev, e->counts_host, 0));
+    k_owner_list<<<(unsigned)blocks, 1024, 0, stream>>>(d.nodes, 2 * bs, d.slot_m, e->epoch_msg, d.n_nodes, world, d.rank, d.own_pos,
+                                                        d.own_ids, d.own_count, d.slot, e->epoch_push, counts_dev);
+    ORCA_LAUNCH_CHECK();
+    e->count_pending = false;
+    if (count) {
+      ORCA_HIP_TRY(hipEventRecord(e->counted, stream));
+      e->counts_blocks = blocks;
+      e->count_pending = true;
+    }
   }
   // the other half of the list buffers (consumed above) is the next step's: its counter restarts at zero
   int32_t* next_count = (!e->sharded && d.eager_ids && d.eager_count) ? d.eager_count + (e->cur ^ 1) : nullptr;
@@ -1379,8 +1449,6 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
     hipStream_t st = (hipStream_t)stream_;
     int64_t bound = 2 * bs < d.q_max ? 2 * bs : d.q_max;     // rows the owner's kernels are launched for: more owned
     if (bound > d.xm_cap) bound = d.xm_cap;                   // ids than xm_cap is the overflow k_pack_rows reports
-    k_owner_list<<<(unsigned)ceil_div64(2 * bs, 1024), 1024, 0, st>>>(d.nodes, 2 * bs, d.slot_m, e->epoch_msg, d.n_nodes, d.world,
-                                                                     d.rank, d.own_pos, d.own_ids, d.own_count);
     k_owner_persist_store<<<(unsigned)ceil_div64(bound, 4), 256, 0, st>>>(
         d.nodes, d.qts, eidx, bs, d.own_pos, d.own_count, d.n_nodes, d.pending, d.overlay, d.memory, d.last_update, d.edge_feats,
         d.d_e, d.time_w, d.time_b, d.messages, d.msg_ts);
@@ -1393,7 +1461,7 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
     }
     if (rc != ORCA_OK) return rc;
     k_pack_rows<<<(unsigned)ceil_div64(bound > 0 ? bound : 1, 4), 256, 0, st>>>(d.own_ids, d.own_count, d.xm_cap, d.overlay,
-                                                                              d.xm + (int64_t)d.rank * xm_chunk_words(d.xm_cap), d.err);
+                                                                              d.xm_own, d.err);
     ORCA_LAUNCH_CHECK();
     return ORCA_OK;
   }
@@ -1445,12 +1513,37 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
   return persist();                           // the positives end without a pending message: nothing to list
 }
 
-ORCA_API int orca_engine_apply(orca_engine_t* e, void* stream_) {
+ORCA_API int orca_engine_xm_rows(orca_engine_t* e, int64_t* rows) {
+  ORCA_REQUIRE(e && rows, "orca_engine_xm_rows: null argument");
+  const orca_engine_desc& d = e->d;
+  int64_t r = d.xm_cap;
+  static const bool off = getenv("ORCA_XM_SIZED") && atoi(getenv("ORCA_XM_SIZED")) == 0;     // (A/B: always xm_cap rows, no wait)
+  if (e->sharded && e->count_pending && !off) {
+    ORCA_HIP_TRY(hipEventSynchronize(e->counted));     // (behind begin()'s first two kernels)
+    e->count_pending = false;
+    uint32_t most = 0;
+    for (int o = 0; o < d.world; ++o) {
+      uint32_t c = 0;
+      for (int64_t b = 0; b < e->counts_blocks; ++b) c += e->counts_host[b * ORCA_MAX_WORLD + o];
+      if (c > most) most = c;
+    }
+    r = ((int64_t)most + 63) / 64 * 64;
+    if (r < 64) r = 64;
+    if (r > d.xm_cap) r = d.xm_cap;
+  }
+  e->xm_rows = r;
+  *rows = r;
+  return ORCA_OK;
+}
+
+ORCA_API int orca_engine_apply(orca_engine_t* e, int64_t rows, void* stream_) {
   ORCA_REQUIRE(e, "orca_engine_apply: null handle");
   const orca_engine_desc& d = e->d;
   if (!e->sharded || e->bs == 0) return ORCA_OK;
-  k_apply_rows<<<(unsigned)ceil_div64((int64_t)d.world * d.xm_cap, 4), 256, 0, (hipStream_t)stream_>>>(
-      d.xm, d.world, d.rank, d.xm_cap, d.n_nodes, d.overlay, d.pending, d.own_count);
+  ORCA_REQUIRE(rows > 0 && rows <= d.xm_cap, "orca_engine_apply: chunks of %lld rows (xm_cap=%lld)", (long long)rows,
+               (long long)d.xm_cap);
+  k_apply_rows<<<(unsigned)ceil_div64((int64_t)d.world * rows, 4), 256, 0, (hipStream_t)stream_>>>(
+      d.xm, d.world, d.rank, rows, d.n_nodes, d.overlay, d.pending, d.own_count);
   ORCA_LAUNCH_CHECK();
   return ORCA_OK;
 }

@@ -91,6 +91,18 @@ def all_gather_chunks(buf, chunk, group=None, async_op=False):
   return work if async_op else None
 
 
+def all_gather_into(full, mine, group=None, async_op=False):
+  """Out-of-place all-gather: rank r's `mine` becomes full[r*len(mine):(r+1)*len(mine)] on every rank.  Returns the work
+  handle when async_op (None when the exchange already completed: gloo with device buffers stages through the host)."""
+  if full.is_cuda and dist.get_backend(group) == "gloo":
+    hf = torch.empty(full.shape, dtype=full.dtype)
+    dist.all_gather_into_tensor(hf, mine.cpu(), group=group)
+    full.copy_(hf)
+    return None
+  work = dist.all_gather_into_tensor(full, mine, group=group, async_op=async_op)
+  return work if async_op else None
+
+
 def sync_owned_rows(tables, group=None, chunk_bytes=64 << 20):
   """Every table [N, ...] of `tables` holds current rows only where owner(row) == this rank; afterwards every rank
   holds every owner's rows.  Masked all-reduce in slabs of about chunk_bytes: each row has exactly one non-zero

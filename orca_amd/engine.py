@@ -450,7 +450,11 @@ class OrcaEngine:
       cap = self.exchange_cap if self.exchange_cap else min(worst, int(1.25 * 2 * per_max / 3) + 256)
       self._xm_cap = int(cap)
       self._xm_chunk = int(L.orca_engine_xm_chunk_words(self._xm_cap))
-      self._w.update(xm=torch.zeros(self._xm_chunk * self.world, dtype=torch.int32, device=dev),
+      xm = torch.zeros(self._xm_chunk * self.world, dtype=torch.int32, device=dev)
+      # (a pretended rank 0 -- tools/slice_probe.py -- packs where the all-gather would deliver its chunk: at word 0 whatever
+      # the step's row count; a real rank's chunk is the all-gather's input)
+      own = xm[:self._xm_chunk] if (self._pretend and self.rank == 0) else torch.zeros(self._xm_chunk, dtype=torch.int32, device=dev)
+      self._w.update(xm=xm, xm_own=own,
                      own_ids=torch.zeros(q_max, dtype=torch.int32, device=dev),
                      own_pos=torch.zeros(q_max, dtype=torch.int32, device=dev),
                      own_count=torch.zeros(1, dtype=torch.int32, device=dev))
@@ -479,6 +483,7 @@ class OrcaEngine:
     if self.world > 1:
       d.world, d.rank = self.world, self.rank
       d.xm, d.xm_cap = ptr(w["xm"]), self._xm_cap
+      d.xm_own = ptr(w["xm_own"])
       d.own_ids, d.own_pos, d.own_count = ptr(w["own_ids"]), ptr(w["own_pos"]), ptr(w["own_count"])
       d.slot_m, d.err = ptr(self.slot_m), ptr(self._err)
     d.eager_ids, d.eager_count = ptr(w["eager_ids"]), ptr(w["eager_count"])
@@ -623,10 +628,15 @@ class OrcaEngine:
       self._rebuild_overlay()
     check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, lo, hi, 1, st),
           "orca_engine_begin")
-    emb, xm = self._w["emb"], self._w["xm"]
+    emb = self._w["emb"]
+    rows = ctypes.c_int64(0)
     def finish():
       check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
-      return self._gather_chunks(xm, self._xm_chunk, async_op=True)
+      # The exchange carries as many rows per rank as the fullest owner has (in 64s), not exchange_cap: every rank derives
+      # the same number from the same global id list (orca_engine_xm_rows: a host wait for begin()'s first two kernels).
+      check(L.orca_engine_xm_rows(self._native, ctypes.byref(rows)), "orca_engine_xm_rows")
+      self._xm_rows_last = rows.value
+      return self._gather_own_chunk(int(L.orca_engine_xm_chunk_words(rows.value)), async_op=True)
     wm = None
     for layer in range(2, self.L + 1):
       wh = self._gather_chunks(emb[layer & 1].view(-1), 3 * per * D, async_op=True)
@@ -639,13 +649,21 @@ class OrcaEngine:
       wm = finish()
     if wm is not None:
       wm.wait()
-    check(L.orca_engine_apply(self._native, st), "orca_engine_apply")
+    check(L.orca_engine_apply(self._native, rows.value, st), "orca_engine_apply")
     self._sharded = True
     out = self._w["emb"][(self.L + 1) & 1]
     if gather_output:       # every rank's rows, then back into the batch's [src;dst;neg] order
       self._gather_chunks(out.view(-1), 3 * per * D)
       return out[dist_utils.interaction_root_index(bs, self.world, self.device)]
     return out[3 * per * self.rank:3 * per * self.rank + 3 * (hi - lo)]
+
+  def _gather_own_chunk(self, words, async_op=False):
+    """all-gather of the first `words` words of every rank's xm_own into xm (rank-major chunks of `words`)"""
+    if self._pretend:       # (a timing aid: one rank of a pretended world -- its own chunk arrives, the others are stale)
+      if self.rank != 0:
+        self._w["xm"][self.rank * words:(self.rank + 1) * words].copy_(self._w["xm_own"][:words])
+      return None
+    return dist_utils.all_gather_into(self._w["xm"][:self.world * words], self._w["xm_own"][:words], self.group, async_op)
 
   def _gather_chunks(self, buf, chunk, async_op=False):
     """in-place all-gather of the first world x chunk elements of buf: rank r contributes chunk r"""

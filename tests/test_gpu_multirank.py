@@ -85,6 +85,15 @@ def _worker(rank, world, port, q, full):
           msg = f"reuse={reuse} batch {b}: embeddings or state differ from the single-rank engine"
         ok = ok and step_ok
       multi.check_errors()
+      if reuse:       # the updated-memory exchange of the last train step was sized by that step's own counts: a multiple
+        # of 64 rows under the cap, the same on every rank, and enough for what this rank sent
+        rows, sent = multi._xm_rows_last, int(multi._w["xm_own"][0].item())
+        every = [None] * world
+        dist.all_gather_object(every, rows)
+        sized = rows % 64 == 0 and sent <= rows < multi._xm_cap and all(r == rows for r in every)
+        if not sized and not msg:
+          msg = f"exchange of {rows} rows per rank (ranks: {every}) for {sent} sent, cap {multi._xm_cap}"
+        ok = ok and sized
     # three layers (two history exchanges per step), 20 uniformly sampled neighbours, zero-feature edges
     # (BASELINE config 5's sampler and width): owner-computes steps only
     ef1 = torch.zeros(E + 1, 1, device=dev)

@@ -35,6 +35,6 @@ for world in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 60
   prof = eng.profile_read()
-  own = int(eng._w["xm"][rank * eng._xm_chunk].item()) if world > 1 else -1
+  own = int(eng._w["xm_own"][0].item()) if world > 1 else -1
   print(f"world {world} rank {rank}: {dt * 1e6:7.1f} us per step (compute only) -> {gbs / dt / 1e6:6.1f} M edges/s if the exchange were free; "
-        + "  ".join(f"{k} {v[1] * 1e3:.1f} us" for k, v in prof.items()) + (f"  owned rows last step {own}" if own >= 0 else ""), flush=True)
+        + "  ".join(f"{k} {v[1] * 1e3:.1f} us" for k, v in prof.items()) + (f"  owned rows last step {own}, exchange sized for {eng._xm_rows_last} rows per rank (exchange_cap {eng._xm_cap})" if own >= 0 else ""), flush=True)
