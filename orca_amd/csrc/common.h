@@ -287,7 +287,7 @@ struct OrcaGemm {
                             // (+ old value when accumulate) goes here -- the bias gradient of a weight-gradient GEMM
   int splits;               // > 1: split-K through `part` (no bias / relu / gate / rowzero then)
 };
-constexpr int ORCA_GEMM_GROUP_MAX = 10;
+constexpr int ORCA_GEMM_GROUP_MAX = 12;
 // floats of `part` a group needs
 int64_t orca_sgemm_group_part_floats(const OrcaGemm* g, int n);
 int orca_sgemm_group(hipStream_t s, const OrcaGemm* g, int n, float* part);

@@ -1,6 +1,6 @@
 // The link decoder of a training step and its loss: model/tgn_model.py:150-157 (affinity_score = MergeLayer,
 // utils/util.py:12-24: fc2(relu(fc1([x1 | x2])))) applied to (src, dst) and (src, neg), the sigmoid, and
-// train.py:231-233: BCE(pos, 1) + BCE(neg, 0) -- forward AND backward in seven launches.  Under torch autograd the
+// train.py:231-233: BCE(pos, 1) + BCE(neg, 0) -- forward AND backward in five launches.  Under torch autograd the
 // same thing is ~25 launches and 0.3 ms of host time per step, a fifth of what is left of the training step.
 // Not the hot path's arithmetic (two tiny dense layers); it is here because it sits between the path's forward and
 // its backward.
@@ -63,8 +63,8 @@ Ws ws_layout(int64_t bs) {
   auto take = [&](int64_t n) { int64_t r = o; o += (n + 63) / 64 * 64; return r; };
   w.U = take(3 * bs * D); w.H = take(2 * bs * D); w.dS = take(2 * bs); w.dU = take(3 * bs * D); w.lossv = take(bs);
   w.part = o;
-  // three split-K problems (D x (D+1), D x D, 1 x (D+1)), or the loss's column sum
-  o += (int64_t)DEC_SPLITS * ((int64_t)D * (D + 1) + (int64_t)D * D + (D + 1)) + 64 * 3 + 4 * 64 * 320;
+  // four split-K problems (D x (D+1), D x D, 1 x (D+1), 1 x 1)
+  o += (int64_t)DEC_SPLITS * ((int64_t)D * (D + 1) + (int64_t)D * D + (D + 1) + 1) + 64 * 4;
   w.total = o;
   return w;
 }
@@ -98,26 +98,23 @@ ORCA_API int orca_decoder_train(const float* emb, int64_t bs, const float* fc1_w
     rc |= orca_sgemm_group(s, g, 2, nullptr);
   }
   k_decoder_mid<<<(unsigned)ceil_div64(bs, 4), 256, 0, s>>>(U, fc1_b, fc2_w, fc2_b, bs, H, dS, dU, lossv, prob);
-  {   // loss = sum of the per-interaction terms / bs (two deterministic passes)
-    const float* X[1] = {lossv};
-    const int64_t ld[1] = {1};
-    const int nc[1] = {1};
-    float* out[1] = {loss};
-    rc |= orca_colsum_group(s, 1, X, ld, nc, out, bs, 1.0f / (float)bs, false, part);
-  }
   {   // d src = dU_a W1a, d [dst; neg] = dU_b W1b
     OrcaGemm g[2] = {G1(B, D, D, dU, D, 1, fc1_w, 2 * D, 1, d_emb, D, 1),
                      G1(2 * B, D, D, dU + bs * D, D, 1, fc1_w + D, 2 * D, 1, d_emb + bs * D, D, 1)};
     rc |= orca_sgemm_group(s, g, 2, nullptr);
   }
   {   // dW1a += dU_a^T src (+ db1 as its ones column), dW1b += dU_b^T [dst; neg], dW2 += dS^T H (+ db2)
-    OrcaGemm g[3] = {G1(D, D, B, dU, 1, D, emb, D, 1, g_fc1_w, 2 * D, 1),
+    // and the loss = sum of the per-interaction terms / bs: a problem that has only its ones column (deterministic: the
+    // split-K pieces are added in a fixed order)
+    OrcaGemm g[4] = {G1(D, D, B, dU, 1, D, emb, D, 1, g_fc1_w, 2 * D, 1),
                      G1(D, D, 2 * B, dU + bs * D, 1, D, emb + bs * D, D, 1, g_fc1_w + D, 2 * D, 1),
-                     G1(1, D, 2 * B, dS, 1, 1, H, D, 1, g_fc2_w, D, 1)};
+                     G1(1, D, 2 * B, dS, 1, 1, H, D, 1, g_fc2_w, D, 1),
+                     G1(1, 0, B, lossv, 1, 1, lossv, 0, 1, nullptr, 1, 1)};
     for (auto& p : g) { p.accumulate = 1; p.splits = DEC_SPLITS; }
     g[0].ones_out = g_fc1_b;
     g[2].ones_out = g_fc2_b;
-    rc |= orca_sgemm_group(s, g, 3, part);
+    g[3].ones_out = loss; g[3].accumulate = 0; g[3].alpha = 1.0f / (float)bs;
+    rc |= orca_sgemm_group(s, g, 4, part);
   }
   if (rc != ORCA_OK) return ORCA_EHIP;      // (orca_last_error keeps the failing callee's own message)
   if (hipGetLastError() != hipSuccess) {

@@ -62,6 +62,35 @@ __global__ void k_gru_gates_bwd_saved(const float* __restrict__ g, const float* 
   a[2 * D + u] = dpn;  b[2 * D + u] = dpn * r;
   if (dh_direct) dh_direct[i] = go * z;
 }
+// the two gathers and k_gru_gates_bwd_saved as one launch (the saved-gates route: nothing lies between them): thread
+// (r, c) copies x[ids[r]][c], and for c < 100 also h[ids[r]][c] and turns the kept gates of (r, c) into d gi, d gh
+__global__ void k_gru_bwd_prep_saved(const float* __restrict__ x, const float* __restrict__ h, const int32_t* __restrict__ ids,
+                                     int64_t n, int w, const float* __restrict__ g, const float* __restrict__ d_out,
+                                     float* __restrict__ xg, float* __restrict__ hg, float* __restrict__ gi, float* __restrict__ gh,
+                                     float* __restrict__ dh_direct) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * w) return;
+  const int64_t r_ = i / w;
+  const int u = (int)(i - r_ * w);
+  const int64_t id = ids ? ids[r_] : r_;
+  xg[i] = x[id * w + u];
+  if (u >= D) return;
+  const float hv = h[id * D + u];
+  hg[r_ * D + u] = hv;
+  const float* gr = g + r_ * 4 * D + u;
+  const float r = gr[0], z = gr[D], nn = gr[2 * D], ghn = gr[3 * D];
+  float* a = gi + r_ * G3;
+  float* b = gh + r_ * G3;
+  const float go = d_out[r_ * D + u];
+  const float dn = go * (1.0f - z), dz = go * (hv - nn);
+  const float dpn = dn * (1.0f - nn * nn);
+  const float dpr = dpn * ghn * r * (1.0f - r);
+  const float dpz = dz * z * (1.0f - z);
+  a[u] = dpr;          b[u] = dpr;
+  a[D + u] = dpz;      b[D + u] = dpz;
+  a[2 * D + u] = dpn;  b[2 * D + u] = dpn * r;
+  if (dh_direct) dh_direct[r_ * D + u] = go * z;
+}
 }  // namespace
 
 namespace { constexpr int GRU_SPLITS = 16; }   // split-K pieces of the two weight-gradient GEMMs (one launch)
@@ -114,7 +143,10 @@ ORCA_API int orca_gru_backward_saved(int msg_dim, const float* weight_ih, const 
   auto ew = [&](int64_t k) { return (unsigned)ceil_div64(k, 256); };
   (void)hipGetLastError();      // (a status left behind by an earlier runtime call is not this call's)
   int rc = ORCA_OK;
-  if (phases & 1) {
+  const bool prep = (phases & 1) && gates && msg_dim >= D;      // one launch for the gathers and the gate derivatives
+  if (prep) {
+    k_gru_bwd_prep_saved<<<ew(n * msg_dim), 256, 0, s>>>(x, h, ids, n, msg_dim, gates, d_out, xg, hg, gi, gh, d_h);
+  } else if (phases & 1) {
     k_gather_wide<<<ew(n * msg_dim), 256, 0, s>>>(x, ids, n, msg_dim, xg);
     k_gather_wide<<<ew(n * D), 256, 0, s>>>(h, ids, n, D, hg);
   }
@@ -127,7 +159,8 @@ ORCA_API int orca_gru_backward_saved(int msg_dim, const float* weight_ih, const 
                      G1(M, G3, D, hg, D, 1, weight_hh, 1, D, gh, G3, 1, bias_hh, 0)};
     rc |= orca_sgemm_group(s, g, 2, nullptr);
   }
-  if ((phases & 1) && gates) k_gru_gates_bwd_saved<<<ew(n * D), 256, 0, s>>>(gates, hg, d_out, n, gi, gh, d_h);
+  if (prep) {
+  } else if ((phases & 1) && gates) k_gru_gates_bwd_saved<<<ew(n * D), 256, 0, s>>>(gates, hg, d_out, n, gi, gh, d_h);
   else if (phases & 1) k_gru_gates_bwd<<<ew(n * D), 256, 0, s>>>(gi, gh, hg, d_out, n, d_h);
   if (phases & 2) {   // weight_ih [300,msg] += dgi^T x;  weight_hh [300,100] += dgh^T h;  the biases as a column of ones: one launch
     OrcaGemm g[2] = {G1(G3, msg_dim, M, gi, 1, G3, xg, msg_dim, 1, g_weight_ih, msg_dim, 1, nullptr, 1),

@@ -576,6 +576,8 @@ int orca_sgemm_group(hipStream_t s, const OrcaGemm* in, int n, float* part) {
       }
       int splits = n_tiles > 0 ? (1024 + n_tiles - 1) / n_tiles : WG_SPLITS;
       splits = splits < WG_SPLITS ? WG_SPLITS : splits;
+      static const int forced = getenv("ORCA_WGRAD_SPLITS") ? atoi(getenv("ORCA_WGRAD_SPLITS")) : 0;
+      if (forced > 0) splits = forced;
       splits = splits > cap ? cap : splits;
       for (int i = 0; i < np; ++i) {
         GemmArgs& g = w.g[i];
@@ -1558,9 +1560,10 @@ Ws ws_layout(int d_e, int64_t Q, int K) {
   w.wpack = o;      // fragment-order copies of the weights for the fused chains
   if (d_e == 172) o += (int64_t)ChainW<QD + 172>::total * 256;
   w.part = o;
-  // the eight weight-gradient problems with their bias columns (each rounded up to 64 floats), or a column sum's slices
-  o += (int64_t)SPLITS * ((int64_t)D * (D + 1) + (int64_t)D * (3 * D + 1) + 2 * (int64_t)QD * (QD + 1) + 4 * (int64_t)D * (kdim + 1) + 2 * D)
-       + 64 * 10 + 4 * 64 * 320;
+  // the eight weight-gradient problems with their bias columns and the three that are column sums only (each rounded up
+  // to 64 floats), or a column sum's slices
+  o += (int64_t)SPLITS * ((int64_t)D * (D + 1) + (int64_t)D * (3 * D + 1) + 2 * (int64_t)QD * (QD + 1) + 4 * (int64_t)D * (kdim + 1) + 2 * D + QD)
+       + 64 * ORCA_GEMM_GROUP_MAX + 4 * 64 * 320;
   w.total = o;
   return w;
 }
@@ -1785,7 +1788,7 @@ int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_input
   // (the bk gradient is zero: softmax is shift-invariant), dWq += dq^T xq;  LayerNorm's affine gradients -- column
   // sums of g * xhat and of g -- ride along as two problems that have only the ones column
   {
-    OrcaGemm g[10];
+    OrcaGemm g[ORCA_GEMM_GROUP_MAX];
     auto GW = [&](int M_, int N_, const float* A, int64_t sak, const float* B, int64_t sbk, float* C, float* bias_grad) {
       OrcaGemm r = G1(M_, N_, M, A, 1, sak, B, sbk, 1, C, N_, 1, nullptr, 1.f);
       r.accumulate = 1;
@@ -1804,15 +1807,16 @@ int tgat_backward_impl(const orca_tgat_params* P, int d_e, const orca_tgat_input
     g[7] = GW(QD, QD, dq, QD, xq, QD, G->q_w, G->in_b);
     g[8] = GW(D, 0, gx, D, gx, 0, nullptr, G->ln_w);
     g[9] = GW(D, 0, grad_out, D, grad_out, 0, nullptr, G->ln_b);
-    rc |= orca_sgemm_group(s, g, 10, part);
+    int ng = 10;
+    if (drop) g[ng++] = GW(QD, 0, scaled, QD, scaled, 0, nullptr, G->in_b + 2 * QD);   // the value bias under dropout: column sums too
+    rc |= orca_sgemm_group(s, g, ng, part);
   }
-  {   // what is left of the bias-like gradients: the value bias under dropout, the time encoder's w and b
+  if (want_t) {   // what is left of the bias-like gradients: the time encoder's w and b
     const float* X[3];
     int64_t ld[3];
     int nc[3], nj = 0;
     float* out[3];
-    if (drop) { X[nj] = scaled; ld[nj] = QD; nc[nj] = QD; out[nj++] = G->in_b + 2 * QD; }
-    if (want_t) {
+    {
       X[nj] = tgrad; ld[nj] = QD; nc[nj] = D; out[nj++] = d_time_w;
       X[nj] = tgrad + D; ld[nj] = QD; nc[nj] = D; out[nj++] = d_time_b;
     }

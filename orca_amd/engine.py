@@ -168,8 +168,7 @@ class OrcaEngine:
     elif not _time_unchanged:  # (step_optimizer with the time encoder frozen: nothing changed them)
       self.time_w.copy_(tw)    # re-pack in place: the native driver holds these addresses
       self.time_b.copy_(tb)
-    pre = "embedding_module.attention_models."
-    sds = [{k[len(f"{pre}{i}."):]: v for k, v in sd.items() if k.startswith(f"{pre}{i}.")} for i in range(self.L)]
+    sds = self._layer_params(sd)
     # in place when they exist (the native driver holds the addresses); all layers' folds in shared launches
     self.att_blobs = ops.tgat_pack_layers(sds, self.d_e, dev, blobs=None if first else self.att_blobs, time_b=self.time_b)
     p = "memory_updater.memory_updater."
@@ -180,6 +179,18 @@ class OrcaEngine:
       # overlay rows computed with the previous GRU weights are stale: the reference recomputes
       # get_updated_memory with the current weights on every batch (memory_updater.py:56-78)
       self._invalidate_overlay()
+
+  def _layer_params(self, sd=None):
+    """the attention layers' parameters as one dict per layer, keyed as ops.TGAT_KEYS; grouped once per parameter set
+    (the optimizer updates self.params in place: same tensors every step)"""
+    sd = self.params if sd is None else sd
+    cached = getattr(self, "_layer_sds", None)
+    if cached is not None and cached[0] is sd and cached[1] == len(sd):
+      return cached[2]
+    pre = "embedding_module.attention_models."
+    sds = [{k[len(f"{pre}{i}."):]: v for k, v in sd.items() if k.startswith(f"{pre}{i}.")} for i in range(self.L)]
+    self._layer_sds = (sd, len(sd), sds)
+    return sds
 
   def refresh(self, beside=False, _time_unchanged=False):
     """Re-packs the kernels' parameter blobs from self.params (after an optimizer step changed them in place).
@@ -1135,7 +1146,7 @@ class OrcaEngine:
       deferred.clear()
     for layer, m, (nbr, eid, dt), tables, sink in reversed(steps):
       p = f"embedding_module.attention_models.{layer - 1}."
-      sd = {k[len(p):]: v for k, v in self.params.items() if k.startswith(p)}
+      sd = self._layer_params()[layer - 1]
       kw = dict(nbr_ids=nbr, edge_table=self.edge_feats, edge_idx=eid, dt=dt, time_w=self.time_w, time_b=self.time_b)
       kw.update(tables)
       saved = kw.pop("saved", None)

@@ -185,13 +185,13 @@ def tgat_pack(sd, d_e, device, blob=None, time_b=None):
     raise ValueError(f"tgat_pack: unsupported edge width {d_e}")
   if blob is None:
     blob = torch.empty(n, dtype=torch.float32, device=device)
-  ts = [sd[k].detach().to(device=device, dtype=torch.float32).contiguous() for k in TGAT_KEYS]
+  ts = [_f32(sd[k], device) for k in TGAT_KEYS]
   k_w = ts[1]
   if k_w.shape != (2 * D, 2 * D + d_e):
     raise ValueError(f"tgat_pack: k_proj_weight has shape {tuple(k_w.shape)}, expected {(2 * D, 2 * D + d_e)}")
   check(_lib.load().orca_tgat_pack(int(d_e), *(ptr(t) for t in ts), ptr(blob), stream()), "orca_tgat_pack")
   if time_b is not None:
-    tb = time_b.detach().to(device=device, dtype=torch.float32).contiguous()
+    tb = _f32(time_b, device)
     if tb.numel() != D:
       raise ValueError(f"tgat_pack: time_b has {tb.numel()} values, expected {D}")
     check(_lib.load().orca_tgat_pack_gather(int(d_e), ptr(ts[0]), ptr(k_w), ptr(ts[3]), ptr(tb), ptr(blob), stream()),
@@ -213,7 +213,7 @@ def tgat_pack_layers(sds, d_e, device, blobs=None, time_b=None):
   P = (_lib.TgatParams * L)()
   keep = []
   for i, sd in enumerate(sds):
-    ts = [sd[k].detach().to(device=device, dtype=torch.float32).contiguous() for k in TGAT_KEYS]
+    ts = [_f32(sd[k], device) for k in TGAT_KEYS]
     if ts[1].shape != (2 * D, 2 * D + d_e):
       raise ValueError(f"tgat_pack_layers: k_proj_weight has shape {tuple(ts[1].shape)}, expected {(2 * D, 2 * D + d_e)}")
     keep.append(ts)
@@ -221,7 +221,7 @@ def tgat_pack_layers(sds, d_e, device, blobs=None, time_b=None):
       setattr(P[i], name, ptr(t))
   tb = None
   if time_b is not None:
-    tb = time_b.detach().to(device=device, dtype=torch.float32).contiguous()
+    tb = _f32(time_b, device)
     if tb.numel() != D:
       raise ValueError(f"tgat_pack_layers: time_b has {tb.numel()} values, expected {D}")
   B = (ctypes.c_void_p * L)(*[ptr(b) for b in blobs])
@@ -305,6 +305,15 @@ class ZeroPool:
     return torch.zeros(n, dtype=torch.float32, device=self.device)
 
 
+def _f32(t, device):
+  """t as a contiguous fp32 tensor on `device`: t itself when it already is one (the common case on the training path,
+  where three tensor operations per parameter and step are host time the step does not have)"""
+  dev = torch.device(device)
+  if t.dtype == torch.float32 and t.device.type == dev.type and (dev.index is None or t.device.index == dev.index) and t.is_contiguous():
+    return t.detach() if t.requires_grad else t
+  return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
 def _zeros(n, dev, pool):
   return pool.take(n) if pool is not None else torch.zeros(n, dtype=torch.float32, device=dev)
 
@@ -319,7 +328,7 @@ def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=Non
   stream is appended to the list and keeps the workspace alive; the caller orders that stream after this call and
   joins it before dropping the callable."""
   dev = grad_out.device
-  ps = [sd[k].detach().to(device=dev, dtype=torch.float32).contiguous() for k in TGAT_KEYS]
+  ps = [_f32(sd[k], dev) for k in TGAT_KEYS]
   gather = kw.get("dt") is not None
   sizes = [p.numel() for p in ps] + ([D, D] if gather and want_time_param_grads else [])
   flat = _zeros(sum(-(-n // 64) * 64 for n in sizes), dev, pool)   # one fill for all of them (pool: for the whole step)
@@ -337,7 +346,7 @@ def tgat_backward(sd, d_e, Q, K, grad_out, want_time_param_grads=False, pool=Non
   if n < 0:
     raise ValueError(f"tgat_backward: unsupported sizes d_e={d_e} K={K}")
   wsp = torch.empty(n, dtype=torch.float32, device=dev)
-  go = grad_out.detach().to(torch.float32).contiguous()
+  go = _f32(grad_out, grad_out.device)
   d_src = torch.empty((Q, D), dtype=torch.float32, device=dev)
   d_nbr = torch.empty((Q * K, D), dtype=torch.float32, device=dev) if want_d_nbr else None
   d_st = d_nt = d_tw = d_tb = None
@@ -376,7 +385,7 @@ def gru_pack(weight_ih, weight_hh, bias_ih, bias_hh, device, blob=None):
   again = blob is not None      # (a blob handed back in was packed here before: orca_gru_repack skips the zero fill)
   if blob is None:
     blob = torch.empty(n, dtype=torch.float32, device=device)
-  ts = [t.detach().to(device=device, dtype=torch.float32).contiguous() for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
+  ts = [_f32(t, device) for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
   fn = _lib.load().orca_gru_repack if again else _lib.load().orca_gru_pack
   check(fn(int(msg_dim), *(ptr(t) for t in ts), ptr(blob), stream()), "orca_gru_pack")
   return blob
@@ -389,7 +398,7 @@ def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_
   gradients are issued by the callable appended to the list).  gates: what gru_update(gates=) kept for the same id
   list (orca_gru_backward_saved: no recompute of the gate pre-activations)."""
   dev = d_out.device
-  ps = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
+  ps = [_f32(t, dev) for t in (weight_ih, weight_hh, bias_ih, bias_hh)]
   flat = _zeros(sum(-(-p.numel() // 64) * 64 for p in ps), dev, pool)    # one fill for the four
   gs, o = [], 0
   for p in ps:
@@ -401,7 +410,7 @@ def gru_backward(weight_ih, weight_hh, bias_ih, bias_hh, ids, x, h, d_out, want_
   if nw < 0:
     raise ValueError(f"gru_backward: unsupported message width {msg_dim}")
   wsp = torch.empty(nw, dtype=torch.float32, device=dev)
-  go = d_out.detach().to(torch.float32).contiguous()
+  go = _f32(d_out, d_out.device)
   d_x = torch.empty((n, msg_dim), dtype=torch.float32, device=dev) if want_inputs else None
   d_h = torch.empty((n, D), dtype=torch.float32, device=dev) if want_inputs else None
   x, h = x.contiguous(), h.contiguous()
@@ -555,7 +564,7 @@ def decoder_train(emb, fc1_w, fc1_b, fc2_w, fc2_b, want_prob=False, pool=None):
   [2*bs] or None)."""
   dev = emb.device
   bs = emb.shape[0] // 3
-  ps = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in (fc1_w, fc1_b, fc2_w, fc2_b)]
+  ps = [_f32(t, dev) for t in (fc1_w, fc1_b, fc2_w, fc2_b)]
   flat = _zeros(sum(-(-p.numel() // 64) * 64 for p in ps) + 64, dev, pool)
   gs, o = [], 0
   for p in ps:
