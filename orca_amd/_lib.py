@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborca_hip.so")
+# (ORCA_HIP_LIB: another build of the same library, for A/B measurements of two kernels in one process environment)
+LIB_PATH = os.environ.get("ORCA_HIP_LIB") or os.path.join(_HERE, "liborca_hip.so")
 
 ORCA_D = 100
 ORCA_MAX_DE = 192

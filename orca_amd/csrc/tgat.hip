@@ -641,10 +641,12 @@ struct QuerySlots {   // lane j (< K) describes neighbour slot j of this wave's 
 // folded-q instantiations, which the host only takes with in.dt (the per-slot test and its loads are then not compiled)
 template <int ME, bool GIVEN_TIMES = true>
 __device__ __forceinline__ void load_key_rows(KeyRows<ME>& R, KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S,
-                                              int64_t q, int j0, int K, int d_e, int lane, unsigned own = ~0u) {
+                                              int64_t q, int j0, int K, int d_e, int lane, unsigned own = ~0u,
+                                              int jlo = 0, int jhi = KC) {
   const int c1 = lane + 64;
 #pragma unroll
   for (int j = 0; j < KC; ++j) {
+    if (j < jlo || j >= jhi) continue;       // (constants at the call: the slots of this call)
     if (j0 + j < K && ((own >> j) & 1u)) {   // wave-uniform
       const int nr = __builtin_amdgcn_readlane(S.nrow, j0 + j);
       const int er = __builtin_amdgcn_readlane(S.erow, j0 + j);
@@ -1016,11 +1018,19 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   // ---- P2: q~_h = Wk_h^T (0.1 q_h)  (column kdim carries (0.1 q_h).bk_h): wave (h = w&1, slot = w>>1)
   //      owns tiles slot, slot+8, slot+16 of head h -> bufT.  With the folded map the operand is src itself
   //      (the columns 100..111 of bufQ hold finite time values that meet zero weights).
+  // The first key rows of P3 are requested ahead of the barrier that ends the key fold: every wave leaves that barrier at
+  // the same moment and would otherwise wait for its first row with nothing else to do; the rest follow behind the
+  // barrier, under the arithmetic on these.  (Same box, per step: none 76.29 us, 2 slots 75.77, 3 slots 75.53, 5 slots
+  // 75.50, all ten 76.23; a slot requested ahead of the fold's MFMA loop as well: no gain, 3 spills with two.  The
+  // several-waves-per-query form keeps its loads behind the barrier: ahead of it config 2's step is 56.8 instead of 56.3 us.)
+  constexpr int PRE = (NQW == 1 && QK && KT != 0 && KT <= KC) ? 3 : 0;
+  KeyRows<ME> R;
   {
     float* dstT = bufT + h2 * KPS;
     const float* a2 = (qk ? bufQ : bufP + h2 * D) + a_off * ASTR;
     g2.run(a2 + a_k, lane, [&](int m, int n, float v) { dstT[m * RS + n] = v; }, a2 + 96 + (lane >> 4));
   }
+  if (PRE && live_q) load_key_rows<ME, !QK>(R, T, in, S, q, 0, K, d_e, lane, ~0u, 0, PRE);
   __syncthreads();
   stamp();
 
@@ -1034,8 +1044,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     if (!live_q) {
       for (int c = lane; c < 2 * KPS; c += 64) xb0[c] = 0.0f;
     } else {
-      KeyRows<ME> R;
-      load_key_rows<ME, !QK>(R, T, in, S, q, 0, K, d_e, lane);
+      load_key_rows<ME, !QK>(R, T, in, S, q, 0, K, d_e, lane, ~0u, PRE, KC);
       unsigned long long livebits = __ballot(lane < K && !S.masked);
       const bool invalid = livebits == 0ull;                           // temporal_attention.py:46
       if (invalid) {
