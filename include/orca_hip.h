@@ -466,8 +466,14 @@ typedef struct {
    * read are exchanged through buffers the CALLER all-gathers (RCCL) between the calls:
    *   emb[b]: rank-major, 3*per rows per rank, per = ceil(bs / world): a rank embeds the src, dst and neg roots of
    *          ITS INTERACTIONS [lo, hi) = [rank*per, ...) (rows [src | dst | neg] of that range, the layout a
-   *          data-parallel link decoder wants, and the same mix of hub and random roots on every rank); layer l
-   *          reads the gathered emb[l&1] -- the history push is applied from it on every rank's replica;
+   *          data-parallel link decoder wants, and the same mix of hub and random roots on every rank); a rank
+   *          writes and reads only its own rows of it (callers that want every rank's output gather it themselves);
+   *   xl    : the history push of a layer's output on every rank's replica.  begin() (layer 1) and layer() (inner
+   *          layers) pack the rows of this rank's output that win the push election -- the last occurrence of their
+   *          id among the batch's roots -- into xl_own as a chunk like xm's: [count, 63 unused | records of (id, 3
+   *          unused, row)]; the caller all-gathers the first orca_engine_xm_chunk_words(P) words of every rank's
+   *          xl_own into xl, P = orca_engine_push_rows (the most winners any rank has, in 64s, at most 3*per; the same
+   *          for every layer of the step), and the next layer() applies them.  Sized for q_max / world rows;
    *   xm    : GRU(message, memory) of the ids a rank owns among the batch's positives.  A chunk of R rows is
    *          orca_engine_xm_chunk_words(R) 32-bit words: [count, 63 unused | R records of (id, 3 unused, the ORCA_D
    *          floats of the row)].  finish() packs this rank's chunk into xm_own (sized for xm_cap rows; record r lies
@@ -482,6 +488,8 @@ typedef struct {
   int32_t world, rank;
   int32_t* xm;                     /* [world * orca_engine_xm_chunk_words(xm_cap)] the gathered chunks */
   int32_t* xm_own;                 /* [orca_engine_xm_chunk_words(xm_cap)] this rank's chunk */
+  int32_t* xl;                     /* [world * orca_engine_xm_chunk_words(q_max / world)] gathered push records (n_layers >= 2) */
+  int32_t* xl_own;                 /* [orca_engine_xm_chunk_words(q_max / world)] this rank's push records */
   int64_t xm_cap;                  /* rows a rank can send per step; more owned ids than this set bit 0 of *err */
   int32_t* own_ids;                /* [q_max] the distinct ids this rank owns among the batch's positives */
   int32_t* own_pos;                /* [q_max] the position of the last occurrence of each in [src;dst] */
@@ -515,8 +523,8 @@ int orca_engine_set_csr(orca_engine_t* e, const orca_csr_t* csr);           /* t
 int64_t orca_engine_take_epochs(orca_engine_t* e, int64_t n);
 /* With world > 1 a train-ordered step is the owner-computes step (it needs an overlay-complete state and the
  * exchange buffers; lo / hi of begin and layer are then bounds in INTERACTIONS, not roots); the caller's sequence is
- *   begin -> [all-gather emb[0]] -> finish -> [all-gather xm] -> layer 2 .. L (all-gather emb[(l+1)&1] between
- *   layers) -> apply.
+ *   begin -> [all-gather xl_own -> xl] -> finish -> [all-gather xm_own -> xm] -> layer 2 .. L ([all-gather xl_own -> xl]
+ *   between layers) -> apply.
  * finish may be enqueued while the first all-gather is in flight; apply must follow the xm all-gather and precede
  * the next begin.  Eval-ordered steps with world > 1 run on replicated tables: every rank redoes the row writes of
  * the whole batch (the caller makes the replicas coherent first: memory, last_update, messages, msg_ts of an id
@@ -557,6 +565,9 @@ int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int64_t* dst,
  * before attention layer 1) and adds them up.  xm_cap when there are no counts (one layer; ORCA_XM_SIZED=0 in the
  * environment, for comparisons). */
 int orca_engine_xm_rows(orca_engine_t* e, int64_t* rows);
+/* the same for the history-push exchanges of the step (xl): the most push winners any rank has among its roots, in 64s, at
+ * most 3*per.  Whichever of the two is called first in a step does the waiting. */
+int orca_engine_push_rows(orca_engine_t* e, int64_t* rows);
 /* owner-computes step: after the xm all-gather of chunks of `rows` rows (orca_engine_desc), overlay[id] = row and
  * pending[id] = 1 for every id any rank sent */
 int orca_engine_apply(orca_engine_t* e, int64_t rows, void* stream);

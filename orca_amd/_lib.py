@@ -54,7 +54,7 @@ class EngineDesc(ctypes.Structure):
                ("q_max", i64), ("nodes", vp), ("qts", vp), ("nodes32", vp), ("nbr", vp), ("eid", vp), ("et", vp),
                ("dt", vp), ("emb", vp * 2), ("winners", vp), ("eager_ids", vp), ("eager_count", vp),
                ("att_q_folded", ctypes.c_int32), ("world", ctypes.c_int32), ("rank", ctypes.c_int32),
-               ("xm", vp), ("xm_own", vp), ("xm_cap", i64), ("own_ids", vp), ("own_pos", vp), ("own_count", vp), ("slot_m", vp),
+               ("xm", vp), ("xm_own", vp), ("xl", vp), ("xl_own", vp), ("xm_cap", i64), ("own_ids", vp), ("own_pos", vp), ("own_count", vp), ("slot_m", vp),
                ("err", vp)])
 
 
@@ -129,6 +129,7 @@ SIGNATURES = {
     "orca_engine_finish": (i32, [vp, vp, vp, vp, vp, vp]),
     "orca_engine_apply": (i32, [vp, i64, vp]),
     "orca_engine_xm_rows": (i32, [vp, vp]),
+    "orca_engine_push_rows": (i32, [vp, vp]),
     "orca_engine_xm_chunk_words": (i64, [i64]),
     "orca_engine_set_sampling": (i32, [vp, i32, u64]),
     "orca_engine_set_overlay_complete": (i32, [vp, i32]),

@@ -33,12 +33,13 @@ struct orca_engine {
   int64_t per;                 // owner-computes step: interactions per rank of the current batch = ceil(bs / world)
   // owner-computes step: every owner's count of the batch begun last, as partial counts per workgroup of k_owner_list in
   // host memory; the event behind that kernel; the row count they gave (orca_engine_xm_rows)
-  uint32_t* counts_host = nullptr;   // [counts_blocks][ORCA_MAX_WORLD], pinned, written by k_owner_list
+  uint32_t* counts_host = nullptr;   // [counts_blocks][2][ORCA_MAX_WORLD], pinned, written by k_owner_list
   int64_t counts_cap = 0;            // workgroups it is sized for
   int64_t counts_blocks = 0;         // workgroups of the last launch
   hipEvent_t counted = nullptr;
   bool count_pending = false;
   int64_t xm_rows = 0;
+  int64_t push_rows = 0;             // rows per rank of the step's history-push exchanges (orca_engine_push_rows)
   int64_t epoch_push, epoch_msg;   // owner-computes step: the election values begin() claimed on slot / slot_m
   int fuse_gru;                // 1: the eager GRU rides in the first kernel (env ORCA_FUSE_GRU=0 keeps it a launch of its own)
   int gru_subs;                // 0: 4-wave GRU groups per block of that kernel chosen per launch (gru_subs_for); env ORCA_GRU_SUBS=1|2|4 pins it
@@ -337,24 +338,60 @@ constexpr int XM_HEADER = 64;
 constexpr int XM_REC = ORCA_D + 4;
 __host__ __device__ inline int64_t xm_chunk_words(int64_t rows) { return XM_HEADER + rows * XM_REC; }
 
-// History push of the all-gathered layer outputs (embedding_module.py:103-113, H7 last occurrence wins): the row of
-// root i = k*bs + e goes to hist[nodes[i]] iff begin()'s election found i to be the last occurrence of its id.  The
-// buffer is rank-major: rank r = e / per_e holds the roots of its n_r interactions as rows
-// 3*per_e*r + k*n_r + (e - per_e*r).
-__global__ __launch_bounds__(256) void k_xpush_write(const int64_t* __restrict__ nodes, int64_t bs, int64_t per_e,
-                                                     const float* __restrict__ rows, const int64_t* __restrict__ slot,
-                                                     int64_t epoch, int64_t n_nodes, float* __restrict__ hist) {
-  const int64_t Q = 3 * bs;
-  // 16 lanes per position (a row is 25 float4): a quarter of the waves a wave-per-row copy needs, and the three
-  // dependent loads (id, slot, row) of four positions share one wave's latency
-  const int sub = threadIdx.x & 15;
+// History push across ranks (embedding_module.py:103-113, H7 last occurrence wins).  A rank sends only the rows that WIN
+// the push election -- the last occurrence of their id among all the batch's roots -- as (id, row) records like the xm
+// chunks: a power-law batch repeats its hubs, so about half of a step's 3*bs rows are winners, and this exchange is the one
+// a step cannot hide (attention layer l + 1 pulls what it delivers).
+// k_pack_push: this rank's rows of a layer's output (rank-local order: row k*n_r + j is root k*bs + lo + j) -> xl_own.
+// 16 lanes per row; one atomicAdd per workgroup on the chunk's count (zeroed by k_owner_list / k_xpush_records before).
+__global__ __launch_bounds__(1024) void k_pack_push(const int64_t* __restrict__ nodes, int64_t bs, int64_t lo, int64_t n_r,
+                                                    const float* __restrict__ rows, const int64_t* __restrict__ slot,
+                                                    int64_t epoch, int64_t n_nodes, int32_t* __restrict__ chunk, int64_t cap) {
+  __shared__ int wave_n[16];
+  __shared__ int block_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x & 15;
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  if (i >= Q) return;
-  const int64_t id = nodes[i];
-  if (id < 0 || id >= n_nodes || slot[id] != epoch + i) return;
-  const int64_t k = i / bs, e = i - k * bs, r = e / per_e;
-  const int64_t n_r = (r + 1) * per_e <= bs ? per_e : bs - r * per_e;
-  const f32x4* src = reinterpret_cast<const f32x4*>(rows + (3 * per_e * r + k * n_r + (e - per_e * r)) * ORCA_D);
+  int64_t id = -1;
+  bool win = false;
+  if (i < 3 * n_r) {
+    const int64_t k = i / n_r, p = k * bs + lo + (i - k * n_r);
+    id = nodes[p];
+    win = id >= 0 && id < n_nodes && slot[id] == epoch + p;
+  }
+  const unsigned long long m = __ballot(win && sub == 0);      // one bit per winning row of this wave
+  if (lane == 0) wave_n[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {      // one atomicAdd per workgroup (64 rows) on the chunk's count
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) { const int c = wave_n[w]; wave_n[w] = tot; tot += c; }
+    block_base = tot ? atomicAdd(chunk, tot) : 0;
+  }
+  __syncthreads();
+  if (!win) return;
+  const int r = block_base + wave_n[wave] + __popcll(m & ((1ull << (lane & ~15)) - 1ull));
+  if (r >= cap) return;      // (cannot happen with a count that started at zero: at most 3*n_r winners)
+  int32_t* rec = chunk + XM_HEADER + (int64_t)r * XM_REC;
+  if (sub == 0) rec[0] = (int32_t)id;
+  const f32x4* src = reinterpret_cast<const f32x4*>(rows + i * ORCA_D);
+  f32x4* dst = reinterpret_cast<f32x4*>(rec + 4);
+  dst[sub] = src[sub];
+  if (sub + 16 < ORCA_D / 4) dst[sub + 16] = src[sub + 16];
+}
+// k_xpush_records: after the all-gather of chunks sized for `rows` records, hist[id] = row for every record of every
+// rank (distinct ids: each has one winner); also clears the count of this rank's chunk for the next layer's pack.
+__global__ __launch_bounds__(256) void k_xpush_records(const int32_t* __restrict__ xl, int world, int64_t rows, int64_t n_nodes,
+                                                       float* __restrict__ hist, int32_t* __restrict__ own_count) {
+  const int sub = threadIdx.x & 15;
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (w == 0 && sub == 0 && own_count) *own_count = 0;
+  const int64_t c = w / rows, r = w - c * rows;
+  if (c >= world) return;
+  const int32_t* chunk = xl + c * xm_chunk_words(rows);
+  if (r >= chunk[0]) return;
+  const int32_t* rec = chunk + XM_HEADER + r * XM_REC;
+  const int64_t id = rec[0];
+  if (id < 0 || id >= n_nodes) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(rec + 4);
   f32x4* dst = reinterpret_cast<f32x4*>(hist + id * ORCA_D);
   dst[sub] = src[sub];
   if (sub + 16 < ORCA_D / 4) dst[sub + 16] = src[sub + 16];
@@ -362,46 +399,52 @@ __global__ __launch_bounds__(256) void k_xpush_write(const int64_t* __restrict__
 
 // The last occurrences of the ids this rank owns in [src;dst] (begin()'s election on slot_m) -> the lists the
 // owner's kernels walk: positions (own_pos) and ids (own_ids), *count of them; one atomicAdd per workgroup.
-// counts (with slot_push): for EVERY owner o, a bound on the distinct positives o holds in this batch, from which every
-// rank derives the same row count for this step's xm all-gather without a collective of its own.  The message election
-// is run per owner (a rank elects only its own ids), but the election of the history push runs over all the batch's
-// roots on every rank: position p of [src;dst] is counted if it is the last occurrence of its id among ALL roots, or
-// if that last occurrence is a negative (then every positive occurrence of the id is counted: an over-count, rare --
-// negatives are uniform draws -- and on the safe side).  counts is HOST memory the device can write ([gridDim.x]
-// [ORCA_MAX_WORLD]): each workgroup stores its own partial counts there and the host adds them up -- no device-side
-// total, no copy engine pass between this kernel and the attention launch behind it.
+// counts (with slot_push): what the caller sizes the step's two exchanges with, the same numbers on every rank without a
+// collective to agree on them.  (a) For EVERY owner o, a bound on the distinct positives o holds in this batch.  The
+// message election is run per owner (a rank elects only its own ids), but the election of the history push runs over all
+// the batch's roots on every rank: position p of [src;dst] is counted if it is the last occurrence of its id among ALL
+// roots, or if that last occurrence is a negative (then every positive occurrence of the id is counted: an over-count,
+// rare -- negatives are uniform draws -- and on the safe side).  (b) For every rank r, the roots of its interactions that
+// win the push election: the records it will send of each layer's output.  counts is HOST memory the device can write
+// ([gridDim.x][2][ORCA_MAX_WORLD]): each workgroup stores its own partial counts there and the host adds them up -- no
+// device-side total, no copy engine pass between this kernel and the attention launch behind it.  The grid covers the
+// 3*bs roots (n = 2*bs of them positives); thread 0 also clears the count of this rank's push chunk.
 __global__ __launch_bounds__(1024) void k_owner_list(const int64_t* __restrict__ nodes, int64_t n,
                                                      const int64_t* __restrict__ slot, int64_t epoch, int64_t n_nodes,
                                                      int own_world, int own_rank, int32_t* __restrict__ own_pos,
                                                      int32_t* __restrict__ own_ids, int32_t* __restrict__ count,
                                                      const int64_t* __restrict__ slot_push, int64_t epoch_push,
-                                                     uint32_t* __restrict__ counts) {
+                                                     int64_t per, uint32_t* __restrict__ counts,
+                                                     int32_t* __restrict__ push_count) {
   __shared__ int wave_n[16];
   __shared__ int block_base;
-  __shared__ unsigned owner_n[ORCA_MAX_WORLD];
-  if (threadIdx.x < ORCA_MAX_WORLD) owner_n[threadIdx.x] = 0u;
+  __shared__ unsigned owner_n[2 * ORCA_MAX_WORLD];
+  if (threadIdx.x < 2 * ORCA_MAX_WORLD) owner_n[threadIdx.x] = 0u;
+  if (push_count && blockIdx.x == 0 && threadIdx.x == 0) *push_count = 0;
   __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t id = -1;
-  int owner = -1;                     // of a counted position
+  int owner = -1, sender = -1;        // of a counted position: the owner of its id / the rank that embeds the root
   bool take = false;
-  if (p < n) {
+  if (p < n + n / 2) {
     id = nodes[p];
     if (id >= 0 && id < n_nodes) {
       const int o = (int)((uint32_t)id % (uint32_t)own_world);
-      take = o == own_rank && slot[id] == epoch + p;
+      take = p < n && o == own_rank && slot[id] == epoch + p;
       if (counts) {
         const int64_t w = slot_push[id] - epoch_push;       // last occurrence of the id among [src;dst;neg]
-        if (w == p || w >= n) owner = o;
+        if (p < n && (w == p || w >= n)) owner = o;
+        if (w == p) sender = (int)((p % (n / 2)) / per);
       }
     }
   }
   const unsigned long long m = __ballot(take);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (counts)
-    for (int o = 0; o < own_world; ++o) {       // one LDS add per wave and owner
-      const int c = __popcll(__ballot(owner == o));
+    for (int o = 0; o < own_world; ++o) {       // one LDS add per wave, owner and sender
+      const int c = __popcll(__ballot(owner == o)), c2 = __popcll(__ballot(sender == o));
       if (lane == 0 && c) atomicAdd(&owner_n[o], (unsigned)c);
+      if (lane == 0 && c2) atomicAdd(&owner_n[ORCA_MAX_WORLD + o], (unsigned)c2);
     }
   if (lane == 0) wave_n[wave] = __popcll(m);
   __syncthreads();
@@ -411,7 +454,7 @@ __global__ __launch_bounds__(1024) void k_owner_list(const int64_t* __restrict__
     block_base = tot ? atomicAdd(count, tot) : 0;
   }
   __syncthreads();
-  if (counts && (int)threadIdx.x < own_world) counts[(int64_t)blockIdx.x * ORCA_MAX_WORLD + threadIdx.x] = owner_n[threadIdx.x];
+  if (counts && (int)threadIdx.x < 2 * ORCA_MAX_WORLD) counts[(int64_t)blockIdx.x * 2 * ORCA_MAX_WORLD + threadIdx.x] = owner_n[threadIdx.x];
   if (take) {
     const int k = block_base + wave_n[wave] + __popcll(m & ((1ull << lane) - 1ull));
     own_pos[k] = (int32_t)p;
@@ -699,6 +742,8 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
     ORCA_REQUIRE(d.xm && d.xm_own && d.xm_cap > 0 && d.own_ids && d.own_pos && d.own_count && d.err && d.slot_m,
                  "orca_engine_begin: a train-ordered step of %d ranks needs the exchange buffers", world);
     ORCA_REQUIRE(world <= ORCA_MAX_WORLD, "orca_engine_begin: %d ranks (at most %d)", world, ORCA_MAX_WORLD);
+    ORCA_REQUIRE(d.n_layers < 2 || (d.xl && d.xl_own), "orca_engine_begin: a train-ordered step of %d ranks with %d layers needs "
+                 "the history-push exchange buffers (xl, xl_own)", world, d.n_layers);
     ORCA_REQUIRE(e->overlay_complete, "orca_engine_begin: the owner-computes step needs an overlay-complete state "
                  "(rebuild the overlay rows of the pending ids first)");
     const int64_t my_lo = (int64_t)d.rank * e->per < bs ? (int64_t)d.rank * e->per : bs;
@@ -803,21 +848,22 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   }
   if (e->sharded) {   // the owner's list, and every owner's count for the caller to size the xm exchange with: here rather
     // than in finish(), so that the counts reach the host while attention layer 1 runs
-    const int64_t blocks = ceil_div64(2 * bs, 1024);
     const bool count = d.n_layers >= 2;      // (the counts lean on the election of the history push)
+    const int64_t blocks = ceil_div64(count ? 3 * bs : 2 * bs, 1024);
     if (count && blocks > e->counts_cap) {
       if (e->counted) ORCA_HIP_TRY(hipEventSynchronize(e->counted));
       if (e->counts_host) ORCA_HIP_TRY(hipHostFree(e->counts_host));
       e->counts_host = nullptr;
       e->counts_cap = 0;
-      ORCA_HIP_TRY(hipHostMalloc((void**)&e->counts_host, (size_t)blocks * ORCA_MAX_WORLD * sizeof(uint32_t), hipHostMallocDefault));
+      ORCA_HIP_TRY(hipHostMalloc((void**)&e->counts_host, (size_t)blocks * 2 * ORCA_MAX_WORLD * sizeof(uint32_t), hipHostMallocDefault));
       e->counts_cap = blocks;
       if (!e->counted) ORCA_HIP_TRY(hipEventCreateWithFlags(&e->counted, hipEventDisableTiming));
     }
     uint32_t* counts_dev = nullptr;
     if (count) ORCA_HIP_TRY(hipHostGetDevicePointer((void**)&counts_dev, e->counts_host, 0));
     k_owner_list<<<(unsigned)blocks, 1024, 0, stream>>>(d.nodes, 2 * bs, d.slot_m, e->epoch_msg, d.n_nodes, world, d.rank, d.own_pos,
-                                                        d.own_ids, d.own_count, d.slot, e->epoch_push, counts_dev);
+                                                        d.own_ids, d.own_count, d.slot, e->epoch_push, e->per, counts_dev,
+                                                        count ? d.xl_own : nullptr);
     ORCA_LAUNCH_CHECK();
     e->count_pending = false;
     if (count) {
@@ -825,6 +871,8 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
       e->counts_blocks = blocks;
       e->count_pending = true;
     }
+    e->xm_rows = d.xm_cap;
+    e->push_rows = 3 * e->per;
   }
   // the other half of the list buffers (consumed above) is the next step's: its counter restarts at zero
   int32_t* next_count = (!e->sharded && d.eager_ids && d.eager_count) ? d.eager_count + (e->cur ^ 1) : nullptr;
@@ -880,8 +928,16 @@ ORCA_API int orca_engine_begin(orca_engine_t* e, const int64_t* src, const int64
   // owner-computes step: rank-major rows (3 * per rows per rank) instead of the batch's root order
   float* out = d.emb[0] + (e->sharded ? 3 * e->per * d.rank : lo) * ORCA_D;
   in.q_folded |= waves_per_query(d, n) << 8;
-  Timed t(e, ORCA_PROF_TGAT, stream);
-  return orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, n, K, out, nullptr, &side, stream_);   // :177 / :181
+  {
+    Timed t(e, ORCA_PROF_TGAT, stream);
+    rc = orca_tgat_forward_side(d.att_blob[0], d.d_e, &in, n, K, out, nullptr, &side, stream_);   // :177 / :181
+  }
+  if (rc == ORCA_OK && e->sharded && d.n_layers >= 2) {      // the rows of this output that win the history push -> xl_own
+    k_pack_push<<<(unsigned)ceil_div64(n, 64), 1024, 0, stream>>>(d.nodes, bs, lo, hi - lo, out, d.slot, e->epoch_push, d.n_nodes,
+                                                                 d.xl_own, 3 * e->per);
+    ORCA_LAUNCH_CHECK();
+  }
+  return rc;
 }
 
 ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t hi, void* stream_) {
@@ -897,17 +953,31 @@ ORCA_API int orca_engine_layer(orca_engine_t* e, int layer, int64_t lo, int64_t 
   in.edge_table = d.edge_feats; in.edge_idx = d.eid;
   in.dt = d.dt; in.time_w = d.time_w; in.time_b = d.time_b; in.q_folded = d.att_q_folded;
   if (e->sharded) {
-    // the all-gathered rows of the previous layer: push the last occurrences begin() elected, attend this rank's rows
+    // the all-gathered records of the previous layer (every rank's push winners): into the history table, then attend
+    // this rank's rows
     const float* prev = d.emb[layer & 1];
-    k_xpush_write<<<(unsigned)ceil_div64(e->Q, 16), 256, 0, (hipStream_t)stream_>>>(d.nodes, e->bs, e->per, prev, d.slot,
-                                                                                    e->epoch_push, d.n_nodes, h);
+    const int64_t pr = e->push_rows;
+    ORCA_REQUIRE(pr > 0 && pr <= 3 * e->per, "orca_engine_layer: %lld rows per rank in the history-push exchange",
+                 (long long)pr);
+    // (xl_own inside xl: a pretended rank, whose chunk is not copied -- its count is then left to the next step's begin())
+    k_xpush_records<<<(unsigned)ceil_div64((int64_t)d.world * pr, 16), 256, 0, (hipStream_t)stream_>>>(
+        d.xl, d.world, pr, d.n_nodes, h, d.xl_own == d.xl ? nullptr : d.xl_own);
     ORCA_LAUNCH_CHECK();
     if (hi == lo) return ORCA_OK;
     const int64_t row0 = 3 * e->per * d.rank * ORCA_D;      // this rank's rows of the rank-major buffers
     in.src_table = prev + row0;
-    Timed t(e, ORCA_PROF_TGAT, (hipStream_t)stream_);
-    return orca_tgat_forward_side(d.att_blob[layer - 1], d.d_e, &in, 3 * (hi - lo), d.K, d.emb[(layer + 1) & 1] + row0, nullptr,
-                                  nullptr, stream_);
+    float* out = d.emb[(layer + 1) & 1] + row0;
+    int rc;
+    {
+      Timed t(e, ORCA_PROF_TGAT, (hipStream_t)stream_);
+      rc = orca_tgat_forward_side(d.att_blob[layer - 1], d.d_e, &in, 3 * (hi - lo), d.K, out, nullptr, nullptr, stream_);
+    }
+    if (rc == ORCA_OK && layer < d.n_layers) {      // this output feeds the next layer's history
+      k_pack_push<<<(unsigned)ceil_div64(3 * (hi - lo), 64), 1024, 0, (hipStream_t)stream_>>>(d.nodes, e->bs, lo, hi - lo, out, d.slot,
+                                                                                             e->epoch_push, d.n_nodes, d.xl_own, 3 * e->per);
+      ORCA_LAUNCH_CHECK();
+    }
+    return rc;
   }
   const float* prev = d.emb[layer & 1];            // layer 2 reads emb[0], layer 3 reads emb[1], ...
   float* next = d.emb[(layer + 1) & 1];
@@ -1513,27 +1583,43 @@ ORCA_API int orca_engine_finish(orca_engine_t* e, const int64_t* src, const int6
   return persist();                           // the positives end without a pending message: nothing to list
 }
 
+namespace {
+// the counts k_owner_list left in host memory -> e->xm_rows, e->push_rows (once per step: the first caller waits)
+int fetch_exchange_rows(orca_engine* e) {
+  const orca_engine_desc& d = e->d;
+  static const bool off = getenv("ORCA_XM_SIZED") && atoi(getenv("ORCA_XM_SIZED")) == 0;     // (A/B: always the caps, no wait)
+  if (!e->sharded || !e->count_pending || off) return ORCA_OK;
+  ORCA_HIP_TRY(hipEventSynchronize(e->counted));     // (behind begin()'s first two kernels)
+  e->count_pending = false;
+  uint32_t most = 0, most_push = 0;
+  for (int o = 0; o < d.world; ++o) {
+    uint32_t c = 0, c2 = 0;
+    for (int64_t b = 0; b < e->counts_blocks; ++b) {
+      c += e->counts_host[(b * 2 + 0) * ORCA_MAX_WORLD + o];
+      c2 += e->counts_host[(b * 2 + 1) * ORCA_MAX_WORLD + o];
+    }
+    if (c > most) most = c;
+    if (c2 > most_push) most_push = c2;
+  }
+  auto in64s = [](int64_t n, int64_t cap) { int64_t r = (n + 63) / 64 * 64; r = r < 64 ? 64 : r; return r > cap ? cap : r; };
+  e->xm_rows = in64s(most, d.xm_cap);
+  e->push_rows = in64s(most_push, 3 * e->per);
+  return ORCA_OK;
+}
+}  // namespace
+
 ORCA_API int orca_engine_xm_rows(orca_engine_t* e, int64_t* rows) {
   ORCA_REQUIRE(e && rows, "orca_engine_xm_rows: null argument");
-  const orca_engine_desc& d = e->d;
-  int64_t r = d.xm_cap;
-  static const bool off = getenv("ORCA_XM_SIZED") && atoi(getenv("ORCA_XM_SIZED")) == 0;     // (A/B: always xm_cap rows, no wait)
-  if (e->sharded && e->count_pending && !off) {
-    ORCA_HIP_TRY(hipEventSynchronize(e->counted));     // (behind begin()'s first two kernels)
-    e->count_pending = false;
-    uint32_t most = 0;
-    for (int o = 0; o < d.world; ++o) {
-      uint32_t c = 0;
-      for (int64_t b = 0; b < e->counts_blocks; ++b) c += e->counts_host[b * ORCA_MAX_WORLD + o];
-      if (c > most) most = c;
-    }
-    r = ((int64_t)most + 63) / 64 * 64;
-    if (r < 64) r = 64;
-    if (r > d.xm_cap) r = d.xm_cap;
-  }
-  e->xm_rows = r;
-  *rows = r;
-  return ORCA_OK;
+  const int rc = fetch_exchange_rows(e);
+  *rows = e->sharded ? e->xm_rows : e->d.xm_cap;
+  return rc;
+}
+
+ORCA_API int orca_engine_push_rows(orca_engine_t* e, int64_t* rows) {
+  ORCA_REQUIRE(e && rows, "orca_engine_push_rows: null argument");
+  const int rc = fetch_exchange_rows(e);
+  *rows = e->sharded ? e->push_rows : 0;
+  return rc;
 }
 
 ORCA_API int orca_engine_apply(orca_engine_t* e, int64_t rows, void* stream_) {

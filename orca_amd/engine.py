@@ -462,10 +462,14 @@ class OrcaEngine:
       self._xm_cap = int(cap)
       self._xm_chunk = int(L.orca_engine_xm_chunk_words(self._xm_cap))
       xm = torch.zeros(self._xm_chunk * self.world, dtype=torch.int32, device=dev)
+      self._xl_chunk = int(L.orca_engine_xm_chunk_words(per_max))       # history-push records: at most a rank's 3*per rows
+      xl = torch.zeros(self._xl_chunk * self.world, dtype=torch.int32, device=dev)
       # (a pretended rank 0 -- tools/slice_probe.py -- packs where the all-gather would deliver its chunk: at word 0 whatever
       # the step's row count; a real rank's chunk is the all-gather's input)
-      own = xm[:self._xm_chunk] if (self._pretend and self.rank == 0) else torch.zeros(self._xm_chunk, dtype=torch.int32, device=dev)
-      self._w.update(xm=xm, xm_own=own,
+      alias = self._pretend and self.rank == 0
+      own = xm[:self._xm_chunk] if alias else torch.zeros(self._xm_chunk, dtype=torch.int32, device=dev)
+      xl_own = xl[:self._xl_chunk] if alias else torch.zeros(self._xl_chunk, dtype=torch.int32, device=dev)
+      self._w.update(xm=xm, xm_own=own, xl=xl, xl_own=xl_own,
                      own_ids=torch.zeros(q_max, dtype=torch.int32, device=dev),
                      own_pos=torch.zeros(q_max, dtype=torch.int32, device=dev),
                      own_count=torch.zeros(1, dtype=torch.int32, device=dev))
@@ -495,6 +499,7 @@ class OrcaEngine:
       d.world, d.rank = self.world, self.rank
       d.xm, d.xm_cap = ptr(w["xm"]), self._xm_cap
       d.xm_own = ptr(w["xm_own"])
+      d.xl, d.xl_own = ptr(w["xl"]), ptr(w["xl_own"])
       d.own_ids, d.own_pos, d.own_count = ptr(w["own_ids"]), ptr(w["own_pos"]), ptr(w["own_count"])
       d.slot_m, d.err = ptr(self.slot_m), ptr(self._err)
     d.eager_ids, d.eager_count = ptr(w["eager_ids"]), ptr(w["eager_count"])
@@ -640,7 +645,13 @@ class OrcaEngine:
     check(L.orca_engine_begin(self._native, ptr(src), ptr(dst), ptr(neg), ptr(eidx), ptr(ts), bs, lo, hi, 1, st),
           "orca_engine_begin")
     emb = self._w["emb"]
-    rows = ctypes.c_int64(0)
+    rows, push = ctypes.c_int64(0), ctypes.c_int64(0)
+    if self.L >= 2:
+      # Both exchanges of the step carry as many rows per rank as the fullest rank has (in 64s): every rank derives the same
+      # numbers from the same global id list (begin()'s second kernel counted; a host wait for begin()'s first two kernels).
+      check(L.orca_engine_push_rows(self._native, ctypes.byref(push)), "orca_engine_push_rows")
+      self._push_rows_last = push.value
+      push_words = int(L.orca_engine_xm_chunk_words(push.value))
     def finish():
       check(L.orca_engine_finish(self._native, ptr(src), ptr(dst), ptr(eidx), ptr(ts), st), "orca_engine_finish")
       # The exchange carries as many rows per rank as the fullest owner has (in 64s), not exchange_cap: every rank derives
@@ -650,7 +661,7 @@ class OrcaEngine:
       return self._gather_own_chunk(int(L.orca_engine_xm_chunk_words(rows.value)), async_op=True)
     wm = None
     for layer in range(2, self.L + 1):
-      wh = self._gather_chunks(emb[layer & 1].view(-1), 3 * per * D, async_op=True)
+      wh = self._gather_own_chunk(push_words, async_op=True, which="xl")     # the previous layer's push winners
       if layer == 2:
         wm = finish()
       if wh is not None:
@@ -668,13 +679,15 @@ class OrcaEngine:
       return out[dist_utils.interaction_root_index(bs, self.world, self.device)]
     return out[3 * per * self.rank:3 * per * self.rank + 3 * (hi - lo)]
 
-  def _gather_own_chunk(self, words, async_op=False):
-    """all-gather of the first `words` words of every rank's xm_own into xm (rank-major chunks of `words`)"""
+  def _gather_own_chunk(self, words, async_op=False, which="xm"):
+    """all-gather of the first `words` words of every rank's xm_own into xm (rank-major chunks of `words`); which="xl":
+    of xl_own into xl"""
+    full, own = self._w[which], self._w[which + "_own"]
     if self._pretend:       # (a timing aid: one rank of a pretended world -- its own chunk arrives, the others are stale)
       if self.rank != 0:
-        self._w["xm"][self.rank * words:(self.rank + 1) * words].copy_(self._w["xm_own"][:words])
+        full[self.rank * words:(self.rank + 1) * words].copy_(own[:words])
       return None
-    return dist_utils.all_gather_into(self._w["xm"][:self.world * words], self._w["xm_own"][:words], self.group, async_op)
+    return dist_utils.all_gather_into(full[:self.world * words], own[:words], self.group, async_op)
 
   def _gather_chunks(self, buf, chunk, async_op=False):
     """in-place all-gather of the first world x chunk elements of buf: rank r contributes chunk r"""

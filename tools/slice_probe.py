@@ -37,4 +37,4 @@ for world in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]):
   prof = eng.profile_read()
   own = int(eng._w["xm_own"][0].item()) if world > 1 else -1
   print(f"world {world} rank {rank}: {dt * 1e6:7.1f} us per step (compute only) -> {gbs / dt / 1e6:6.1f} M edges/s if the exchange were free; "
-        + "  ".join(f"{k} {v[1] * 1e3:.1f} us" for k, v in prof.items()) + (f"  owned rows last step {own}, exchange sized for {eng._xm_rows_last} rows per rank (exchange_cap {eng._xm_cap})" if own >= 0 else ""), flush=True)
+        + "  ".join(f"{k} {v[1] * 1e3:.1f} us" for k, v in prof.items()) + (f"  owned rows last step {own}, exchanges sized for {eng._push_rows_last} (history push, of {3 * bs}) and {eng._xm_rows_last} (memory rows, cap {eng._xm_cap}) rows per rank" if own >= 0 else ""), flush=True)
