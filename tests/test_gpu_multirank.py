@@ -39,7 +39,7 @@ def _worker(rank, world, port, q, full):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from orca_amd import ops, synth
+    from orca_amd import _lib, ops, synth
     from orca_amd.dist import interaction_slice, query_slice
     from orca_amd.engine import OrcaEngine
     dev = "cuda:0"
@@ -93,6 +93,16 @@ def _worker(rank, world, port, q, full):
         sized = rows % 64 == 0 and sent <= rows < multi._xm_cap and all(r == rows for r in every)
         if not sized and not msg:
           msg = f"exchange of {rows} rows per rank (ranks: {every}) for {sent} sent, cap {multi._xm_cap}"
+        ok = ok and sized
+        # the same for the history-push records: every rank's gathered chunk fits the step's size, which is under 3*per
+        push = multi._push_rows_last
+        words = int(_lib.load().orca_engine_xm_chunk_words(push))
+        counts = [int(multi._w["xl"][c * words].item()) for c in range(world)]
+        dist.all_gather_object(every, push)
+        per = -(-bs // world)
+        sized = push % 64 == 0 and max(counts) <= push <= 3 * per and push > max(counts) - 64 and all(r == push for r in every)
+        if not sized and not msg:
+          msg = f"history-push exchange of {push} rows per rank (ranks: {every}), chunk counts {counts}, 3*per {3 * per}"
         ok = ok and sized
     # three layers (two history exchanges per step), 20 uniformly sampled neighbours, zero-feature edges
     # (BASELINE config 5's sampler and width): owner-computes steps only
