@@ -217,13 +217,18 @@ def _rccl_worker(port, q):
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
-    from orca_amd.dist import all_gather_chunks, all_gather_rows, all_reduce_sum, sync_owned_rows
+    from orca_amd.dist import all_gather_chunks, all_gather_into, all_gather_rows, all_reduce_sum, sync_owned_rows
     dev = "cuda:0"
     buf = torch.arange(1000, dtype=torch.int32, device=dev)
     w = all_gather_chunks(buf, 640, dist.group.WORLD, async_op=True)     # in-place all_gather_into_tensor on RCCL
     if w is not None:
       w.wait()
     ok = torch.equal(buf, torch.arange(1000, dtype=torch.int32, device=dev))
+    full = torch.zeros(1000, dtype=torch.int32, device=dev)             # out of place, a prefix of both buffers: the sized
+    w = all_gather_into(full[:384], buf[:384], dist.group.WORLD, async_op=True)      # record exchanges of the N-rank step
+    if w is not None:
+      w.wait()
+    ok = ok and torch.equal(full[:384], buf[:384]) and int(full[384:].abs().sum()) == 0
     t = torch.randn(50, 7, device=dev)
     c = t.clone()
     sync_owned_rows([t], dist.group.WORLD)
