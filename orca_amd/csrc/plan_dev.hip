@@ -8,8 +8,8 @@
 // (cache.py:80-87).
 // Pass 2 (sequential over the batches: the cache after batch b decides what batch b+1 reuses): ONE workgroup walks
 // the batches; per batch it gathers the candidates {uncached out-of-batch neighbours, cached ids, targets}
-// (cache.py:121-127), looks up each candidate's next use as a neighbour (:129-146), sorts (distance, id) keys in LDS
-// (bitonic, up to 16384 candidates) and keeps the `budget` nearest (:150-157).  Equal distances are ordered by node
+// (cache.py:121-127), looks up each candidate's next use as a neighbour (:129-146), sorts (distance, id) keys in
+// registers (bitonic, up to 16384 candidates) and keeps the `budget` nearest (:150-157).  Equal distances are ordered by node
 // id, as in plan.hip (the reference's unstable argsort leaves that order undefined: SURVEY H11).
 #include <rocprim/device/device_radix_sort.hpp>
 #include "common.h"
@@ -77,12 +77,79 @@ __global__ void k_pointers(const uint64_t* __restrict__ keys, int64_t n, int shi
   ptr[b] = lower_bound_u64(keys, n, (uint64_t)b << shift);
 }
 
+// ---- the (distance, id) sort of a batch's candidates: bitonic, ascending, keys in REGISTERS -----------------------------
+// Element i of the P2 = 1024 R keys lives in register i / 1024 of thread i % 1024.  A compare-exchange at distance j then
+// is, for j >= 1024, between two registers of one thread; for j < 64, between two lanes of one wave (two 32-bit
+// shuffles); and only for 64 <= j < 1024 between two waves: through LDS, two barriers.  Of the 66 stages of a 2048-key
+// sort that is 1 + 51 + 14 -- the same sort kept in LDS with a barrier per stage took 29 of a batch's 44 us, this one
+// takes 22 of 36: what is left is the vector instructions of 2048 x 66 compare-exchanges on ONE CU's four SIMDs.
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int j) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, j, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), j, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+template <int R, int JR>
+__device__ __forceinline__ void bitonic_in_thread(uint64_t (&a)[R], int tid, int k) {
+  if constexpr (JR < R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if ((r & JR) == 0) {
+        const bool asc = ((tid + 1024 * r) & k) == 0;
+        const uint64_t x = a[r], y = a[r | JR];
+        const bool sw = asc ? x > y : x < y;
+        a[r] = sw ? y : x;
+        a[r | JR] = sw ? x : y;
+      }
+  }
+}
+// n2: a power of two, 1024 <= n2 <= 1024 R: the keys from n2 on are all SENT (padding) and stay where they are
+template <int R>
+__device__ __forceinline__ void bitonic_regs(uint64_t (&a)[R], uint64_t* lds, int tid, int n2) {
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 1024) {
+        switch (j >> 10) {      // (uniform)
+          case 1: bitonic_in_thread<R, 1>(a, tid, k); break;
+          case 2: bitonic_in_thread<R, 2>(a, tid, k); break;
+          case 4: bitonic_in_thread<R, 4>(a, tid, k); break;
+          default: bitonic_in_thread<R, 8>(a, tid, k); break;
+        }
+      } else if (j >= 64) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (1024 * r < n2) lds[tid + 1024 * r] = a[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (1024 * r >= n2) continue;      // (uniform)
+          const int i = tid + 1024 * r;
+          const uint64_t c = lds[i ^ j];
+          const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+          a[r] = keep_min ? (a[r] < c ? a[r] : c) : (a[r] > c ? a[r] : c);
+        }
+        __syncthreads();
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (1024 * r >= n2) continue;      // (uniform)
+          const int i = tid + 1024 * r;
+          const uint64_t c = shfl_xor_u64(a[r], j);
+          const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+          a[r] = keep_min ? (a[r] < c ? a[r] : c) : (a[r] > c ? a[r] : c);
+        }
+      }
+    }
+}
+
 struct PlanState {          // carried from one launch of k_mrd_batches to the next
   int32_t cached_n;
   int32_t overflow;         // a batch had more candidates than PLAN_KEYS
+  int32_t grow;             // a batch had more candidates than the launch's instantiation sorts (1024 R): the walk stopped
+  int32_t pad_;
+  long long next_b;         // ... in front of this batch
   long long n_reuse, n_recompute, total_rd;
 };
 
+template <int R>
 __global__ __launch_bounds__(PLAN_THREADS) void k_mrd_batches(
     int64_t b0, int64_t b1, int64_t budget, const uint64_t* __restrict__ tk, const int64_t* __restrict__ tptr,
     const uint64_t* __restrict__ ok, const int64_t* __restrict__ optr, const uint64_t* __restrict__ ev,
@@ -92,7 +159,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_mrd_batches(
   extern __shared__ uint64_t keys[];                 // PLAN_KEYS
   __shared__ int n_cand;
   const int tid = threadIdx.x;
-  long long reuse = 0, recompute = 0, rd = 0;
+  long long reuse_all = 0, recompute_all = 0, rd_all = 0;
   int cached_n = st->cached_n;
   if (st->overflow) return;
   auto add = [&](uint32_t v) {
@@ -100,16 +167,44 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_mrd_batches(
     if (idx < PLAN_KEYS) keys[idx] = v;
   };
   for (int64_t b = b0; b < b1; ++b) {
+    long long reuse = 0, recompute = 0, rd = 0;      // of this batch: counted once it has been sorted (see `grow`)
     if (tid == 0) n_cand = 0;
     __syncthreads();
-    // out-of-batch neighbours of batch b (with multiplicity): reuse / recompute counts, uncached ones are candidates
-    for (int64_t i = optr[b] + tid; i < optr[b + 1]; i += PLAN_THREADS) {
-      const uint64_t k = ok[i];
-      const uint32_t v = (uint32_t)k;
-      if (cache_flag[v]) { ++reuse; rd += b - time_flag[v]; }          // cache.py:113-119
-      else {
-        ++recompute;
-        if (i == optr[b] || ok[i - 1] != k) { fresh[v] = (int32_t)b; add(v); }
+    // out-of-batch neighbours of batch b (with multiplicity): reuse / recompute counts, uncached ones are candidates.
+    // One workgroup walks the batches, so what a batch costs is its chains of dependent loads: the loop is taken four
+    // positions per thread at a time, every load of a level requested before the first is looked at (clamped positions,
+    // masked results: no branch around a load).
+    {
+      const int64_t o_lo = optr[b], o_hi = optr[b + 1];
+      for (int64_t i0 = o_lo + tid; i0 < o_hi; i0 += 4 * PLAN_THREADS) {
+        uint64_t k[4], kp[4];
+        bool in[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t i = i0 + (int64_t)r * PLAN_THREADS;
+          in[r] = i < o_hi;
+          const int64_t ic = in[r] ? i : o_lo;
+          k[r] = ok[ic];
+          kp[r] = ok[ic > o_lo ? ic - 1 : o_lo];
+        }
+        uint8_t cf[4];
+        int32_t tf[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          cf[r] = cache_flag[(uint32_t)k[r]];
+          tf[r] = time_flag[(uint32_t)k[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (!in[r]) continue;
+          const int64_t i = i0 + (int64_t)r * PLAN_THREADS;
+          const uint32_t v = (uint32_t)k[r];
+          if (cf[r]) { ++reuse; rd += b - tf[r]; }                         // cache.py:113-119
+          else {
+            ++recompute;
+            if (i == o_lo || kp[r] != k[r]) { fresh[v] = (int32_t)b; add(v); }
+          }
+        }
       }
     }
     // unique targets of batch b: new_computed (:124-125)
@@ -135,37 +230,64 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_mrd_batches(
       if (tid == 0) st->overflow = 1;
       break;
     }
-    int P2 = 1;
-    while (P2 < C) P2 <<= 1;
-    // next use as a neighbour (:129-146); key = (distance << 32) | id
-    for (int i = tid; i < P2; i += PLAN_THREADS) {
-      if (i >= C) { keys[i] = SENT; continue; }
-      const uint32_t v = (uint32_t)keys[i];
-      const int64_t o0 = occ_ptr[v], o1 = occ_ptr[v + 1];
-      int64_t p = o0 + pos[v];
-      while (p < o1 && (int64_t)((ev[p] >> 1) & 0xffffffffull) <= b) ++p;
-      pos[v] = (int32_t)(p - o0);
-      const uint64_t d = (p == o1 || (ev[p] & 1ull) == 0) ? (uint64_t)(MAX_DISTANCE + 1)
-                                                          : (uint64_t)((int64_t)((ev[p] >> 1) & 0xffffffffull) - b);
-      keys[i] = (d << 32) | v;
+    if (C > 1024 * R) {                  // more candidates than this instantiation sorts: the host re-launches from batch b
+      if (tid == 0) { st->grow = 1; st->next_b = b; }      // with the next size (nothing of batch b has been changed that
+      break;                                                // its second walk does not set again)
     }
-    __syncthreads();
-    for (int k = 2; k <= P2; k <<= 1)                                   // bitonic sort, ascending (:150-152)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < P2; i += PLAN_THREADS) {
-          const int x = i ^ j;
-          if (x > i) {
-            const uint64_t a = keys[i], c = keys[x];
-            if (((i & k) == 0) ? (a > c) : (a < c)) { keys[i] = c; keys[x] = a; }
-          }
-        }
-        __syncthreads();
+    // next use as a neighbour (:129-146); key = (distance << 32) | id.  The thread's R candidates at a time, level by level
+    // as above: the occurrence-list bounds and the cursor, then the event under the cursor; a cursor that has to move on
+    // (the id has events in batches up to b that this walk has not passed yet) finishes in the loop below.
+    uint64_t key[R];
+    constexpr int G = R < 4 ? R : 4;
+#pragma unroll
+    for (int g = 0; g < R; g += G) {
+      uint32_t v[G];
+      bool in[G];
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        const int i = tid + 1024 * (g + r);
+        in[r] = i < C;
+        v[r] = in[r] ? (uint32_t)keys[i] : 0u;
       }
+      int64_t o0[G], o1[G], p[G];
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        o0[r] = occ_ptr[v[r]];
+        o1[r] = occ_ptr[v[r] + 1];
+        p[r] = pos[v[r]];
+      }
+      uint64_t e[G];
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        p[r] += o0[r];
+        e[r] = ev[p[r] < o1[r] ? p[r] : (o1[r] > o0[r] ? o1[r] - 1 : 0)];
+      }
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        key[g + r] = SENT;
+        if (!in[r]) continue;
+        while (p[r] < o1[r] && (int64_t)((e[r] >> 1) & 0xffffffffull) <= b) {
+          ++p[r];
+          if (p[r] < o1[r]) e[r] = ev[p[r]];
+        }
+        pos[v[r]] = (int32_t)(p[r] - o0[r]);
+        const uint64_t d = (p[r] == o1[r] || (e[r] & 1ull) == 0) ? (uint64_t)(MAX_DISTANCE + 1)
+                                                                 : (uint64_t)((int64_t)((e[r] >> 1) & 0xffffffffull) - b);
+        key[g + r] = (d << 32) | v[r];
+      }
+    }
+    __syncthreads();                     // (every candidate id has been read: the sort's exchanges reuse `keys`)
+    int n2 = 1024;
+    while (n2 < C) n2 <<= 1;
+    bitonic_regs<R>(key, keys, tid, n2);     // ascending (:150-152)
     const int n_keep = (int64_t)C < budget ? C : (int)budget;
     for (int i = tid; i < cached_n; i += PLAN_THREADS) cache_flag[cached[i]] = 0;    // :155-156
     __syncthreads();
-    for (int i = tid; i < n_keep; i += PLAN_THREADS) {
-      const uint32_t v = (uint32_t)keys[i];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = tid + 1024 * r;
+      if (i >= n_keep) continue;
+      const uint32_t v = (uint32_t)key[r];
       plan_out[b * budget + i] = (int64_t)v;
       cache_flag[v] = 1;
       cached[i] = (int32_t)v;
@@ -173,12 +295,13 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_mrd_batches(
     }
     if (tid == 0) plan_len[b] = n_keep;
     cached_n = n_keep;
+    reuse_all += reuse; recompute_all += recompute; rd_all += rd;
     __syncthreads();
   }
   if (tid == 0) st->cached_n = cached_n;
-  atomicAdd((unsigned long long*)&st->n_reuse, (unsigned long long)reuse);
-  atomicAdd((unsigned long long*)&st->n_recompute, (unsigned long long)recompute);
-  atomicAdd((unsigned long long*)&st->total_rd, (unsigned long long)rd);
+  atomicAdd((unsigned long long*)&st->n_reuse, (unsigned long long)reuse_all);
+  atomicAdd((unsigned long long*)&st->n_recompute, (unsigned long long)recompute_all);
+  atomicAdd((unsigned long long*)&st->total_rd, (unsigned long long)rd_all);
 }
 
 struct Buffers {            // everything the planner allocates, freed on every exit path
@@ -276,13 +399,38 @@ ORCA_API int orca_mrd_plan_device(int64_t E, int64_t bs, int K, const int64_t* s
   ORCA_HIP_TRY(hipMemsetAsync(st, 0, sizeof(PlanState), stream));
   static bool attr_set[64] = {};
   const size_t lds = (size_t)PLAN_KEYS * sizeof(uint64_t);
-  if (orca_first_use_on_device(attr_set))
-    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_mrd_batches, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (orca_first_use_on_device(attr_set)) {
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_mrd_batches<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_mrd_batches<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_mrd_batches<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_mrd_batches<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ORCA_HIP_TRY(hipFuncSetAttribute((const void*)k_mrd_batches<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  // The sort holds 1024 R keys in registers; R follows the batches: a launch that meets a batch with more candidates
+  // stops in front of it, and the walk goes on from there with the next size (it never shrinks: a trace's batches are alike).
   const int64_t chunk = 1024;            // batches per launch: a launch stays in the tens of milliseconds
-  for (int64_t b0 = 0; b0 < num_batch; b0 += chunk) {
+  int R = 1;
+  while (1024 * R < budget && R < 16) R *= 2;      // (the cached ids alone are candidates)
+  for (int64_t b0 = 0; b0 < num_batch;) {
     const int64_t b1 = b0 + chunk < num_batch ? b0 + chunk : num_batch;
-    k_mrd_batches<<<1, PLAN_THREADS, lds, stream>>>(b0, b1, budget, tk, tptr, ok, optr, ev, occ_ptr, cache_flag, time_flag, pos,
-                                                    fresh, mark, cached, st, plan_out, plan_len);
+#define PLAN_LAUNCH(RR) k_mrd_batches<RR><<<1, PLAN_THREADS, lds, stream>>>(b0, b1, budget, tk, tptr, ok, optr, ev, occ_ptr, cache_flag, \
+                                                                        time_flag, pos, fresh, mark, cached, st, plan_out, plan_len)
+    if (R == 1) PLAN_LAUNCH(1); else if (R == 2) PLAN_LAUNCH(2); else if (R == 4) PLAN_LAUNCH(4); else if (R == 8) PLAN_LAUNCH(8);
+    else PLAN_LAUNCH(16);
+#undef PLAN_LAUNCH
+    ORCA_LAUNCH_CHECK();
+    PlanState hs{};
+    ORCA_HIP_TRY(hipMemcpyAsync(&hs, st, sizeof(PlanState), hipMemcpyDeviceToHost, stream));
+    ORCA_HIP_TRY(hipStreamSynchronize(stream));
+    if (hs.overflow) break;
+    if (hs.grow) {
+      ORCA_REQUIRE(R < 16, "orca_mrd_plan_device: a batch asks for more than %d sort keys", PLAN_KEYS);
+      R *= 2;
+      b0 = hs.next_b;
+      ORCA_HIP_TRY(hipMemsetAsync(&st->grow, 0, sizeof(int32_t), stream));
+    } else {
+      b0 = b1;
+    }
   }
   ORCA_LAUNCH_CHECK();
   PlanState h{};
