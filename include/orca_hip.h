@@ -239,8 +239,9 @@ int orca_tgat_pack_layers(int n_layers, int d_e, const orca_tgat_params* params,
                           float* const* blobs, int blobs_packed_before, void* stream);
 
 
-/* Profiling aid (no counterpart in the reference): when buf != NULL (device int64 [ceil(Q/16) * 16]) later
- * orca_tgat_forward launches write the 100 MHz real-time counter at each internal phase boundary. */
+/* Profiling aid (no counterpart in the reference): when buf != NULL (device int64 [workgroups * 32]) later
+ * orca_tgat_forward launches write, per workgroup, the 100 MHz real-time counter at each internal phase boundary
+ * (words 0..15) and the shader clock counter beside it (words 16..31). */
 int orca_debug_tgat_phase_clock(void* buf);
 /* same for the streaming GRU kernel: device int64 [ceil(n/64)*7 * 4 waves * 4 stamps] */
 int orca_debug_gru_phase_clock(void* buf);

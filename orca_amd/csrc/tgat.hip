@@ -568,8 +568,15 @@ struct WaveGemm {
 #pragma unroll
         for (int t = 0; t < NT; ++t) b[t] = ring[g][t];
         if (kb + G < KBC) {
+          if (TAIL1 && kb + G == KBC - 1) {
+            // one word per lane is all the tail step uses; as a dwordx4 whose upper words are dead the three loads
+            // were given overlapping registers, and the next LDS read into one of them waited for vmcnt(0)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) ring[g][t] = bp[t][(kb + G) * 64];
+            for (int t = 0; t < NT; ++t) ring[g][t][0] = *reinterpret_cast<const float*>(&bp[t][(kb + G) * 64]);
+          } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ring[g][t] = bp[t][(kb + G) * 64];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the refill ahead of the MFMAs (the scheduler sinks it otherwise)
         if constexpr (TAIL1) {
@@ -760,10 +767,23 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
                                                           orca_tgat_side side, long long* __restrict__ phase_clock) {
   extern __shared__ __align__(16) float lds[];
   // optional profiling aid (orca_debug_tgat_phase_clock): wave 0 of each workgroup stamps the 100 MHz
-  // real-time counter at every phase boundary
+  // real-time counter at every phase boundary (words 0..15 of its 32) and the shader clock beside it (16..31)
+#ifdef ORCA_WAVE_STAMPS   // diagnostic build only (tools/build_diag.sh): every wave's shader clock around the GEMM stages,
+                          // behind the workgroups' 32 words each: [workgroup][wave][8]
+  auto wstamp = [&](int i) {
+    if (phase_clock && (threadIdx.x & 63) == 0)
+      phase_clock[(int64_t)gridDim.x * 32 + ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 8 + i] =
+          (long long)__builtin_amdgcn_s_memtime();
+  };
+#else
+  auto wstamp = [](int) {};
+#endif
   int phase_no = 0;
   auto stamp = [&]() {
-    if (phase_clock && threadIdx.x == 0) phase_clock[(int64_t)blockIdx.x * 16 + phase_no] = wall_clock64();
+    if (phase_clock && threadIdx.x == 0) {
+      phase_clock[(int64_t)blockIdx.x * 32 + phase_no] = wall_clock64();
+      phase_clock[(int64_t)blockIdx.x * 32 + 16 + phase_no] = (long long)__builtin_amdgcn_s_memtime();
+    }
     ++phase_no;
   };
   stamp();
@@ -1028,10 +1048,14 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   {
     float* dstT = bufT + h2 * KPS;
     const float* a2 = (qk ? bufQ : bufP + h2 * D) + a_off * ASTR;
+    wstamp(0);
     g2.run(a2 + a_k, lane, [&](int m, int n, float v) { dstT[m * RS + n] = v; }, a2 + 96 + (lane >> 4));
+    wstamp(1);
   }
   if (PRE && live_q) load_key_rows<ME, !QK>(R, T, in, S, q, 0, K, d_e, lane, ~0u, 0, PRE);
+  wstamp(2);
   __syncthreads();
+  wstamp(3);
   stamp();
 
   // ---- P3: this wave's query: scores, masked softmax, weighted key sum ---------------------------
@@ -1364,8 +1388,10 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   {
     const float* a4 = bufT + a_off * RS + a_k + kb4 * 16;
     float* dst = part + wave * 256;
+    wstamp(4);
     if (big) g4b.run(a4, lane, [&](int m, int n, float v) { dst[m * 16 + n] = v; });
     else     g4s.run(a4, lane, [&](int m, int n, float v) { dst[m * 16 + n] = v; });
+    wstamp(5);
   }
   WaveGemm<1, 7, 7, true> g7;
   g7.prefetch(blob4 + L.pw_2 / 4, NT100, wave < NT100 ? wave : -1, NW, NT100, lane, blob + L.b_2);
@@ -1373,7 +1399,9 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   // a spilled register -- ahead of the gathers)
   const float ln_ga = blob[L.ln_w + lane], ln_ba = blob[L.ln_b + lane];
   const float ln_gb = blob[c1 < D ? L.ln_w + c1 : L.ln_w], ln_bb = blob[c1 < D ? L.ln_b + c1 : L.ln_b];
+  wstamp(6);
   __syncthreads();
+  wstamp(7);
   stamp();
   for (int e = tid; e < TQ * 112; e += NW * 64) {
     const int m = e / 112, n = e - m * 112, t = n >> 4, o = m * 16 + (n & 15);

@@ -4,6 +4,7 @@ Usage (on the GPU box): python tools/kbench.py [--nodes 1000000] [--edges 100000
 import argparse
 import os
 import sys
+import time
 
 import torch
 
@@ -73,17 +74,43 @@ def main():
   from orca_amd import _lib
   qpw = 4 if a.waves == 4 else 16
   nwg = (Q + qpw - 1) // qpw
-  clk = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
+  clk = torch.zeros(nwg * (32 + 16 * 8), dtype=torch.int64, device=dev)   # (+ the per-wave words of a -DORCA_WAVE_STAMPS build)
+  # the clock the chip holds is read under load: two seconds of back-to-back launches first
+  t_end = time.time() + 2.0
+  while time.time() < t_end:
+    for _ in range(200):
+      ops.tgat_forward(blob, d_e, Q, K, out=out, src_table=memory, src_idx=n32, src_overlay=overlay, src_flags=pending,
+                       nbr_table=memory, nbr_idx=nbr, nbr_overlay=overlay, nbr_flags=pending, nbr_ids=nbr, edge_table=ef,
+                       edge_idx=eid, dt=dt, time_w=tw, time_b=tb, q_folded=True, waves_per_query=a.waves)
+    torch.cuda.synchronize()
   _lib.load().orca_debug_tgat_phase_clock(clk.data_ptr())
   ops.tgat_forward(blob, d_e, Q, K, out=out, src_table=memory, src_idx=n32, src_overlay=overlay, src_flags=pending,
                    nbr_table=memory, nbr_idx=nbr, nbr_overlay=overlay, nbr_flags=pending, nbr_ids=nbr, edge_table=ef,
                    edge_idx=eid, dt=dt, time_w=tw, time_b=tb, q_folded=True, waves_per_query=a.waves)
   torch.cuda.synchronize()
   _lib.load().orca_debug_tgat_phase_clock(None)
-  c = clk.view(nwg, 16).cpu().double()
+  c32 = clk[:nwg * 32].view(nwg, 32).cpu().double()
+  ws = clk[nwg * 32:].view(nwg, 16, 8).cpu().double()
+  if float(ws.abs().sum()) > 0:     # the library was built with -DORCA_WAVE_STAMPS
+    t0 = ws[:, :, 0].min(dim=1, keepdim=True).values
+    t4 = ws[:, :, 4].min(dim=1, keepdim=True).values
+    med = lambda x: [int(v) for v in x.median(dim=0).values]
+    print("P2 per wave, cycles from the first wave's entry: entry", med(ws[:, :, 0] - t0))
+    print("   after the chain and its epilogue", med(ws[:, :, 1] - t0))
+    print("   after the row requests", med(ws[:, :, 2] - t0))
+    print("   after the barrier", med(ws[:, :, 3] - t0))
+    print("P4 per wave: entry", med(ws[:, :, 4] - t4))
+    print("   after the chain and its epilogue", med(ws[:, :, 5] - t4))
+    print("   at the barrier", med(ws[:, :, 6] - t4))
+    print("   after the barrier", med(ws[:, :, 7] - t4))
+  c, cyc = c32[:, :16], c32[:, 16:]
   d = (c[:, 1:9] - c[:, 0:8]) / 100.0
+  dc = cyc[:, 1:9] - cyc[:, 0:8]
   names = ["T0 stage", "P1 q-proj", "P2 key fold", "P3 per-query", "P4 folded tail", "P4 reduce", "P7 fc2", "P8 LN"]
   print("tgat phases (median us over workgroups):", {n: round(float(d[:, i].median()), 2) for i, n in enumerate(names)})
+  mhz = ((cyc[:, 8] - cyc[:, 0]) / ((c[:, 8] - c[:, 0]) / 100.0)).median()
+  print("tgat in-kernel clock under load: %.0f MHz; shader cycles per phase (median):" % float(mhz),
+        {n: int(dc[:, i].median()) for i, n in enumerate(names)})
   print("tgat workgroup span us: median", float(((c[:, 8] - c[:, 0]) / 100).median()), "chip span",
         float((c[:, 8].max() - c[:, 0].min()) / 100), " start skew", float((c[:, 0].max() - c[:, 0].min()) / 100))
   if a.attention_only:
