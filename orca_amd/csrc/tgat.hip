@@ -689,10 +689,12 @@ __device__ __forceinline__ void load_key_rows(KeyRows<ME>& R, KeyTimes& T, const
 // column 0 and compute a surplus value: no lane-conditional code)
 template <bool GIVEN_TIMES = true>
 __device__ __forceinline__ void encode_key_times(KeyTimes& T, const orca_tgat_inputs& in, const QuerySlots& S, int j0,
-                                                 int K, int lane, float wa, float ba, float wb, float bb, unsigned own = ~0u) {
+                                                 int K, int lane, float wa, float ba, float wb, float bb, unsigned own = ~0u,
+                                                 int jlo = 0, int jhi = KC) {
   if (GIVEN_TIMES && !in.dt) return;
 #pragma unroll
   for (int j = 0; j < KC; ++j) {
+    if (j < jlo || j >= jhi) continue;       // (constants at the call: the slots of this call)
     if (j0 + j < K && ((own >> j) & 1u)) {
       const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.dt), j0 + j));
       T.ta[j] = orca_cosf(orca_time_arg(d, wa, ba));
@@ -898,6 +900,29 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       m_e[i] = in.edge_table[ec * d_e + (c < d_e ? c : 0)];
     }
   }
+  // The time encodings need only dt (level 1): the first EARLY slots' are computed HERE, under the round trip of level 2 --
+  // behind the touches of level 3, which wait for it, the stage was two round trips and then twenty cosines per lane
+  // (2.2 us of the SIMD's vector time) end to end.
+  // (Same box, per step: none early 75.4 us, five slots 74.8, six 74.5, seven 74.2, eight 74.3, all ten 75.3.)
+  KeyTimes T;
+  float lta[NSL], ltb[NSL];                      // (several waves per query: the encodings of this wave's slots)
+  constexpr int EARLY = NQW == 1 ? 7 : 0;
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (NQW == 1) {
+    if (live_q) encode_key_times<!QK>(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b, ~0u, 0, EARLY);
+  } else {
+#pragma unroll
+    for (int jl = 0; jl < NSL; ++jl) {
+      const int j = qr + NQW * jl;
+      lta[jl] = ltb[jl] = 0.f;
+      if (live_q && j < K) {
+        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.dt), j));
+        lta[jl] = orca_cosf(orca_time_arg(d, tw_a, tb_a));
+        ltb[jl] = orca_cosf(orca_time_arg(d, tw_b, tb_b));
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   if (in.nbr_flags && slot) S.ovl = nf1 ? 1 : 0;
   // source row [src(100) | src_time(100)] of query m = wave and the merger's copy of src
   float sa = 0.f, sb = 0.f, sta = 0.f, stb = 0.f;
@@ -990,22 +1015,9 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
                 blob + L.b_qk + h2 * KPS);
   else
     g1.prefetch(blob4 + L.pw_q / 4, NT200, wave < NT200 ? wave : -1, NW, NT200, lane, blob + L.b_q);
-  // the time encodings of slots 0..KC-1 need only dt: all VALU, computed while the loads above are in flight
-  KeyTimes T;
-  float lta[NSL], ltb[NSL];                      // (several waves per query: the encodings of this wave's slots)
+  // the other slots' time encodings: all VALU, computed while the loads above are in flight
   if constexpr (NQW == 1) {
-    if (live_q) encode_key_times<!QK>(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b);
-  } else {
-#pragma unroll
-    for (int jl = 0; jl < NSL; ++jl) {
-      const int j = qr + NQW * jl;
-      lta[jl] = ltb[jl] = 0.f;
-      if (live_q && j < K) {
-        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.dt), j));
-        lta[jl] = orca_cosf(orca_time_arg(d, tw_a, tb_a));
-        ltb[jl] = orca_cosf(orca_time_arg(d, tw_b, tb_b));
-      }
-    }
+    if (live_q) encode_key_times<!QK>(T, in, S, 0, K, lane, tw_a, tb_a, tw_b, tb_b, ~0u, EARLY, KC);
   }
   if (!lead) { sa = sb = sta = stb = 0.f; }       // (an idle row of the M-tile)
   {
@@ -1379,6 +1391,21 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   const int t4 = big ? (wave >> 1) : 6;
   const int kb4 = big ? (wave & 1) * (L.KBT / 2) : (wave - 12) * (L.KBT / 4);
   const f32x4* pw4 = blob4 + L.pw_t / 4 + ((int64_t)t4 * L.KBT + kb4) * 64;
+  // Small operands of the last stages, requested ahead of the tail's weight stream (behind it, i.e. in front of the barrier
+  // that ends the tail, their issue waited for room in a memory pipe that the other waves' streams keep full: the stage
+  // grew by what the later ones lost).  The winner flag and the id of the fused history push (P8): read where they are
+  // used they were two dependent round trips at the very end of every workgroup.  Without a push the loads go to a valid
+  // address and are ignored (no branch around a load: it would be waited for on the spot).
+  const bool pushing = side.push_table != nullptr;
+  const int64_t pq = (pushing && live_q && lead) ? q : 0;
+  const uint8_t push_win = (pushing ? side.push_winner : reinterpret_cast<const uint8_t*>(blob))[pq];
+  const int64_t push_id = (pushing ? side.push_ids : reinterpret_cast<const int64_t*>(blob))[pq];
+  // The fc1 bias of this thread's two elements of the sum of the tail's partial tiles: read inside that loop it was an L2
+  // round trip between two barriers.
+  static_assert(TQ * 112 <= 2 * NW * 64, "two elements per thread");
+  const int e_a = tid, e_b = tid + NW * 64;
+  const int n_a = e_a % 112, n_b = e_b % 112;
+  const float b1_a = blob[L.b_1 + n_a], b1_b = blob[L.b_1 + n_b];      // (the bias vector is padded to 112 zeros-filled columns)
   WaveGemm<1, 8, KBT_C / 2, true> g4b;
   WaveGemm<1, 8, KBT_C / 4, true> g4s;
   if (big) g4b.prefetch(pw4, L.KBT / 2, 0, 1, 1, lane);
@@ -1403,12 +1430,14 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   __syncthreads();
   wstamp(7);
   stamp();
-  for (int e = tid; e < TQ * 112; e += NW * 64) {
-    const int m = e / 112, n = e - m * 112, t = n >> 4, o = m * 16 + (n & 15);
+  auto sum_parts = [&](int e, int n, float b1) {
+    const int m = e / 112, t = n >> 4, o = m * 16 + (n & 15);
     float v = t < 6 ? part[(2 * t) * 256 + o] + part[(2 * t + 1) * 256 + o]
                     : (part[12 * 256 + o] + part[13 * 256 + o]) + (part[14 * 256 + o] + part[15 * 256 + o]);
-    bufM[m * HSTR + n] = n < D ? fmaxf(v + blob[L.b_1 + n], 0.0f) : 0.0f;
-  }
+    bufM[m * HSTR + n] = n < D ? fmaxf(v + b1, 0.0f) : 0.0f;
+  };
+  sum_parts(e_a, n_a, b1_a);
+  if (e_b < TQ * 112) sum_parts(e_b, n_b, b1_b);
   // ---- P7: y = fc2 h1 + b2 -> bufQ[:, 0:100] -----------------------------------------------------
   __syncthreads();
   stamp();
@@ -1432,10 +1461,9 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     const float oa = da * rstd * ln_ga + ln_ba, ob = db * rstd * ln_gb + ln_bb;
     out[q * D + lane] = oa;
     if (c1 < D) out[q * D + c1] = ob;
-    if (side.push_table && side.push_winner[q]) {   // fused history push of the winner rows (common.h)
-      const int64_t id = side.push_ids[q];
-      side.push_table[id * D + lane] = oa;
-      if (c1 < D) side.push_table[id * D + c1] = ob;
+    if (pushing && push_win) {                      // fused history push of the winner rows (common.h)
+      side.push_table[push_id * D + lane] = oa;
+      if (c1 < D) side.push_table[push_id * D + c1] = ob;
     }
   }
   stamp();
