@@ -166,9 +166,48 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr int pw_tiles(int n) { return (n + 15) / 16; }
 __host__ __device__ constexpr int64_t pw_floats(int N, int Kd) { return (int64_t)pw_tiles(N) * pw_tiles(Kd) * 256; }
 
+// ---- lane exchanges without the LDS --------------------------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32: an LDS round trip (a hundred-odd cycles) per call, and a reduction is a chain of
+// them.  The xor distances a reduction needs all exist as vector instructions on gfx950: quad permutes (1, 2), two masked
+// row shifts (4), a row rotation (8), and the two row / half swaps new in this chip (16, 32).  The swaps exchange between TWO
+// registers -- v_permlane16_swap: the odd rows of a with the even rows of b; v_permlane32_swap: the upper half of a with the
+// lower half of b -- which is exactly a halving step: with a = (what the lanes whose bit is clear keep) and b = (what the
+// others keep), a + b afterwards is `kept + partner's copy` in every lane, without a select.  (Inline asm: the builtins'
+// second result is lost by this compiler -- both elements of the returned pair come out as the first.  The s_nop's stand
+// in for the hazard checks the compiler cannot do inside an asm statement.)
+__device__ __forceinline__ void lanes_swap32(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lanes_swap16(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+template <int CTRL>
+__device__ __forceinline__ float lanes_dpp(float v) {     // a full permutation: every lane receives
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lanes_xor1(float v) { return lanes_dpp<0xB1>(v); }    // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lanes_xor2(float v) { return lanes_dpp<0x4E>(v); }    // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lanes_xor8(float v) { return lanes_dpp<0x128>(v); }   // row_ror:8
+__device__ __forceinline__ float lanes_xor4(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  int x = __builtin_amdgcn_update_dpp(0, iv, 0x104, 0xF, 0x5, false);     // row_shl:4 into lanes 0-3, 8-11 of a row: lane i <- i + 4
+  x = __builtin_amdgcn_update_dpp(x, iv, 0x114, 0xF, 0xA, false);         // row_shr:4 into lanes 4-7, 12-15:       lane i <- i - 4
+  return __builtin_bit_cast(float, x);
+}
+// v + (the value of lane ^ 16) resp. (lane ^ 32), as the butterfly of a reduction takes them
+__device__ __forceinline__ float lanes_add_xor16(float v) { float a = v, b = v; lanes_swap16(a, b); return a + b; }
+__device__ __forceinline__ float lanes_add_xor32(float v) { float a = v, b = v; lanes_swap32(a, b); return a + b; }
+__device__ __forceinline__ float lanes_max_xor16(float v) { float a = v, b = v; lanes_swap16(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float lanes_max_xor32(float v) { float a = v, b = v; lanes_swap32(a, b); return fmaxf(a, b); }
+
+// the sum over the wave in every lane: the same butterfly, distance 32 first, as with __shfl_xor (same bits)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = lanes_add_xor32(v);
+  v = lanes_add_xor16(v);
+  v += lanes_xor8(v);
+  v += lanes_xor4(v);
+  v += lanes_xor2(v);
+  v += lanes_xor1(v);
   return v;
 }
 // cos(x) for the time encoder (model/time_encoding.py:27).  Arguments reach 2.6e6 (Δt in seconds times

@@ -723,32 +723,38 @@ __device__ __forceinline__ int held_slot(int lane) {
 }
 __device__ __forceinline__ float reduce_2xKC(const float (&p0)[KC], const float (&p1)[KC], int lane) {
   static_assert(KC == 10, "the halving schedule below is written for 10 slots");
-  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+  // (every exchange is a vector instruction -- common.h, lane exchanges -- and the two widest steps need no select: the
+  // swap leaves `kept` and `partner's copy` in the two registers)
   float w[10];
 #pragma unroll
-  for (int j = 0; j < 10; ++j) w[j] = (b5 ? p1[j] : p0[j]) + __shfl_xor(b5 ? p0[j] : p1[j], 32, 64);
+  for (int j = 0; j < 10; ++j) { float a = p0[j], b = p1[j]; lanes_swap32(a, b); w[j] = a + b; }
   float x[5];
 #pragma unroll
-  for (int j = 0; j < 5; ++j) x[j] = (b4 ? w[5 + j] : w[j]) + __shfl_xor(b4 ? w[j] : w[5 + j], 16, 64);
+  for (int j = 0; j < 5; ++j) { float a = w[j], b = w[5 + j]; lanes_swap16(a, b); x[j] = a + b; }
   float y[3];
-  y[0] = (b3 ? x[3] : x[0]) + __shfl_xor(b3 ? x[0] : x[3], 8, 64);
-  y[1] = (b3 ? x[4] : x[1]) + __shfl_xor(b3 ? x[1] : x[4], 8, 64);
-  y[2] = (b3 ? 0.f : x[2]) + __shfl_xor(b3 ? x[2] : 0.f, 8, 64);
+  y[0] = (b3 ? x[3] : x[0]) + lanes_xor8(b3 ? x[0] : x[3]);
+  y[1] = (b3 ? x[4] : x[1]) + lanes_xor8(b3 ? x[1] : x[4]);
+  y[2] = (b3 ? 0.f : x[2]) + lanes_xor8(b3 ? x[2] : 0.f);
   float z[2];
-  z[0] = (b2 ? y[2] : y[0]) + __shfl_xor(b2 ? y[0] : y[2], 4, 64);
-  z[1] = (b2 ? 0.f : y[1]) + __shfl_xor(b2 ? y[1] : 0.f, 4, 64);
-  float u = (b1 ? z[1] : z[0]) + __shfl_xor(b1 ? z[0] : z[1], 2, 64);
-  return u + __shfl_xor(u, 1, 64);
+  z[0] = (b2 ? y[2] : y[0]) + lanes_xor4(b2 ? y[0] : y[2]);
+  z[1] = (b2 ? 0.f : y[1]) + lanes_xor4(b2 ? y[1] : 0.f);
+  float u = (b1 ? z[1] : z[0]) + lanes_xor2(b1 ? z[0] : z[1]);
+  return u + lanes_xor1(u);
 }
 __device__ __forceinline__ float half_max(float v) {   // over the 32-lane half this lane is in
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = lanes_max_xor16(v);
+  v = fmaxf(v, lanes_xor8(v));
+  v = fmaxf(v, lanes_xor4(v));
+  v = fmaxf(v, lanes_xor2(v));
+  return fmaxf(v, lanes_xor1(v));
 }
 __device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = lanes_add_xor16(v);
+  v += lanes_xor8(v);
+  v += lanes_xor4(v);
+  v += lanes_xor2(v);
+  return v + lanes_xor1(v);
 }
 
 // KT = compile-time neighbour count (10, the reference's default n_degree: every per-slot predicate and
@@ -1221,7 +1227,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       xb0[tb + lane] = at0; xb1[tb + lane] = at1;
       if (c1 < D) { xb0[tb + c1] = bt0; xb1[tb + c1] = bt1; }
       // constant columns of the tail: each head's value-bias term times its weight sum, the out-projection bias once
-      const float ws1 = __shfl(wsum, 32, 64);
+      const float ws1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wsum), 32));
       if (lane == 0) { xb0[kdim] = wsum; xb1[kdim] = ws1; xb0[2 * KPS + D] = invalid ? 0.f : 1.f; }
       if (side.save_xbar) {
         if (lane == 0) { side.save_wsum[q * 2] = wsum; side.save_wsum[q * 2 + 1] = ws1; }
@@ -1378,7 +1384,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
       total(tb + lane);
       if (c1 < D) total(tb + c1);
       // constant columns of the tail: each head's value-bias term times its weight sum, the out-projection bias once
-      const float ws1 = __shfl(wsum, 32, 64);
+      const float ws1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wsum), 32));
       if (lane == 0) { xb0[kdim] = wsum; xb1[kdim] = ws1; xb0[2 * KPS + D] = (invalid || !live_q) ? 0.f : 1.f; }
     }
   }
