@@ -553,22 +553,25 @@ struct WaveGemm {
   }
 
   // a_row: LDS pointer to this lane's A row (row l&15) already offset by 4*(l>>4) floats.
-  template <typename F>
+  // KBN: the k-blocks this call multiplies (<= KBC: the same prefetched ring serves waves whose pieces differ in length --
+  // two objects, one per length, were merged by the compiler through register copies behind a wait for every load).
+  template <int KBN = KBC, typename F>
   __device__ __forceinline__ void run(const float* a_row, int lane, F epilogue, const float* a_tail = nullptr) {
+    static_assert(KBN <= KBC && (KBC == 0 || KBN >= G), "a piece no longer than the ring was sized for");
     if (nt == 0) return;
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (KBC > 0) {
 #pragma unroll
-      for (int kb = 0; kb < KBC; ++kb) {
+      for (int kb = 0; kb < KBN; ++kb) {
         const int g = kb % G;
         const f32x4 a = *reinterpret_cast<const f32x4*>(a_row + kb * 16);
         f32x4 b[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) b[t] = ring[g][t];
-        if (kb + G < KBC) {
-          if (TAIL1 && kb + G == KBC - 1) {
+        if (kb + G < KBN) {
+          if (TAIL1 && kb + G == KBN - 1) {
             // one word per lane is all the tail step uses; as a dwordx4 whose upper words are dead the three loads
             // were given overlapping registers, and the next LDS read into one of them waited for vmcnt(0)
 #pragma unroll
@@ -580,7 +583,7 @@ struct WaveGemm {
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the refill ahead of the MFMAs (the scheduler sinks it otherwise)
         if constexpr (TAIL1) {
-          if (kb == KBC - 1) {
+          if (kb == KBN - 1) {
             const float at = *a_tail;
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, b[t][0], acc[t], 0, 0, 0);
@@ -1412,18 +1415,21 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   const int e_a = tid, e_b = tid + NW * 64;
   const int n_a = e_a % 112, n_b = e_b % 112;
   const float b1_a = blob[L.b_1 + n_a], b1_b = blob[L.b_1 + n_b];      // (the bias vector is padded to 112 zeros-filled columns)
-  WaveGemm<1, 8, KBT_C / 2, true> g4b;
-  WaveGemm<1, 8, KBT_C / 4, true> g4s;
-  if (big) g4b.prefetch(pw4, L.KBT / 2, 0, 1, 1, lane);
-  else     g4s.prefetch(pw4, L.KBT / 4, 0, 1, 1, lane);
+  WaveGemm<1, 8, KBT_C / 2, true> g4;              // ONE ring for both piece lengths (see WaveGemm::run)
+  g4.prefetch(pw4, big ? L.KBT / 2 : L.KBT / 4, 0, 1, 1, lane);
   __syncthreads();
   stamp();
   {
     const float* a4 = bufT + a_off * RS + a_k + kb4 * 16;
     float* dst = part + wave * 256;
+    auto put = [&](int m, int n, float v) { dst[m * 16 + n] = v; };
     wstamp(4);
-    if (big) g4b.run(a4, lane, [&](int m, int n, float v) { dst[m * 16 + n] = v; });
-    else     g4s.run(a4, lane, [&](int m, int n, float v) { dst[m * 16 + n] = v; });
+    if constexpr (KBT_C > 0) {
+      if (big) g4.template run<KBT_C / 2>(a4, lane, put);
+      else     g4.template run<KBT_C / 4>(a4, lane, put);
+    } else {
+      g4.run(a4, lane, put);
+    }
     wstamp(5);
   }
   WaveGemm<1, 7, 7, true> g7;
