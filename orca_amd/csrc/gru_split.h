@@ -178,6 +178,11 @@ __device__ __forceinline__ void gru_split_workgroup(const float* __restrict__ bl
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) hp[m][r] = h[id_o[m][r] * D + (u < D ? u : 0)];
+    // ... and the message time stamps that become last_update (hidden tile 0 stores them): read where they are stored
+    // they were a dependent round trip at the very end of one workgroup in seven -- the ones the launch then waits for
+    float mts[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) mts[m] = (last_update ? msg_ts : blob)[last_update ? id_a[m] : 0];
     if (phase_clock) clk1 = wall_clock64();
     f32x4 acc[MT][3];
 #pragma unroll
@@ -226,7 +231,7 @@ __device__ __forceinline__ void gru_split_workgroup(const float* __restrict__ bl
             }
           }
         }
-        if (t == 0 && last_update && lane < 16 && r0 + m * 16 + lane < n) last_update[id_a[m]] = msg_ts[id_a[m]];
+        if (t == 0 && last_update && lane < 16 && r0 + m * 16 + lane < n) last_update[id_a[m]] = mts[m];
       }
     }
     __syncthreads();   // `part` is reused by the next tile
