@@ -428,11 +428,16 @@ __global__ __launch_bounds__(1024) void k_owner_list(const int64_t* __restrict__
   bool take = false;
   if (p < n + n / 2) {
     id = nodes[p];
-    if (id >= 0 && id < n_nodes) {
+    const bool ok = id >= 0 && id < n_nodes;
+    // (both election words requested together, from a clamped id: behind the range test and the `counts` test they were
+    // two more dependent round trips)
+    const int64_t idc = ok ? id : 0;
+    const int64_t s_m = slot[idc], s_p = (counts ? slot_push : slot)[idc];
+    if (ok) {
       const int o = (int)((uint32_t)id % (uint32_t)own_world);
-      take = p < n && o == own_rank && slot[id] == epoch + p;
+      take = p < n && o == own_rank && s_m == epoch + p;
       if (counts) {
-        const int64_t w = slot_push[id] - epoch_push;       // last occurrence of the id among [src;dst;neg]
+        const int64_t w = s_p - epoch_push;                 // last occurrence of the id among [src;dst;neg]
         if (p < n && (w == p || w >= n)) owner = o;
         if (w == p) sender = (int)((p % (n / 2)) / per);
       }
@@ -475,30 +480,52 @@ __global__ __launch_bounds__(256) void k_owner_persist_store(
     const float* __restrict__ overlay, float* __restrict__ memory, float* __restrict__ last_update,
     const float* __restrict__ edge_feats, int d_e, const float* __restrict__ tw, const float* __restrict__ tb,
     float* __restrict__ messages, float* __restrict__ msg_ts) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, c1 = lane + 64, cb = c1 < ORCA_D ? c1 : 0;
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= *own_count) return;
+  // A wave per row, and what the row costs is its dependent round trips: the loads go out level by level, both candidates
+  // of every `pending ? a : b` requested and the choice made on the values (a select on the ADDRESS is one more level, a
+  // load behind a branch is waited for where it stands) -- position -> ids, edge, time -> flags, both time stamps, both
+  // candidate rows of id and partner, the edge row -> the stores.  (Written as the reference reads it was seven levels.)
   const int64_t p = own_pos[r];
   const int64_t e = p < bs ? p : p - bs;
+  // level 2
   const int64_t id = nodes[p], partner = nodes[p < bs ? p + bs : p - bs];
-  const bool pend = pending[id] != 0;
-  const bool ppend = partner >= 0 && partner < n_nodes && pending[partner] != 0;
-  const float* ms = (pend ? overlay : memory) + id * ORCA_D;
-  const float* md = (ppend ? overlay : memory) + partner * ORCA_D;
   const float tf = (float)qts[p];                                    // tgn_model.py:181
-  const float lu = pend ? msg_ts[id] : last_update[id];              // memory_updater.py:37
+  const int64_t ei = eidx[e];
+  const bool pok = partner >= 0 && partner < n_nodes;
+  const int64_t pc = pok ? partner : 0;
+  // level 3
+  const uint8_t f_id = pending[id], f_pa = pending[pc];
+  const float t_msg = msg_ts[id], t_lu = last_update[id];
+  const float so_a = overlay[id * ORCA_D + lane], so_b = overlay[id * ORCA_D + cb];
+  const float sm_a = memory[id * ORCA_D + lane], sm_b = memory[id * ORCA_D + cb];
+  const float do_a = overlay[pc * ORCA_D + lane], do_b = overlay[pc * ORCA_D + cb];
+  const float dm_a = memory[pc * ORCA_D + lane], dm_b = memory[pc * ORCA_D + cb];
+  const float* ef = edge_feats + ei * d_e;
+  constexpr int ME = (ORCA_MAX_DE + 63) / 64;
+  float ev[ME];
+#pragma unroll
+  for (int i = 0; i < ME; ++i) { const int c = lane + 64 * i; ev[i] = ef[c < d_e ? c : 0]; }
+  const float w_a = tw[lane], w_b = tw[cb], b_a = tb[lane], b_b = tb[cb];
+  const bool pend = f_id != 0, ppend = pok && f_pa != 0;
+  const float lu = pend ? t_msg : t_lu;                              // memory_updater.py:37
   const float delta = tf - lu;                                       // tgn_model.py:187
   const int msg_dim = 3 * ORCA_D + d_e;
   float* row = messages + id * msg_dim;
-  const float* ef = edge_feats + eidx[e] * d_e;
-  for (int c = lane; c < ORCA_D; c += 64) {
-    const float a = ms[c];
-    row[c] = a;
-    if (pend) memory[id * ORCA_D + c] = a;                           // memory_updater.py:38
-    row[ORCA_D + c] = md[c];
-    row[2 * ORCA_D + d_e + c] = orca_cosf(orca_time_arg(delta, tw[c], tb[c]));   // tgn_model.py:188
+  const float a0 = pend ? so_a : sm_a, a1 = pend ? so_b : sm_b;
+  row[lane] = a0;
+  row[ORCA_D + lane] = ppend ? do_a : dm_a;
+  row[2 * ORCA_D + d_e + lane] = orca_cosf(orca_time_arg(delta, w_a, b_a));       // tgn_model.py:188
+  if (pend) memory[id * ORCA_D + lane] = a0;                         // memory_updater.py:38
+  if (c1 < ORCA_D) {
+    row[c1] = a1;
+    row[ORCA_D + c1] = ppend ? do_b : dm_b;
+    row[2 * ORCA_D + d_e + c1] = orca_cosf(orca_time_arg(delta, w_b, b_b));
+    if (pend) memory[id * ORCA_D + c1] = a1;
   }
-  for (int c = lane; c < d_e; c += 64) row[2 * ORCA_D + c] = ef[c];
+#pragma unroll
+  for (int i = 0; i < ME; ++i) { const int c = lane + 64 * i; if (c < d_e) row[2 * ORCA_D + c] = ev[i]; }
   if (lane == 0) {
     if (pend) last_update[id] = lu;
     msg_ts[id] = tf;
