@@ -145,6 +145,28 @@ def test_time_encode_bias(ops):
   assert_close_fp32(out, O.time_encode(t, w, b).numpy(), 1e-5, "time_encode with bias")
 
 
+def test_time_encode_large_arguments(ops):
+  """cos(t*w + b) for arguments from months to decades of seconds (the reference's datasets reach 2.6e6; Wiki-Talk's and
+  GDELT's spans are far longer), also at the half-integers of x/pi where a rounded n = rint(x/pi) would be off by one:
+  against cos in fp64 of the same fp32 argument (the argument's two roundings as oracle.time_encode defines them),
+  absolute error <= 4e-7.  (orca_cosf reduces in fp64; an fp32 Cody-Waite reduction below |x| = 5e6 passed this test too
+  and was no faster -- fp64 vector instructions run at the fp32 rate on this chip.)"""
+  rs = np.random.RandomState(12)
+  halves = ((np.rint(rs.uniform(0, 5e6 / np.pi, 2000)) + 0.5) * np.pi).astype(np.float32)
+  t = np.concatenate([rs.uniform(0, 5e6, 4000), rs.uniform(4.9e6, 5.1e6, 2000), rs.uniform(5e6, 2e9, 2000), halves,
+                      np.array([0.0, 4999999.5, 5e6, 5000000.5, 1e7, 2.0e9])]).astype(np.float32)
+  t = t[: (t.size // 10) * 10]
+  w = torch.ones(100, dtype=torch.float32)                    # omega = 1: the argument IS t (+ b)
+  w[1::2] = 0.5
+  b = torch.from_numpy(rs.uniform(-3, 3, 100).astype(np.float32))
+  out = ops.time_encode(torch.from_numpy(t).view(-1, 10).to(DEV), w.to(DEV), b.to(DEV)).cpu().numpy().reshape(-1, 100)
+  x = (t.reshape(-1, 1) * w.numpy().reshape(1, -1)).astype(np.float32)      # product rounded, then the sum rounded
+  x = (x + b.numpy().reshape(1, -1)).astype(np.float32)
+  ref = np.cos(x.astype(np.float64))
+  err = np.abs(out.astype(np.float64) - ref)
+  assert err.max() <= 4e-7, f"time_encode: max abs error {err.max():.3e} at argument {x.flat[err.argmax()]!r}"
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["de172_K10_", "de1_K10_", "de4_K20_", "de172_K1_"])
 def test_attention_dense_boundary(ops, golden, tag):
