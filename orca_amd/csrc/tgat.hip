@@ -1484,7 +1484,7 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
 }  // namespace
 
 static long long* g_phase_clock = nullptr;
-// Profiling aid, not part of the product surface: buf = device int64 [n_workgroups * 16] (or NULL to stop);
+// Profiling aid, not part of the product surface: buf = device int64 [n_workgroups * 32] (or NULL to stop; a diagnostic build writes n_workgroups * 16 * 8 more words behind them);
 // later orca_tgat_forward launches stamp their phase boundaries into it.
 ORCA_API int orca_debug_tgat_phase_clock(void* buf) {
   g_phase_clock = (long long*)buf;
