@@ -771,7 +771,14 @@ __device__ __forceinline__ float half_sum(float v) {
 // size, where 600 queries are 38 workgroups on 256 CUs and what a step costs is ONE workgroup's latency: the per-query
 // stages are a quarter as long, and four times as many CUs stream the weights.  K <= KC, gather mode with a folded q, no
 // saving of intermediates; sums over the slots are taken in another order than NQW = 1 (same bars, not the same bits).
-template <int KT, int DE, bool QK, int NQW = 1>
+// PROF: which of the optional inputs and fused writes a launch carries, as a compile-time fact (tgat_profile() on the host
+// picks it from the arguments, 0 = anything goes).  The kernel tests some twenty pointers of orca_tgat_inputs /
+// orca_tgat_side at run time; with the answers known the compiler drops a sixth of the instructions of the bench shape's
+// kernel.  1 = the step driver's first layer (gather mode over the memory table: ids, flags and overlays of source and
+// neighbours, computed times; commits the flagged source rows, pushes its winners' rows; stores no messages); 2 = its
+// last layer (dense source rows, history table without flags; no persist, no push; stores the raw messages).  Neither
+// saves intermediates, returns weights or source rows, applies dropout or has a device-side query count.
+template <int KT, int DE, bool QK, int NQW = 1, int PROF = 0>
 __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restrict__ blob, int d_e_rt,
                                                           orca_tgat_inputs in, int64_t Q, int K_rt,
                                                           float* __restrict__ out, float* __restrict__ out_w,
@@ -798,6 +805,21 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     ++phase_no;
   };
   stamp();
+  if constexpr (PROF != 0) {        // (what tgat_profile() has checked on the host)
+    __builtin_assume(in.nbr_idx != nullptr); __builtin_assume(in.edge_idx != nullptr); __builtin_assume(in.nbr_ids != nullptr);
+    __builtin_assume(in.dt != nullptr); __builtin_assume(side.src_rows_out == nullptr); __builtin_assume(side.save_qt == nullptr);
+    __builtin_assume(side.save_a == nullptr); __builtin_assume(side.save_xbar == nullptr); __builtin_assume(out_w == nullptr);
+    __builtin_assume(!(in.dropout_p > 0.f)); __builtin_assume(side.q_extra == nullptr);
+    if constexpr (PROF == 1) {
+      __builtin_assume(in.src_idx != nullptr); __builtin_assume(in.src_flags != nullptr); __builtin_assume(in.nbr_flags != nullptr);
+      __builtin_assume(side.persist_memory != nullptr); __builtin_assume(side.push_table != nullptr);
+      __builtin_assume(side.store_bs == 0);
+    } else {
+      __builtin_assume(in.src_idx == nullptr); __builtin_assume(in.src_flags == nullptr); __builtin_assume(in.nbr_flags == nullptr);
+      __builtin_assume(side.persist_memory == nullptr); __builtin_assume(side.push_table == nullptr);
+      __builtin_assume(side.store_bs > 0);
+    }
+  }
   if (side.q_extra) {               // block-uniform, ahead of every barrier
     const int64_t lim = side.q_base + *side.q_extra;
     Q = lim < Q ? lim : Q;
@@ -1531,6 +1553,18 @@ ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_input
   return orca_tgat_forward_side(blob, d_e, in, Q, K, out, out_weights, nullptr, stream);
 }
 
+// the PROF of k_tgat_forward a launch may take: every fact that instantiation assumes is checked here
+static int tgat_profile(const orca_tgat_inputs& in, const orca_tgat_side& side, const float* out_weights) {
+  if (getenv("ORCA_TGAT_PROFILES") && getenv("ORCA_TGAT_PROFILES")[0] == '0') return 0;      // (A/B switch)
+  if (!in.nbr_idx || !in.edge_idx || !in.nbr_ids || !in.dt || side.src_rows_out || side.save_qt || side.save_a ||
+      side.save_xbar || out_weights || in.dropout_p > 0.f || side.q_extra)
+    return 0;
+  if (in.src_idx && in.src_flags && in.src_overlay && in.nbr_flags && in.nbr_overlay && side.persist_memory && side.push_table &&
+      side.store_bs == 0)
+    return 1;
+  if (!in.src_idx && !in.src_flags && !in.nbr_flags && !side.persist_memory && !side.push_table && side.store_bs > 0) return 2;
+  return 0;
+}
 int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
                            float* out_weights, const orca_tgat_side* side_, void* stream) {
   const orca_tgat_side side = side_ ? *side_ : orca_tgat_side{};
@@ -1556,7 +1590,8 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
                          (const void*)k_tgat_forward<0, 0, false>,    (const void*)k_tgat_forward<0, 0, true>,
                          (const void*)k_tgat_forward<10, 1, false>,   (const void*)k_tgat_forward<10, 1, true>,
                          (const void*)k_tgat_forward<20, 1, false>,   (const void*)k_tgat_forward<20, 1, true>,
-                         (const void*)k_tgat_forward<10, 172, true, 4>, (const void*)k_tgat_forward<10, 1, true, 4>};
+                         (const void*)k_tgat_forward<10, 172, true, 4>, (const void*)k_tgat_forward<10, 1, true, 4>,
+                         (const void*)k_tgat_forward<10, 172, true, 1, 1>, (const void*)k_tgat_forward<10, 172, true, 1, 2>};
     for (const void* f : fns) ORCA_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
   ORCA_REQUIRE(lds_bytes <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds_bytes);
@@ -1577,6 +1612,21 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
     return ORCA_OK;
   }
   const unsigned grid = (unsigned)ceil_div64(Q, TQ);
+  if (K == 10 && d_e == 172 && (in->q_folded & 1)) {      // the bench shape: the two launches of the step driver as PROF 1 / 2
+    const int prof = tgat_profile(*in, side, out_weights);
+    if (prof == 1) {
+      ORCA_LAUNCH_TIMED((k_tgat_forward<10, 172, true, 1, 1>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights,
+                        side, g_phase_clock);
+      ORCA_LAUNCH_CHECK();
+      return ORCA_OK;
+    }
+    if (prof == 2) {
+      ORCA_LAUNCH_TIMED((k_tgat_forward<10, 172, true, 1, 2>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights,
+                        side, g_phase_clock);
+      ORCA_LAUNCH_CHECK();
+      return ORCA_OK;
+    }
+  }
 #define ORCA_TGAT_LAUNCH(KT_, DE_)                                                                              \
   do {                                                                                                          \
     if (in->q_folded & 1)                                                                                       \
