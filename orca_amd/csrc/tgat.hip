@@ -776,8 +776,9 @@ __device__ __forceinline__ float half_sum(float v) {
 // orca_tgat_side at run time; with the answers known the compiler drops a sixth of the instructions of the bench shape's
 // kernel.  1 = the step driver's first layer (gather mode over the memory table: ids, flags and overlays of source and
 // neighbours, computed times; commits the flagged source rows, pushes its winners' rows; stores no messages); 2 = its
-// last layer (dense source rows, history table without flags; no persist, no push; stores the raw messages).  Neither
-// saves intermediates, returns weights or source rows, applies dropout or has a device-side query count.
+// last layer (dense source rows, history table without flags; no persist, no push; stores the raw messages); 3 = the
+// only layer of a one-layer model (as 1, without the push).  None saves intermediates, returns weights or source rows,
+// applies dropout or has a device-side query count.
 template <int KT, int DE, bool QK, int NQW = 1, int PROF = 0>
 __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restrict__ blob, int d_e_rt,
                                                           orca_tgat_inputs in, int64_t Q, int K_rt,
@@ -810,10 +811,11 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
     __builtin_assume(in.dt != nullptr); __builtin_assume(side.src_rows_out == nullptr); __builtin_assume(side.save_qt == nullptr);
     __builtin_assume(side.save_a == nullptr); __builtin_assume(side.save_xbar == nullptr); __builtin_assume(out_w == nullptr);
     __builtin_assume(!(in.dropout_p > 0.f)); __builtin_assume(side.q_extra == nullptr);
-    if constexpr (PROF == 1) {
+    if constexpr (PROF == 1 || PROF == 3) {
       __builtin_assume(in.src_idx != nullptr); __builtin_assume(in.src_flags != nullptr); __builtin_assume(in.nbr_flags != nullptr);
-      __builtin_assume(side.persist_memory != nullptr); __builtin_assume(side.push_table != nullptr);
-      __builtin_assume(side.store_bs == 0);
+      __builtin_assume(side.persist_memory != nullptr); __builtin_assume(side.store_bs == 0);
+      if constexpr (PROF == 1) __builtin_assume(side.push_table != nullptr);
+      else __builtin_assume(side.push_table == nullptr);
     } else {
       __builtin_assume(in.src_idx == nullptr); __builtin_assume(in.src_flags == nullptr); __builtin_assume(in.nbr_flags == nullptr);
       __builtin_assume(side.persist_memory == nullptr); __builtin_assume(side.push_table == nullptr);
@@ -1559,9 +1561,8 @@ static int tgat_profile(const orca_tgat_inputs& in, const orca_tgat_side& side, 
   if (!in.nbr_idx || !in.edge_idx || !in.nbr_ids || !in.dt || side.src_rows_out || side.save_qt || side.save_a ||
       side.save_xbar || out_weights || in.dropout_p > 0.f || side.q_extra)
     return 0;
-  if (in.src_idx && in.src_flags && in.src_overlay && in.nbr_flags && in.nbr_overlay && side.persist_memory && side.push_table &&
-      side.store_bs == 0)
-    return 1;
+  if (in.src_idx && in.src_flags && in.src_overlay && in.nbr_flags && in.nbr_overlay && side.persist_memory && side.store_bs == 0)
+    return side.push_table ? 1 : 3;
   if (!in.src_idx && !in.src_flags && !in.nbr_flags && !side.persist_memory && !side.push_table && side.store_bs > 0) return 2;
   return 0;
 }
@@ -1591,42 +1592,51 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
                          (const void*)k_tgat_forward<10, 1, false>,   (const void*)k_tgat_forward<10, 1, true>,
                          (const void*)k_tgat_forward<20, 1, false>,   (const void*)k_tgat_forward<20, 1, true>,
                          (const void*)k_tgat_forward<10, 172, true, 4>, (const void*)k_tgat_forward<10, 1, true, 4>,
-                         (const void*)k_tgat_forward<10, 172, true, 1, 1>, (const void*)k_tgat_forward<10, 172, true, 1, 2>};
+#define ORCA_PROFS_OF(KT_, DE_, NQW_)                                                                            \
+  (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 1>, (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 2>,      \
+  (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 3>
+                         ORCA_PROFS_OF(10, 172, 1), ORCA_PROFS_OF(10, 1, 1), ORCA_PROFS_OF(20, 1, 1),
+                         ORCA_PROFS_OF(10, 172, 4), ORCA_PROFS_OF(10, 1, 4)};
+#undef ORCA_PROFS_OF
     for (const void* f : fns) ORCA_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
   ORCA_REQUIRE(lds_bytes <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds_bytes);
   ORCA_REQUIRE(!in->q_folded || in->dt, "orca_tgat_forward: q_folded needs gather-mode time inputs (dt)");
   ORCA_REQUIRE(in->dropout_p >= 0.f && in->dropout_p < 1.f, "orca_tgat_forward: dropout_p=%g outside [0,1)", (double)in->dropout_p);
   hipStream_t st = (hipStream_t)stream;
+  // (q-folded launches of the compile-time shapes take the instantiation of their profile, see k_tgat_forward)
+  const int prof = (in->q_folded & 1) ? tgat_profile(*in, side, out_weights) : 0;
+#define ORCA_TGAT_LAUNCH_PROF(KT_, DE_, NQW_, GRID_, LDS_)                                                        \
+  do {                                                                                                          \
+    switch (prof) {                                                                                             \
+      case 1: ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true, NQW_, 1>), GRID_, NW * 64, LDS_, st, blob, d_e, *in, Q, K, out, \
+                                out_weights, side, g_phase_clock); break;                                       \
+      case 2: ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true, NQW_, 2>), GRID_, NW * 64, LDS_, st, blob, d_e, *in, Q, K, out, \
+                                out_weights, side, g_phase_clock); break;                                       \
+      case 3: ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true, NQW_, 3>), GRID_, NW * 64, LDS_, st, blob, d_e, *in, Q, K, out, \
+                                out_weights, side, g_phase_clock); break;                                       \
+      default: ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true, NQW_>), GRID_, NW * 64, LDS_, st, blob, d_e, *in, Q, K, out,   \
+                                 out_weights, side, g_phase_clock); break;                                      \
+    }                                                                                                           \
+  } while (0)
   if (ORCA_TGAT_WAVES(in->q_folded) == 4 && K == 10 && (d_e == 172 || d_e == 1) && (in->q_folded & 1) && !side.save_qt) {
     const size_t lds4 = lds_bytes + (size_t)(TQ * 2 * L.KP + TQ * 2 * KC) * sizeof(float);     // partial x-bar rows, scores
     ORCA_REQUIRE(lds4 <= 160 * 1024 - 256, "orca_tgat_forward: LDS budget exceeded (%zu B)", lds4);
     const unsigned grid4 = (unsigned)ceil_div64(Q, TQ / 4);
-    if (d_e == 172)
-      ORCA_LAUNCH_TIMED((k_tgat_forward<10, 172, true, 4>), grid4, NW * 64, lds4, st, blob, d_e, *in, Q, K, out, out_weights, side,
-                        g_phase_clock);
-    else
-      ORCA_LAUNCH_TIMED((k_tgat_forward<10, 1, true, 4>), grid4, NW * 64, lds4, st, blob, d_e, *in, Q, K, out, out_weights, side,
-                        g_phase_clock);
+    if (d_e == 172) ORCA_TGAT_LAUNCH_PROF(10, 172, 4, grid4, lds4);
+    else            ORCA_TGAT_LAUNCH_PROF(10, 1, 4, grid4, lds4);
     ORCA_LAUNCH_CHECK();
     return ORCA_OK;
   }
   const unsigned grid = (unsigned)ceil_div64(Q, TQ);
-  if (K == 10 && d_e == 172 && (in->q_folded & 1)) {      // the bench shape: the two launches of the step driver as PROF 1 / 2
-    const int prof = tgat_profile(*in, side, out_weights);
-    if (prof == 1) {
-      ORCA_LAUNCH_TIMED((k_tgat_forward<10, 172, true, 1, 1>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights,
-                        side, g_phase_clock);
-      ORCA_LAUNCH_CHECK();
-      return ORCA_OK;
-    }
-    if (prof == 2) {
-      ORCA_LAUNCH_TIMED((k_tgat_forward<10, 172, true, 1, 2>), grid, NW * 64, lds_bytes, st, blob, d_e, *in, Q, K, out, out_weights,
-                        side, g_phase_clock);
-      ORCA_LAUNCH_CHECK();
-      return ORCA_OK;
-    }
+  if ((in->q_folded & 1) && prof != 0 && ((K == 10 && (d_e == 172 || d_e == 1)) || (K == 20 && d_e == 1))) {
+    if (K == 10 && d_e == 172) ORCA_TGAT_LAUNCH_PROF(10, 172, 1, grid, lds_bytes);
+    else if (K == 10)          ORCA_TGAT_LAUNCH_PROF(10, 1, 1, grid, lds_bytes);
+    else                       ORCA_TGAT_LAUNCH_PROF(20, 1, 1, grid, lds_bytes);
+    ORCA_LAUNCH_CHECK();
+    return ORCA_OK;
   }
+#undef ORCA_TGAT_LAUNCH_PROF
 #define ORCA_TGAT_LAUNCH(KT_, DE_)                                                                              \
   do {                                                                                                          \
     if (in->q_folded & 1)                                                                                       \
