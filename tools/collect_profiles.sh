@@ -19,9 +19,10 @@ head = open(md).read().split("## pass 1")[0]
 fetch, write = open("gpurun_out/prof/pmc_fetch.md").read(), open("gpurun_out/prof/pmc_write.md").read()
 open(md, "w").write(head + "## pass 1 (FETCH_SIZE)\n\n" + fetch + "\n## pass 2 (WRITE_SIZE)\n\n" + write)
 j = json.load(open("tools/pmc_traffic.json"))
-def val(text, kernel, counter):
-  m = re.search(r"\| [^|]*" + re.escape(kernel) + r"[^|]*\| " + counter + r" \| ([0-9.]+) \| (\d+) \|", text)
-  return float(m.group(1)), int(m.group(2))
+def val(text, kernel, counter):     # mean per dispatch over every instantiation whose name starts like `kernel`
+  rows = re.findall(r"\| [^|]*" + re.escape(kernel) + r"[^|]*\| " + counter + r" \| ([0-9.]+) \| (\d+) \|", text)
+  n = sum(int(c) for _, c in rows)
+  return round(sum(float(v) * int(c) for v, c in rows) / n, 1), n
 for key, name in (("k_tgat_forward", "k_tgat_forward<10, 172, true"), ("k_gru_split", "k_gru_split<472"), ("k_begin_queries", "k_begin_queries<0, 1>")):
   f, n = val(fetch, name, "FETCH_SIZE")
   w, _ = val(write, name, "WRITE_SIZE")
