@@ -1557,7 +1557,8 @@ ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_input
 
 // the PROF of k_tgat_forward a launch may take: every fact that instantiation assumes is checked here
 static int tgat_profile(const orca_tgat_inputs& in, const orca_tgat_side& side, const float* out_weights) {
-  if (getenv("ORCA_TGAT_PROFILES") && getenv("ORCA_TGAT_PROFILES")[0] == '0') return 0;      // (A/B switch)
+  static const bool off = getenv("ORCA_TGAT_PROFILES") && getenv("ORCA_TGAT_PROFILES")[0] == '0';      // (A/B switch)
+  if (off) return 0;
   if (!in.nbr_idx || !in.edge_idx || !in.nbr_ids || !in.dt || side.src_rows_out || side.save_qt || side.save_a ||
       side.save_xbar || out_weights || in.dropout_p > 0.f || side.q_extra)
     return 0;
