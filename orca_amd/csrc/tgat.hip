@@ -772,13 +772,14 @@ __device__ __forceinline__ float half_sum(float v) {
 // stages are a quarter as long, and four times as many CUs stream the weights.  K <= KC, gather mode with a folded q, no
 // saving of intermediates; sums over the slots are taken in another order than NQW = 1 (same bars, not the same bits).
 // PROF: which of the optional inputs and fused writes a launch carries, as a compile-time fact (tgat_profile() on the host
-// picks it from the arguments, 0 = anything goes).  The kernel tests some twenty pointers of orca_tgat_inputs /
+// derives it from the arguments; 0 = anything goes).  The kernel tests some twenty pointers of orca_tgat_inputs /
 // orca_tgat_side at run time; with the answers known the compiler drops a sixth of the instructions of the bench shape's
-// kernel.  1 = the step driver's first layer (gather mode over the memory table: ids, flags and overlays of source and
-// neighbours, computed times; commits the flagged source rows, pushes its winners' rows; stores no messages); 2 = its
-// last layer (dense source rows, history table without flags; no persist, no push; stores the raw messages); 3 = the
-// only layer of a one-layer model (as 1, without the push).  None saves intermediates, returns weights or source rows,
-// applies dropout or has a device-side query count.
+// kernel.  A profile is 16 + a set of bits: 1 = gather mode over the memory table with ids, flags and overlays of source
+// and neighbours (a first layer; without it: dense source rows and a flag-less neighbour table, a later layer), 2 = commits
+// the flagged source rows (persist), 4 = pushes its winners' rows, 8 = stores the raw messages.  All profiles: neighbour,
+// edge and id arrays and computed times given; no saved intermediates, attention weights, source rows out, dropout or
+// device-side query count.  Instantiated: 16|7 the step driver's first layer of several, 16|3 the only layer of a
+// one-layer model, 16|8 its last layer, 16|1 and 16|0 the first and later layers of the owner-computes (multi-rank) step.
 template <int KT, int DE, bool QK, int NQW = 1, int PROF = 0>
 __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restrict__ blob, int d_e_rt,
                                                           orca_tgat_inputs in, int64_t Q, int K_rt,
@@ -807,20 +808,19 @@ __global__ __launch_bounds__(NW * 64) void k_tgat_forward(const float* __restric
   };
   stamp();
   if constexpr (PROF != 0) {        // (what tgat_profile() has checked on the host)
+    static_assert((PROF & ~15) == 16, "16 + profile bits");
     __builtin_assume(in.nbr_idx != nullptr); __builtin_assume(in.edge_idx != nullptr); __builtin_assume(in.nbr_ids != nullptr);
     __builtin_assume(in.dt != nullptr); __builtin_assume(side.src_rows_out == nullptr); __builtin_assume(side.save_qt == nullptr);
     __builtin_assume(side.save_a == nullptr); __builtin_assume(side.save_xbar == nullptr); __builtin_assume(out_w == nullptr);
     __builtin_assume(!(in.dropout_p > 0.f)); __builtin_assume(side.q_extra == nullptr);
-    if constexpr (PROF == 1 || PROF == 3) {
+    if constexpr (PROF & 1) {
       __builtin_assume(in.src_idx != nullptr); __builtin_assume(in.src_flags != nullptr); __builtin_assume(in.nbr_flags != nullptr);
-      __builtin_assume(side.persist_memory != nullptr); __builtin_assume(side.store_bs == 0);
-      if constexpr (PROF == 1) __builtin_assume(side.push_table != nullptr);
-      else __builtin_assume(side.push_table == nullptr);
     } else {
       __builtin_assume(in.src_idx == nullptr); __builtin_assume(in.src_flags == nullptr); __builtin_assume(in.nbr_flags == nullptr);
-      __builtin_assume(side.persist_memory == nullptr); __builtin_assume(side.push_table == nullptr);
-      __builtin_assume(side.store_bs > 0);
     }
+    if constexpr (PROF & 2) __builtin_assume(side.persist_memory != nullptr); else __builtin_assume(side.persist_memory == nullptr);
+    if constexpr (PROF & 4) __builtin_assume(side.push_table != nullptr); else __builtin_assume(side.push_table == nullptr);
+    if constexpr (PROF & 8) __builtin_assume(side.store_bs > 0); else __builtin_assume(side.store_bs == 0);
   }
   if (side.q_extra) {               // block-uniform, ahead of every barrier
     const int64_t lim = side.q_base + *side.q_extra;
@@ -1555,17 +1555,18 @@ ORCA_API int orca_tgat_forward(const float* blob, int d_e, const orca_tgat_input
   return orca_tgat_forward_side(blob, d_e, in, Q, K, out, out_weights, nullptr, stream);
 }
 
-// the PROF of k_tgat_forward a launch may take: every fact that instantiation assumes is checked here
+// the PROF of k_tgat_forward a launch may take (0: none): every fact that instantiation assumes is checked here
 static int tgat_profile(const orca_tgat_inputs& in, const orca_tgat_side& side, const float* out_weights) {
   static const bool off = getenv("ORCA_TGAT_PROFILES") && getenv("ORCA_TGAT_PROFILES")[0] == '0';      // (A/B switch)
   if (off) return 0;
   if (!in.nbr_idx || !in.edge_idx || !in.nbr_ids || !in.dt || side.src_rows_out || side.save_qt || side.save_a ||
-      side.save_xbar || out_weights || in.dropout_p > 0.f || side.q_extra)
+      side.save_xbar || out_weights || in.dropout_p > 0.f || side.q_extra || side.store_bs < 0)
     return 0;
-  if (in.src_idx && in.src_flags && in.src_overlay && in.nbr_flags && in.nbr_overlay && side.persist_memory && side.store_bs == 0)
-    return side.push_table ? 1 : 3;
-  if (!in.src_idx && !in.src_flags && !in.nbr_flags && !side.persist_memory && !side.push_table && side.store_bs > 0) return 2;
-  return 0;
+  const bool all = in.src_idx && in.src_flags && in.src_overlay && in.nbr_flags && in.nbr_overlay;
+  const bool none = !in.src_idx && !in.src_flags && !in.nbr_flags;
+  if (!all && !none) return 0;
+  const int bits = (all ? 1 : 0) | (side.persist_memory ? 2 : 0) | (side.push_table ? 4 : 0) | (side.store_bs > 0 ? 8 : 0);
+  return (bits == 7 || bits == 3 || bits == 8 || bits == 1 || bits == 0) ? 16 | bits : 0;      // the instantiated ones
 }
 int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* in, int64_t Q, int K, float* out,
                            float* out_weights, const orca_tgat_side* side_, void* stream) {
@@ -1594,8 +1595,9 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
                          (const void*)k_tgat_forward<20, 1, false>,   (const void*)k_tgat_forward<20, 1, true>,
                          (const void*)k_tgat_forward<10, 172, true, 4>, (const void*)k_tgat_forward<10, 1, true, 4>,
 #define ORCA_PROFS_OF(KT_, DE_, NQW_)                                                                            \
-  (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 1>, (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 2>,      \
-  (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 3>
+  (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 16 | 7>, (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 16 | 3>, \
+  (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 16 | 8>, (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 16 | 1>, \
+  (const void*)k_tgat_forward<KT_, DE_, true, NQW_, 16 | 0>
                          ORCA_PROFS_OF(10, 172, 1), ORCA_PROFS_OF(10, 1, 1), ORCA_PROFS_OF(20, 1, 1),
                          ORCA_PROFS_OF(10, 172, 4), ORCA_PROFS_OF(10, 1, 4)};
 #undef ORCA_PROFS_OF
@@ -1607,17 +1609,18 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
   hipStream_t st = (hipStream_t)stream;
   // (q-folded launches of the compile-time shapes take the instantiation of their profile, see k_tgat_forward)
   const int prof = (in->q_folded & 1) ? tgat_profile(*in, side, out_weights) : 0;
+#define ORCA_TGAT_LAUNCH_P1(KT_, DE_, NQW_, P_, GRID_, LDS_)                                                      \
+  ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true, NQW_, P_>), GRID_, NW * 64, LDS_, st, blob, d_e, *in, Q, K, out, out_weights, \
+                    side, g_phase_clock)
 #define ORCA_TGAT_LAUNCH_PROF(KT_, DE_, NQW_, GRID_, LDS_)                                                        \
   do {                                                                                                          \
     switch (prof) {                                                                                             \
-      case 1: ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true, NQW_, 1>), GRID_, NW * 64, LDS_, st, blob, d_e, *in, Q, K, out, \
-                                out_weights, side, g_phase_clock); break;                                       \
-      case 2: ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true, NQW_, 2>), GRID_, NW * 64, LDS_, st, blob, d_e, *in, Q, K, out, \
-                                out_weights, side, g_phase_clock); break;                                       \
-      case 3: ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true, NQW_, 3>), GRID_, NW * 64, LDS_, st, blob, d_e, *in, Q, K, out, \
-                                out_weights, side, g_phase_clock); break;                                       \
-      default: ORCA_LAUNCH_TIMED((k_tgat_forward<KT_, DE_, true, NQW_>), GRID_, NW * 64, LDS_, st, blob, d_e, *in, Q, K, out,   \
-                                 out_weights, side, g_phase_clock); break;                                      \
+      case 16 | 7: ORCA_TGAT_LAUNCH_P1(KT_, DE_, NQW_, 16 | 7, GRID_, LDS_); break;                             \
+      case 16 | 3: ORCA_TGAT_LAUNCH_P1(KT_, DE_, NQW_, 16 | 3, GRID_, LDS_); break;                             \
+      case 16 | 8: ORCA_TGAT_LAUNCH_P1(KT_, DE_, NQW_, 16 | 8, GRID_, LDS_); break;                             \
+      case 16 | 1: ORCA_TGAT_LAUNCH_P1(KT_, DE_, NQW_, 16 | 1, GRID_, LDS_); break;                             \
+      case 16 | 0: ORCA_TGAT_LAUNCH_P1(KT_, DE_, NQW_, 16 | 0, GRID_, LDS_); break;                             \
+      default: ORCA_TGAT_LAUNCH_P1(KT_, DE_, NQW_, 0, GRID_, LDS_); break;                                      \
     }                                                                                                           \
   } while (0)
   if (ORCA_TGAT_WAVES(in->q_folded) == 4 && K == 10 && (d_e == 172 || d_e == 1) && (in->q_folded & 1) && !side.save_qt) {
@@ -1638,6 +1641,7 @@ int orca_tgat_forward_side(const float* blob, int d_e, const orca_tgat_inputs* i
     return ORCA_OK;
   }
 #undef ORCA_TGAT_LAUNCH_PROF
+#undef ORCA_TGAT_LAUNCH_P1
 #define ORCA_TGAT_LAUNCH(KT_, DE_)                                                                              \
   do {                                                                                                          \
     if (in->q_folded & 1)                                                                                       \
